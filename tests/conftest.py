@@ -1,0 +1,45 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'zero-inflated-gp_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def make_problem(N, M, D, seed=0, Mg=None, ell=0.3, u_scale=0.5):
+    """Seeded synthetic zero-inflated regression problem + parameter dict (generator of SURVEY.md section 8d)."""
+    rs = np.random.RandomState(seed)
+    X = rs.rand(N, D)
+    f = np.sin(2 * np.pi * X[:, 0]) * np.cos(2 * np.pi * X[:, min(1, D - 1)]) + X[:, D - 1]
+    g = 2 * np.sin(2 * np.pi * (X[:, 0] + X[:, D - 1]))
+    Y = np.where(g + rs.randn(N) > 0, f + 0.1 * rs.randn(N), 0.0)[:, None]
+    Mg = M if Mg is None else Mg
+    rz = np.random.RandomState(seed + 1)
+    ru = np.random.RandomState(seed + 2)
+    p = dict(Zf=rz.rand(M, D), Zg=rz.rand(Mg, D),
+             u_fm=u_scale * ru.randn(M, 1), u_gm=u_scale * ru.randn(Mg, 1),
+             u_fs_sqrt=0.3 + ru.rand(M, 1), u_gs_sqrt=0.3 + ru.rand(Mg, 1),
+             ell_f=np.full(D, ell) * (1 + 0.1 * np.arange(D)), ell_g=np.full(D, ell * 1.3) * (1 + 0.05 * np.arange(D)),
+             var_f=1.0, var_g=5.0, noise=0.01)
+    return X, Y, p
+
+
+@pytest.fixture(scope='session')
+def engine():
+    import zigp
+    e = zigp.DenseEngine(0)
+    yield e
+    e.close()
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))

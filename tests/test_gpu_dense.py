@@ -1,0 +1,174 @@
+"""GPU parity of the dense ELBO path (predict 9-tuple, ELBO, KL, full gradient) against the CPU oracle.
+
+Tolerances: north_star asks for 1e-6 relative (fp64) on ELBO and predictive mean/var; the tests use
+tighter bounds where cond(Kuu) allows and print cond(Kuu) next to each case."""
+import numpy as np
+import pytest
+
+from conftest import make_problem, relerr
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, M, Mg, D, ell, chunk, u_scale
+    (450, 9, 9, 1, 2.0, None, 0.5),        # cfg1-like (notebook: 9 inducing points)
+    (450, 50, 50, 1, 2.0, None, 0.01),     # cfg1 of BASELINE.json (M=50): cond(Kuu)~2e7, u_m at the reference's init scale (OnOffSVGP.py:56-57)
+    (2048, 128, 128, 3, 0.3, None, 0.5),   # cut-down cfg2
+    (3000, 200, 136, 3, 0.25, 1024, 0.5),  # ragged: M not a multiple of 128, Mf != Mg, 3 chunks with a partial last one
+    (1500, 300, 300, 2, 0.2, 1024, 0.5),
+]
+
+
+def _cond(p, jitter):
+    import zigp_oracle as o
+    K = o.rbf_K(p['Zf'], None, p['ell_f'], p['var_f']) + jitter * np.eye(p['Zf'].shape[0])
+    return np.linalg.cond(K)
+
+
+@pytest.mark.parametrize('N,M,Mg,D,ell,chunk,us', CASES)
+def test_predict_matches_oracle(engine, N, M, Mg, D, ell, chunk, us):
+    import zigp_oracle as o
+    X, Y, p = make_problem(N, M, D, seed=N + M, Mg=Mg, ell=ell, u_scale=us)
+    if D == 1:
+        X = X * 10.0
+        p['Zf'] *= 10.0
+        p['Zg'] *= 10.0
+    engine.set_chunk(chunk or 16384)
+    for g_off in (0.0, -1.0):
+        out = engine.predict(p, X, jitter=1e-6, g_offset=g_off)
+        ref = o.build_predict(X, p, 1e-6, g_off)
+        c = _cond(p, 1e-6)
+        tol = max(1e-9, 1e-13 * c)
+        for i, name in enumerate(('gfmean', 'gfvar', 'gfmeanu', 'fmean', 'fvar', 'gmean', 'gvar', 'ephi_g', 'evar_phi_g')):
+            e = relerr(out[i], ref[i].reshape(-1))
+            print('cond(Kuu)=%.2e %s relerr=%.2e' % (c, name, e))
+            assert e < min(tol, 1e-6), (name, e, c)
+
+
+@pytest.mark.parametrize('N,M,Mg,D,ell,chunk,us', CASES)
+def test_elbo_and_gradient_match_oracle(engine, N, M, Mg, D, ell, chunk, us):
+    import zigp_oracle_torch as ot
+    X, Y, p = make_problem(N, M, D, seed=N + M, Mg=Mg, ell=ell, u_scale=us)
+    if D == 1:
+        X = X * 10.0
+        p['Zf'] *= 10.0
+        p['Zg'] *= 10.0
+    engine.set_chunk(chunk or 16384)
+    engine.set_data(X, Y)
+    scale = 1.7
+    ed, kl, g = engine.elbo(p, jitter=1e-6, scale=scale, g_offset=0.0)
+    elbo_r, data_r, kl_r, g_r = ot.elbo_and_grad(X, Y, p, 1e-6, scale=scale, chunk=1000)
+    c = _cond(p, 1e-6)
+    print('cond(Kuu)=%.2e elbo %.10e ref %.10e' % (c, ed - kl, elbo_r))
+    assert abs(ed - scale * data_r) <= 1e-7 * abs(scale * data_r)
+    assert abs(kl - kl_r) <= 1e-8 * abs(kl_r)
+    assert abs((ed - kl) - elbo_r) <= 1e-7 * abs(elbo_r)
+    for k in ot.PARAM_KEYS:
+        a, b = np.asarray(g[k]).reshape(-1), np.asarray(g_r[k]).reshape(-1)
+        e = np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+        print('  grad %-10s relerr %.2e (max |ref| %.3e)' % (k, e, np.max(np.abs(b))))
+        assert e < max(1e-6, 1e-13 * c), (k, e)
+
+
+def test_value_only_and_no_kl(engine):
+    import zigp_oracle as o
+    X, Y, p = make_problem(1000, 64, 3, seed=5)
+    engine.set_chunk(16384)
+    engine.set_data(X, Y)
+    ed, kl, g = engine.elbo(p, need_grad=False)
+    assert g is None
+    e_r, d_r, klf, klg = o.elbo(X, Y, p, 1e-6)
+    assert abs(ed - d_r) < 1e-8 * abs(d_r) and abs(kl - (klf + klg)) < 1e-9 * abs(klf + klg)
+    ed2, kl2, _ = engine.elbo(p, include_kl=False, need_grad=False)
+    assert kl2 == 0.0 and ed2 == ed
+    assert np.allclose(engine.prior_kl(p), [klf, klg], rtol=1e-9)
+
+
+def test_row_shards_sum_to_full(engine):
+    """Data-parallel invariance: shard partials + KL once == full-batch step."""
+    X, Y, p = make_problem(4096, 128, 3, seed=11)
+    engine.set_chunk(1024)
+    engine.set_data(X, Y)
+    ed, kl, g = engine.elbo(p)
+    parts = [engine.elbo(p, rows=(0, 1500), include_kl=True), engine.elbo(p, rows=(1500, 4096), include_kl=False)]
+    assert abs(sum(q[0] for q in parts) - ed) < 1e-11 * abs(ed)
+    assert parts[0][1] == kl and parts[1][1] == 0.0
+    for k in g:
+        s = np.asarray(parts[0][2][k]) + np.asarray(parts[1][2][k])
+        assert np.max(np.abs(s - np.asarray(g[k]))) <= 1e-9 * max(np.max(np.abs(np.asarray(g[k]))), 1e-300), k
+
+
+def test_bit_stable_run_to_run(engine):
+    X, Y, p = make_problem(3000, 128, 3, seed=3)
+    engine.set_chunk(1024)
+    engine.set_data(X, Y)
+    a = engine.elbo(p)
+    b = engine.elbo(p)
+    assert a[0] == b[0] and a[1] == b[1]
+    for k in a[2]:
+        assert np.array_equal(np.asarray(a[2][k]), np.asarray(b[2][k]))
+
+
+def test_not_pd_raises(engine):
+    import zigp
+    X, Y, p = make_problem(500, 32, 3, seed=1)
+    p['Zf'][5, 0] = np.nan   # NaN pivot: tf.cholesky fails on such a Kuu too
+    engine.set_data(X, Y)
+    with pytest.raises(zigp.NotPositiveDefiniteError):
+        engine.elbo(p, jitter=0.0)
+    p['Zf'][5, 0] = 0.5       # the context recovers
+    assert np.isfinite(engine.elbo(p, need_grad=False)[0])
+
+
+def test_bad_arguments(engine):
+    X, Y, p = make_problem(100, 16, 3, seed=1)
+    engine.set_data(X, Y)
+    q = dict(p)
+    q['var_f'] = -1.0
+    with pytest.raises(ValueError):
+        engine.elbo(q)
+    with pytest.raises(ValueError):
+        engine.elbo(p, rows=(0, 101))
+    with pytest.raises(ValueError):
+        engine.set_chunk(1000)
+
+
+def _longdouble_conditional(Xnew, Z, ell, var, q_mu, q_sqrt, jitter):
+    """80-bit evaluation of the same formulas (onofftf/main.py:257-305) -- 'truth' for the ill-conditioned case."""
+    ld = np.longdouble
+    Xn, Zs = (Xnew / ell).astype(ld), (Z / ell).astype(ld)
+    def K(A, B):
+        d2 = ((A[:, None, :] - B[None, :, :]) ** 2).sum(-1)
+        return ld(var) * np.exp(-d2 / 2)
+    M = Z.shape[0]
+    Kmm = K(Zs, Zs) + ld(jitter) * np.eye(M, dtype=ld)
+    Kmn = K(Zs, Xn)
+    L = np.zeros((M, M), dtype=ld)
+    for j in range(M):
+        L[j, j] = np.sqrt(Kmm[j, j] - (L[j, :j] ** 2).sum())
+        L[j + 1:, j] = (Kmm[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+    A = np.zeros_like(Kmn)
+    for i in range(M):
+        A[i] = (Kmn[i] - L[i, :i] @ A[:i]) / L[i, i]
+    fvar = ld(var) - (A ** 2).sum(0)
+    B = np.zeros_like(A)
+    for i in range(M - 1, -1, -1):
+        B[i] = (A[i] - L[i + 1:, i] @ B[i + 1:]) / L[i, i]
+    fmean = B.T @ q_mu.reshape(-1).astype(ld)
+    fvar = fvar + ((B * q_sqrt.reshape(-1, 1).astype(ld)) ** 2).sum(0)
+    return fmean, fvar
+
+
+def test_ill_conditioned_accuracy_vs_extended_precision(engine):
+    """cond(Kuu) ~ 2e7 with a rough u_m: GPU and oracle both drift from 80-bit truth; the GPU W-form
+    (explicit triangular inverse + GEMMs) must not be meaningfully worse than the oracle's triangular solves."""
+    import zigp_oracle as o
+    X, Y, p = make_problem(450, 50, 1, seed=500, ell=2.0, u_scale=0.5)
+    X, p['Zf'], p['Zg'] = X * 10.0, p['Zf'] * 10.0, p['Zg'] * 10.0
+    tm, tv = _longdouble_conditional(X, p['Zf'], p['ell_f'], p['var_f'], p['u_fm'], p['u_fs_sqrt'], 1e-6)
+    out = engine.predict(p, X, jitter=1e-6)
+    ref = o.build_predict(X, p, 1e-6)
+    e_gpu_m, e_orc_m = relerr(out[3], tm.astype(np.float64)), relerr(ref[3].reshape(-1), tm.astype(np.float64))
+    e_gpu_v, e_orc_v = relerr(out[4], tv.astype(np.float64)), relerr(ref[4].reshape(-1), tv.astype(np.float64))
+    print('fmean: gpu %.2e oracle %.2e ; fvar: gpu %.2e oracle %.2e' % (e_gpu_m, e_orc_m, e_gpu_v, e_orc_v))
+    assert e_gpu_m < 10 * e_orc_m + 1e-9 and e_gpu_v < 10 * e_orc_v + 1e-9

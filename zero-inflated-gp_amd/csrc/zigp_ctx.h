@@ -1,0 +1,142 @@
+// Context, error handling, device-buffer and profiling helpers shared by the dense and Kronecker paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/zigp.h"
+#include "zigp_gemm.h"
+
+namespace zigp {
+
+struct DevBuf {
+  double* p = nullptr;
+  size_t cap = 0;  // doubles
+  int ensure(size_t n) {
+    if (n <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipMalloc((void**)&p, n * sizeof(double));
+    if (e != hipSuccess) return -1;
+    cap = n;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+enum ProfClass { PC_GEMM = 0, PC_SYR2K = 1, PC_KUF = 2, PC_POINT = 3, PC_RED = 4, PC_MXM = 5, PC_OTHER = 6 };
+
+struct TileList {
+  GemmTile* d = nullptr;
+  int n = 0;
+};
+
+// Per-latent (f or g) device state of the dense path
+struct Latent {
+  int M = 0, Mp = 0;
+  DevBuf Z, ell, u, s, s2;              // Z (Mp,D) zero padded; u,s,s2 (Mp) zero padded
+  double var = 1.0;
+  DevBuf Kuu, L, W;                      // (Mp,Mp)
+  DevBuf K, A1, A2;                      // chunk panels [Mp][Nc]
+  DevBuf part;                           // colred partials [2][MSPLIT][Nc]
+  DevBuf gm, gv;                         // cotangents of mean / var per column [Nc]
+  DevBuf du, dsq, krow;                  // row accumulators: du[Mp], dsq[Mp], krow[Mp][1+2D]
+  DevBuf dLpart;                         // [S][Mp*Mp] split-K partials of the rank-N updates
+  DevBuf T1, T2, T3, G;                  // MxM scratch
+  DevBuf vec;                            // small vectors: v=W u [Mp], alpha [Mp], dkinv [Mp], scal[8]
+};
+
+}  // namespace zigp
+
+struct zigp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int info = 0;
+  int64_t chunk = 16384;
+  // data
+  const double* dX = nullptr; const double* dY = nullptr;
+  zigp::DevBuf ownX, ownY;
+  int64_t N = 0; int D = 0;
+  // dense path state
+  zigp::Latent lat[2];
+  zigp::DevBuf E, dA1, F;               // shared backward panels [Mp][Nc]
+  zigp::DevBuf pw_part;                 // pointwise block partials
+  zigp::DevBuf out9;                    // predict outputs (9,Nc)
+  zigp::DevBuf scratch, scratch2;       // misc
+  int* d_info = nullptr;
+  std::map<std::string, zigp::TileList> tiles;
+  // profiling
+  bool prof_on = false;
+  double prof_ms[ZIGP_NCLASS] = {0};
+  int64_t prof_n[ZIGP_NCLASS] = {0};
+  double prof_flops[ZIGP_NCLASS] = {0};
+  struct PendingEv { hipEvent_t a, b; int cls; };
+  std::vector<PendingEv> pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace zigp {
+
+#define ZIGP_HIP(ctx, expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      char _b[512];                                                                      \
+      snprintf(_b, sizeof(_b), "HIP error '%s' at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+      (ctx)->err = _b;                                                                   \
+      return ZIGP_EHIP;                                                                  \
+    }                                                                                    \
+  } while (0)
+
+#define ZIGP_TRY(expr)            \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != 0) return _rc;     \
+  } while (0)
+
+#define ZIGP_ENSURE(ctx, buf, n)                                        \
+  do {                                                                  \
+    if ((buf).ensure((size_t)(n)) != 0) {                               \
+      (ctx)->err = "hipMalloc failed for " #buf;                        \
+      return ZIGP_EHIP;                                                 \
+    }                                                                   \
+  } while (0)
+
+inline int fail_arg(zigp_ctx* c, const char* msg) { c->err = msg; return ZIGP_EARG; }
+
+// RAII-less profiling bracket: call prof_begin before and prof_end after a group of launches.
+struct ProfScope {
+  zigp_ctx* c; hipEvent_t a = nullptr, b = nullptr; int cls; bool on;
+  static hipEvent_t get_ev(zigp_ctx* c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; return e;
+  }
+  ProfScope(zigp_ctx* c_, int cls_, double flops = 0.0) : c(c_), cls(cls_), on(c_->prof_on) {
+    if (!on) return;
+    a = get_ev(c); b = get_ev(c);
+    if (!a || !b) { on = false; return; }
+    (void)hipEventRecord(a, c->stream);
+    c->prof_flops[cls] += flops;
+    c->prof_n[cls] += 1;
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({a, b, cls});
+  }
+};
+
+inline void prof_collect(zigp_ctx* c) {
+  for (auto& p : c->pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->prof_ms[p.cls] += ms;
+    c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b);
+  }
+  c->pending.clear();
+}
+
+}  // namespace zigp

@@ -1,0 +1,703 @@
+// Dense zero-inflated-GP ELBO path: host orchestration + C-ABI (include/zigp.h).
+//
+// Per ELBO step (value + gradient), for each latent h in {f, g}:
+//   MxM stage   Kuu = k(Z,Z)+jitter I ; L = chol(Kuu) ; W = L^-1                    (OnOffSVGP.py:96-97, main.py:267-268)
+//   per chunk   K = k(Z, Xc) ; A1 = W K ; A2 = W^T A1 ; column sums -> mean, var      (main.py:266-303)
+//               point-wise probit / likelihood / reverse pass                         (OnOffSVGP.py:168-204, OnOffLikelihood.py:30-32)
+//               E = W dA2 ; dA1 = E - 2 gv A1 ; F = W^T dA1                           (reverse of the two triangular solves)
+//               dL -= tril(F A1^T + A2 E^T) ; du, ds, (dZ, dell, dvar)|Kuf            (rank-N updates, split-K, fixed order)
+//   MxM stage   Kuu-bar = sym(W^T Phi(L^T dL) W) - dKL/dKuu ; -> dZ, dell, dvar        (Cholesky reverse, Murray 2016 / TF CholeskyGrad)
+#include "zigp_ctx.h"
+#include "zigp_kernels.h"
+#include <algorithm>
+#include <cmath>
+
+using namespace zigp;
+
+namespace {
+
+struct EpiPhi {  // Phi: keep strictly-lower, halve the diagonal, zero above
+  __device__ __forceinline__ void operator()(double* C, int64_t ldc, int64_t i, int64_t j, double v) const {
+    C[i * ldc + j] = (j < i) ? v : ((j == i) ? 0.5 * v : 0.0);
+  }
+};
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+template <class F>
+int get_tiles(zigp_ctx* c, const std::string& key, F build, TileList& out) {
+  auto it = c->tiles.find(key);
+  if (it != c->tiles.end()) { out = it->second; return 0; }
+  std::vector<GemmTile> v;
+  build(v);
+  TileList tl;
+  tl.n = (int)v.size();
+  if (tl.n > 0) {
+    ZIGP_HIP(c, hipMalloc((void**)&tl.d, sizeof(GemmTile) * v.size()));
+    ZIGP_HIP(c, hipMemcpy(tl.d, v.data(), sizeof(GemmTile) * v.size(), hipMemcpyHostToDevice));
+  }
+  c->tiles[key] = tl;
+  out = tl;
+  return 0;
+}
+
+inline GemmTile mk_tile(int bi, int bj, int kbeg, int kend, int slice = 0) {
+  GemmTile t; t.bi = bi; t.bj = bj; t.kbeg = kbeg; t.kend = kend; t.slice = slice; t.pad0 = t.pad1 = t.pad2 = 0; return t;
+}
+
+template <int AL, int BL, class BP, class EP>
+int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, BP bp, EP ep) {
+  if (tl.n == 0) return 0;
+  g.tiles = tl.d;
+  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, BP, EP>), dim3(tl.n), dim3(GEMM_THREADS), 0, c->stream, g, bp, ep);
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+
+inline GemmArgs mk_args(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha = 1.0) {
+  GemmArgs g;
+  g.seg[0].A = A; g.seg[0].B = B; g.seg[0].lda = lda; g.seg[0].ldb = ldb;
+  g.seg[1] = g.seg[0];
+  g.nseg = 1; g.tiles = nullptr; g.C = C; g.ldc = ldc; g.slice_stride = 0; g.alpha = alpha;
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile lists
+// ------------------------------------------------------------------------------------------------
+// C(Mp x Nc) = W * B, W lower triangular: row block bi needs k blocks [0, bi]; heavy tiles first.
+int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl) {
+  return get_tiles(c, "trl:" + std::to_string(nbm) + ":" + std::to_string(nbn), [&](std::vector<GemmTile>& v) {
+    for (int bi = nbm - 1; bi >= 0; --bi)
+      for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, (bi + 1) * (BM / BK)));
+  }, tl);
+}
+// C = W^T * B: row block bi needs k blocks [bi, nbm)
+int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl) {
+  return get_tiles(c, "tru:" + std::to_string(nbm) + ":" + std::to_string(nbn), [&](std::vector<GemmTile>& v) {
+    for (int bi = 0; bi < nbm; ++bi)
+      for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * (BM / BK), nbm * (BM / BK)));
+  }, tl);
+}
+// lower-triangular output tiles x S split-K slices over nk k-steps
+int tiles_syr2k(zigp_ctx* c, int nbm, int nk, int S, TileList& tl) {
+  return get_tiles(c, "syr:" + std::to_string(nbm) + ":" + std::to_string(nk) + ":" + std::to_string(S), [&](std::vector<GemmTile>& v) {
+    for (int s = 0; s < S; ++s)
+      for (int bi = 0; bi < nbm; ++bi)
+        for (int bj = 0; bj <= bi; ++bj) v.push_back(mk_tile(bi, bj, (int)((int64_t)nk * s / S), (int)((int64_t)nk * (s + 1) / S), s));
+  }, tl);
+}
+int tiles_full(zigp_ctx* c, int nbm, int nbn, int nk, TileList& tl) {
+  return get_tiles(c, "full:" + std::to_string(nbm) + ":" + std::to_string(nbn) + ":" + std::to_string(nk), [&](std::vector<GemmTile>& v) {
+    for (int bi = 0; bi < nbm; ++bi)
+      for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, nk));
+  }, tl);
+}
+
+int check_info(zigp_ctx* c, const char* what) {
+  int h = 0;
+  ZIGP_HIP(c, hipMemcpyAsync(&h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+  if (h != 0) {
+    c->info = h;
+    char b[256];
+    snprintf(b, sizeof(b), "Cholesky decomposition was not successful for %s: the input might not be positive definite (pivot %d)", what, h);
+    c->err = b;
+    return ZIGP_ENOTPD;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// L = chol(A) in place in `Lb` (which holds a copy of A on entry), W = L^-1.  Mp multiple of 128.
+// ------------------------------------------------------------------------------------------------
+int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool want_W) {
+  const int nb = Mp / BM;
+  const int kb = BM / BK;  // k-steps per block
+  ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+  ZIGP_HIP(c, hipMemsetAsync(Wb, 0, sizeof(double) * Mp * Mp, c->stream));
+  const size_t shm = sizeof(double) * PB * PBLD;
+  for (int j = 0; j < nb; ++j) {
+    double* Ajj = Lb + (int64_t)j * BM * Mp + (int64_t)j * BM;
+    double* Wjj = Wb + (int64_t)j * BM * Mp + (int64_t)j * BM;
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(1024), shm, c->stream, Ajj, Ajj, Wjj, (int64_t)Mp, j * BM, c->d_info);
+    ZIGP_HIP(c, hipGetLastError());
+    if (j + 1 < nb) {
+      TileList tp, ts;
+      ZIGP_TRY(get_tiles(c, "po_p:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
+        for (int bi = j + 1; bi < nb; ++bi) v.push_back(mk_tile(bi, j, j * kb, (j + 1) * kb));
+      }, tp));
+      // L[bi][j] = A[bi][j] * W_jj^T   (in place: each tile reads only itself and W_jj)
+      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, tp, mk_args(Lb, Mp, Wb, Mp, Lb, Mp), BIdentity(), EpiStore())));
+      ZIGP_TRY(get_tiles(c, "po_s:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
+        for (int bi = j + 1; bi < nb; ++bi)
+          for (int bj = j + 1; bj <= bi; ++bj) v.push_back(mk_tile(bi, bj, j * kb, (j + 1) * kb));
+      }, ts));
+      // A[bi][bj] -= L[bi][j] L[bj][j]^T
+      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, ts, mk_args(Lb, Mp, Lb, Mp, Lb, Mp, -1.0), BIdentity(), EpiAccum())));
+    }
+  }
+  // zero the strictly-upper blocks of L (they still hold the copy of A)
+  for (int bi = 0; bi + 1 < nb; ++bi)
+    ZIGP_HIP(c, hipMemset2DAsync(Lb + (int64_t)bi * BM * Mp + (int64_t)(bi + 1) * BM, sizeof(double) * Mp, 0,
+                                 sizeof(double) * (size_t)(Mp - (bi + 1) * BM), BM, c->stream));
+  if (!want_W) return 0;
+  // W by recursive doubling over diagonal-block groups: W21 = -W22 (L21 W11)
+  for (int b = 1; b < nb; b *= 2) {
+    TileList t1, t2;
+    ZIGP_TRY(get_tiles(c, "tri1:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
+      for (int lo = 0; lo < nb; lo += 2 * b) {
+        const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
+        if (mid >= nb) continue;
+        for (int bi = mid; bi < hi; ++bi)
+          for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, mid * kb));
+      }
+    }, t1));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t1, mk_args(Lb, Mp, Wb, Mp, Tb, Mp), BIdentity(), EpiStore())));
+    ZIGP_TRY(get_tiles(c, "tri2:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
+      for (int lo = 0; lo < nb; lo += 2 * b) {
+        const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
+        if (mid >= nb) continue;
+        for (int bi = mid; bi < hi; ++bi)
+          for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, mid * kb, (bi + 1) * kb));
+      }
+    }, t2));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t2, mk_args(Wb, Mp, Tb, Mp, Wb, Mp, -1.0), BIdentity(), EpiStore())));
+  }
+  return 0;
+}
+
+KernHyp make_hyp(const double* ell, double var, int D) {
+  KernHyp h;
+  for (int d = 0; d < MAXD; ++d) h.inv_ell[d] = (d < D) ? 1.0 / ell[d] : 0.0;
+  h.var = var; h.D = D;
+  return h;
+}
+
+struct HostLatent {
+  int M; const double *Z, *u, *s, *ell; double var;
+};
+
+int upload_padded(zigp_ctx* c, DevBuf& b, const double* src, size_t n, size_t npad) {
+  ZIGP_ENSURE(c, b, npad);
+  ZIGP_HIP(c, hipMemsetAsync(b.p, 0, sizeof(double) * npad, c->stream));
+  if (n) ZIGP_HIP(c, hipMemcpyAsync(b.p, src, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+// MxM forward for one latent: parameters to device, Kuu, L, W.
+int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double jitter, bool want_W) {
+  ProfScope ps(c, PC_MXM);
+  lt.M = h.M;
+  lt.Mp = (int)round_up(h.M, BM);
+  lt.var = h.var;
+  const int Mp = lt.Mp;
+  ZIGP_TRY(upload_padded(c, lt.Z, h.Z, (size_t)h.M * D, (size_t)Mp * D));
+  ZIGP_TRY(upload_padded(c, lt.ell, h.ell, D, MAXD));
+  ZIGP_TRY(upload_padded(c, lt.u, h.u, h.M, Mp));
+  ZIGP_TRY(upload_padded(c, lt.s, h.s, h.M, Mp));
+  ZIGP_ENSURE(c, lt.s2, Mp);
+  hipLaunchKernelGGL(k_square, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.s.p, lt.s2.p, Mp);
+  ZIGP_ENSURE(c, lt.Kuu, (size_t)Mp * Mp);
+  ZIGP_ENSURE(c, lt.L, (size_t)Mp * Mp);
+  ZIGP_ENSURE(c, lt.W, (size_t)Mp * Mp);
+  ZIGP_ENSURE(c, lt.T1, (size_t)Mp * Mp);
+  KernHyp hyp = make_hyp(h.ell, h.var, D);
+  hipLaunchKernelGGL(k_rbf_matrix, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.Z.p, (int64_t)h.M, lt.Z.p,
+                     (int64_t)h.M, hyp, jitter, lt.Kuu.p, (int64_t)Mp, (int64_t)Mp, (int64_t)Mp);
+  ZIGP_HIP(c, hipGetLastError());
+  ZIGP_HIP(c, hipMemcpyAsync(lt.L.p, lt.Kuu.p, sizeof(double) * Mp * Mp, hipMemcpyDeviceToDevice, c->stream));
+  ZIGP_TRY(potrf_trtri(c, lt.L.p, lt.W.p, lt.T1.p, Mp, want_W));
+  return 0;
+}
+
+// KL value pieces: v = W u, alpha = W^T v, dkinv = diag(K^-1), kl -> vec[3*Mp]
+int latent_kl(zigp_ctx* c, Latent& lt) {
+  ProfScope ps(c, PC_MXM);
+  const int Mp = lt.Mp;
+  ZIGP_ENSURE(c, lt.vec, (size_t)3 * Mp + 8);
+  double* v = lt.vec.p; double* alpha = v + Mp; double* dkinv = v + 2 * Mp; double* klv = v + 3 * Mp;
+  hipLaunchKernelGGL(k_gemv_rows, dim3(Mp), dim3(256), 0, c->stream, lt.W.p, lt.u.p, (int64_t)Mp, v);
+  hipLaunchKernelGGL(k_kl_cols, dim3(ceil_div(Mp, 64)), dim3(64), 0, c->stream, lt.W.p, v, (int64_t)Mp, alpha, dkinv);
+  hipLaunchKernelGGL(k_kl_value, dim3(1), dim3(256), 0, c->stream, v, lt.L.p, lt.s.p, dkinv, lt.M, (int64_t)Mp, klv);
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+
+// Forward panels of one latent for the chunk starting at row n0: K, A1, A2, column partials.
+int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D,
+                         const double* ell_host) {
+  const int Mp = lt.Mp, nbm = Mp / BM, nbn = (int)(Nc / BN);
+  ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc);
+  ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc);
+  ZIGP_ENSURE(c, lt.A2, (size_t)Mp * Nc);
+  ZIGP_ENSURE(c, lt.part, (size_t)2 * MSPLIT * Nc);
+  KernHyp hyp = make_hyp(ell_host, lt.var, D);
+  {
+    ProfScope ps(c, PC_KUF);
+    hipLaunchKernelGGL(k_kuf_build, dim3((unsigned)(Nc / 256), Mp / 16), dim3(256), 0, c->stream, dX, Nrows, n0, lt.Z.p, lt.M, hyp,
+                       lt.K.p, Nc);
+    ZIGP_HIP(c, hipGetLastError());
+  }
+  TileList tl, tu;
+  ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, tl));
+  ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu));
+  const double fl = (double)lt.M * lt.M * (double)Nc;
+  {
+    ProfScope ps(c, PC_GEMM, fl);
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), BIdentity(), EpiStore())));
+  }
+  {
+    ProfScope ps(c, PC_GEMM, fl);
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), BIdentity(), EpiStore())));
+  }
+  {
+    ProfScope ps(c, PC_POINT);
+    hipLaunchKernelGGL(k_colred, dim3((unsigned)(Nc / 256), MSPLIT), dim3(256), 0, c->stream, lt.A1.p, lt.A2.p, lt.u.p, lt.s2.p, Mp, Nc,
+                       lt.part.p);
+    ZIGP_HIP(c, hipGetLastError());
+  }
+  return 0;
+}
+
+constexpr int SYR_SLICES = 16;
+
+int latent_chunk_backward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D) {
+  const int Mp = lt.Mp, nbm = Mp / BM, nbn = (int)(Nc / BN);
+  ZIGP_ENSURE(c, c->E, (size_t)Mp * Nc);
+  ZIGP_ENSURE(c, c->dA1, (size_t)Mp * Nc);
+  ZIGP_ENSURE(c, c->F, (size_t)Mp * Nc);
+  TileList tl, tu, ts;
+  ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, tl));
+  ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu));
+  ZIGP_TRY(tiles_syr2k(c, nbm, (int)(Nc / BK), SYR_SLICES, ts));
+  const double fl = (double)lt.M * lt.M * (double)Nc;
+  {
+    ProfScope ps(c, PC_GEMM, fl);
+    BProdDA2 bp{lt.gm.p, lt.gv.p, lt.u.p, lt.s2.p};
+    EpiDA1 ep{lt.A1.p, c->dA1.p, lt.gv.p};
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, mk_args(lt.W.p, Mp, lt.A2.p, Nc, c->E.p, Nc), bp, ep)));
+  }
+  {
+    ProfScope ps(c, PC_GEMM, fl);
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tu, mk_args(lt.W.p, Mp, c->dA1.p, Nc, c->F.p, Nc), BIdentity(), EpiStore())));
+  }
+  {
+    ProfScope ps(c, PC_RED);
+    hipLaunchKernelGGL(k_rowred, dim3(Mp), dim3(256), 0, c->stream, lt.A2.p, lt.gm.p, lt.gv.p, Nc, lt.du.p, lt.dsq.p);
+    hipLaunchKernelGGL(k_kgrad, dim3(Mp), dim3(256), 0, c->stream, c->F.p, lt.K.p, dX, Nrows, n0, lt.Z.p, lt.M, D, Nc, lt.krow.p);
+    ZIGP_HIP(c, hipGetLastError());
+  }
+  {
+    ProfScope ps(c, PC_SYR2K, 2.0 * fl);
+    GemmArgs g = mk_args(c->F.p, Nc, lt.A1.p, Nc, lt.dLpart.p, Mp);
+    g.seg[1].A = lt.A2.p; g.seg[1].B = c->E.p; g.seg[1].lda = Nc; g.seg[1].ldb = Nc;
+    g.nseg = 2; g.slice_stride = (int64_t)Mp * Mp;
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, ts, g, BIdentity(), EpiAccum())));
+  }
+  return 0;
+}
+
+// MxM backward: G = dELBO/dKuu (symmetric) -> krow accumulators.
+int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with_data, bool with_kl) {
+  ProfScope ps(c, PC_MXM);
+  const int Mp = lt.Mp, nb = Mp / BM, kb = BM / BK;
+  const size_t mm = (size_t)Mp * Mp;
+  ZIGP_ENSURE(c, lt.T1, mm); ZIGP_ENSURE(c, lt.T2, mm); ZIGP_ENSURE(c, lt.T3, mm); ZIGP_ENSURE(c, lt.G, mm);
+  const int gridmm = ceil_div((int64_t)mm, 256);
+  double* S = lt.T1.p;
+  if (with_data) {
+    hipLaunchKernelGGL(k_reduce_planes_tril, dim3(gridmm), dim3(256), 0, c->stream, lt.dLpart.p, SYR_SLICES, (int64_t)Mp, lt.T1.p);
+    TileList t1, t2, t3;
+    // Q = Phi(L^T dL) -> T2  (upper tiles get an empty k range -> zeros)
+    ZIGP_TRY(get_tiles(c, "bw_q:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
+      for (int bi = 0; bi < nb; ++bi)
+        for (int bj = 0; bj < nb; ++bj) v.push_back(bj <= bi ? mk_tile(bi, bj, bi * kb, nb * kb) : mk_tile(bi, bj, 0, 0));
+    }, t1));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t1, mk_args(lt.L.p, Mp, lt.T1.p, Mp, lt.T2.p, Mp), BIdentity(), EpiPhi())));
+    // T = Q W -> T3 (lower)
+    ZIGP_TRY(get_tiles(c, "bw_t:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
+      for (int bi = 0; bi < nb; ++bi)
+        for (int bj = 0; bj < nb; ++bj) v.push_back(bj <= bi ? mk_tile(bi, bj, bj * kb, (bi + 1) * kb) : mk_tile(bi, bj, 0, 0));
+    }, t2));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t2, mk_args(lt.T2.p, Mp, lt.W.p, Mp, lt.T3.p, Mp), BIdentity(), EpiStore())));
+    // S = W^T T -> T1
+    ZIGP_TRY(get_tiles(c, "bw_s:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
+      for (int bi = 0; bi < nb; ++bi)
+        for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, std::max(bi, bj) * kb, nb * kb));
+    }, t3));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t3, mk_args(lt.W.p, Mp, lt.T3.p, Mp, lt.T1.p, Mp), BIdentity(), EpiStore())));
+  }
+  double* P = lt.T2.p; double* PSP = lt.G.p;
+  if (with_kl) {
+    TileList t3, tf;
+    ZIGP_TRY(get_tiles(c, "bw_s:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
+      for (int bi = 0; bi < nb; ++bi)
+        for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, std::max(bi, bj) * kb, nb * kb));
+    }, t3));
+    // P = W^T W -> T2
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t3, mk_args(lt.W.p, Mp, lt.W.p, Mp, lt.T2.p, Mp), BIdentity(), EpiStore())));
+    // Ps = diag(s2) P -> T3 ; PSP = P Ps -> G
+    hipLaunchKernelGGL(k_rowscale, dim3(gridmm), dim3(256), 0, c->stream, lt.T2.p, lt.s2.p, (int64_t)Mp, lt.T3.p);
+    ZIGP_TRY(tiles_full(c, nb, nb, nb * kb, tf));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tf, mk_args(lt.T2.p, Mp, lt.T3.p, Mp, lt.G.p, Mp), BIdentity(), EpiStore())));
+  }
+  // G = sym(S) - dKL/dKuu -> T3 (T3 free again)
+  hipLaunchKernelGGL(k_sym_combine, dim3(gridmm), dim3(256), 0, c->stream, S, P, PSP, lt.vec.p + Mp, with_data ? 1 : 0, with_kl ? 1 : 0,
+                     (int64_t)Mp, lt.T3.p);
+  hipLaunchKernelGGL(k_kuu_grad, dim3(Mp), dim3(256), 0, c->stream, lt.T3.p, lt.Kuu.p, jitter, lt.Z.p, lt.M, D, (int64_t)Mp, lt.krow.p);
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+
+int validate_params(zigp_ctx* c, const zigp_params* p) {
+  if (!p) return fail_arg(c, "params is NULL");
+  if (p->Mf <= 0 || p->Mg <= 0) return fail_arg(c, "Mf and Mg must be positive");
+  if (p->D <= 0 || p->D > MAXD) return fail_arg(c, "D must be in [1, 8]");
+  if (!p->Zf || !p->Zg || !p->u_fm || !p->u_gm || !p->u_fs_sqrt || !p->u_gs_sqrt || !p->ell_f || !p->ell_g)
+    return fail_arg(c, "NULL pointer in params");
+  if (!(p->var_f > 0) || !(p->var_g > 0) || !(p->noise > 0)) return fail_arg(c, "variances must be positive");
+  for (int d = 0; d < p->D; ++d)
+    if (!(p->ell_f[d] > 0) || !(p->ell_g[d] > 0)) return fail_arg(c, "lengthscales must be positive");
+  return 0;
+}
+
+// shared driver for zigp_elbo / zigp_predict
+int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double* dY, int64_t Nrows, int D, double jitter,
+              double scale, double g_offset, int64_t row_begin, int64_t row_end, int include_kl, bool predict, double* d_out9,
+              double* elbo_data, double* kl, zigp_grads* grads) {
+  const bool need_grad = (grads != nullptr) && !predict;
+  const bool has_rows = row_end > row_begin;
+  HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
+  const double* ell_h[2] = {p->ell_f, p->ell_g};
+  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], D, jitter, true));
+  ZIGP_TRY(check_info(c, "Kuu"));
+  if (include_kl && !predict)
+    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_kl(c, c->lat[h]));
+
+  int64_t Nc = c->chunk;
+  const int64_t span = has_rows ? (row_end - row_begin) : 0;
+  if (span < Nc) Nc = std::max<int64_t>(1024, round_up(span, 1024));
+  const int pw_blocks = (int)(Nc / PW_THREADS);
+  ZIGP_ENSURE(c, c->pw_part, (size_t)pw_blocks * 4);
+  ZIGP_HIP(c, hipMemsetAsync(c->pw_part.p, 0, sizeof(double) * pw_blocks * 4, c->stream));
+  for (int h = 0; h < 2; ++h) {
+    Latent& lt = c->lat[h];
+    const int Mp = lt.Mp;
+    ZIGP_ENSURE(c, lt.gm, Nc); ZIGP_ENSURE(c, lt.gv, Nc);
+    if (need_grad) {
+      ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)Mp * (1 + 2 * D));
+      ZIGP_ENSURE(c, lt.dLpart, (size_t)SYR_SLICES * Mp * Mp);
+      ZIGP_HIP(c, hipMemsetAsync(lt.du.p, 0, sizeof(double) * Mp, c->stream));
+      ZIGP_HIP(c, hipMemsetAsync(lt.dsq.p, 0, sizeof(double) * Mp, c->stream));
+      ZIGP_HIP(c, hipMemsetAsync(lt.krow.p, 0, sizeof(double) * Mp * (1 + 2 * D), c->stream));
+      if (has_rows) ZIGP_HIP(c, hipMemsetAsync(lt.dLpart.p, 0, sizeof(double) * SYR_SLICES * Mp * Mp, c->stream));
+    }
+  }
+  for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc) {
+    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], dX, Nrows, n0, Nc, D, ell_h[h]));
+    {
+      ProfScope ps(c, PC_POINT);
+      PwArgs a;
+      a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
+      a.var_f = p->var_f; a.var_g = p->var_g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
+      a.gm_f = need_grad ? c->lat[0].gm.p : nullptr; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
+      a.acc = c->pw_part.p; a.out9 = d_out9 ? d_out9 - row_begin : nullptr; a.ld9 = row_end - row_begin;
+      if (predict) hipLaunchKernelGGL(k_pointwise<true>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
+      else hipLaunchKernelGGL(k_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
+      ZIGP_HIP(c, hipGetLastError());
+    }
+    if (need_grad)
+      for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_backward(c, c->lat[h], dX, Nrows, n0, Nc, D));
+  }
+  if (predict) { ZIGP_HIP(c, hipStreamSynchronize(c->stream)); prof_collect(c); return 0; }
+  if (need_grad)
+    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_mxm_backward(c, c->lat[h], D, jitter, has_rows, include_kl != 0));
+
+  // ---- gather results on the host (fixed-order final sums) ----
+  std::vector<double> hpw((size_t)pw_blocks * 4);
+  ZIGP_HIP(c, hipMemcpyAsync(hpw.data(), c->pw_part.p, sizeof(double) * hpw.size(), hipMemcpyDeviceToHost, c->stream));
+  std::vector<double> hvec[2], hdu[2], hdsq[2], hkrow[2];
+  for (int h = 0; h < 2; ++h) {
+    Latent& lt = c->lat[h];
+    if (include_kl) {
+      hvec[h].resize((size_t)3 * lt.Mp + 8);
+      ZIGP_HIP(c, hipMemcpyAsync(hvec[h].data(), lt.vec.p, sizeof(double) * hvec[h].size(), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (need_grad) {
+      hdu[h].resize(lt.Mp); hdsq[h].resize(lt.Mp); hkrow[h].resize((size_t)lt.Mp * (1 + 2 * D));
+      ZIGP_HIP(c, hipMemcpyAsync(hdu[h].data(), lt.du.p, sizeof(double) * lt.Mp, hipMemcpyDeviceToHost, c->stream));
+      ZIGP_HIP(c, hipMemcpyAsync(hdsq[h].data(), lt.dsq.p, sizeof(double) * lt.Mp, hipMemcpyDeviceToHost, c->stream));
+      ZIGP_HIP(c, hipMemcpyAsync(hkrow[h].data(), lt.krow.p, sizeof(double) * hkrow[h].size(), hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  double s_ve = 0, s_dn = 0, s_gvf = 0, s_gvg = 0;
+  for (int b = 0; b < pw_blocks; ++b) { s_ve += hpw[4 * b]; s_dn += hpw[4 * b + 1]; s_gvf += hpw[4 * b + 2]; s_gvg += hpw[4 * b + 3]; }
+  if (elbo_data) *elbo_data = s_ve;
+  double klsum = 0.0;
+  if (include_kl) klsum = hvec[0][3 * c->lat[0].Mp] + hvec[1][3 * c->lat[1].Mp];
+  if (kl) *kl = klsum;
+  if (need_grad) {
+    double* gZ[2] = {grads->Zf, grads->Zg};
+    double* gu[2] = {grads->u_fm, grads->u_gm};
+    double* gs[2] = {grads->u_fs_sqrt, grads->u_gs_sqrt};
+    double* gl[2] = {grads->ell_f, grads->ell_g};
+    double gvar[2];
+    const double sgv[2] = {s_gvf, s_gvg};
+    for (int h = 0; h < 2; ++h) {
+      Latent& lt = c->lat[h];
+      const int M = lt.M, W = 1 + 2 * D;
+      const double* ell = ell_h[h];
+      double dv = 0.0;
+      std::vector<double> dl(D, 0.0);
+      for (int m = 0; m < M; ++m) {
+        const double* r = &hkrow[h][(size_t)m * W];
+        dv += r[0];
+        for (int d = 0; d < D; ++d) {
+          if (gZ[h]) gZ[h][m * D + d] = r[1 + d] / (ell[d] * ell[d]);
+          dl[d] += r[1 + D + d];
+        }
+        double dum = hdu[h][m], dsm = 2.0 * hl[h].s[m] * hdsq[h][m];
+        if (include_kl) {
+          dum -= hvec[h][lt.Mp + m];
+          dsm -= (-1.0 / hl[h].s[m] + hvec[h][2 * lt.Mp + m] * hl[h].s[m]);
+        }
+        if (gu[h]) gu[h][m] = dum;
+        if (gs[h]) gs[h][m] = dsm;
+      }
+      for (int d = 0; d < D; ++d)
+        if (gl[h]) gl[h][d] = dl[d] / (ell[d] * ell[d] * ell[d]);
+      gvar[h] = dv / lt.var + sgv[h];
+    }
+    grads->var_f = gvar[0]; grads->var_g = gvar[1]; grads->noise = s_dn;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+int zigp_create(zigp_ctx** out, int device_id) {
+  if (!out) return ZIGP_EARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZIGP_EHIP;
+  if (device_id < 0 || device_id >= ndev) return ZIGP_EARG;
+  if (hipSetDevice(device_id) != hipSuccess) return ZIGP_EHIP;
+  zigp_ctx* c = new (std::nothrow) zigp_ctx();
+  if (!c) return ZIGP_EHIP;
+  c->device = device_id;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZIGP_EHIP; }
+  if (hipMalloc((void**)&c->d_info, sizeof(int)) != hipSuccess) { delete c; return ZIGP_EHIP; }
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(sizeof(double) * PB * PBLD)) != hipSuccess) { delete c; return ZIGP_EHIP; }
+  *out = c;
+  return ZIGP_OK;
+}
+
+int zigp_destroy(zigp_ctx* c) {
+  if (!c) return ZIGP_EARG;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int h = 0; h < 2; ++h) {
+    Latent& l = c->lat[h];
+    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
+                    &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec};
+    for (DevBuf* b : bs) b->release();
+  }
+  DevBuf* bs[] = {&c->ownX, &c->ownY, &c->E, &c->dA1, &c->F, &c->pw_part, &c->out9, &c->scratch, &c->scratch2};
+  for (DevBuf* b : bs) b->release();
+  for (auto& kv : c->tiles) if (kv.second.d) (void)hipFree(kv.second.d);
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->d_info) (void)hipFree(c->d_info);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return ZIGP_OK;
+}
+
+const char* zigp_last_error(zigp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int zigp_last_info(zigp_ctx* c) { return c ? c->info : 0; }
+
+int zigp_set_chunk(zigp_ctx* c, int64_t chunk_rows) {
+  if (!c) return ZIGP_EARG;
+  if (chunk_rows < 1024 || chunk_rows % 1024 != 0) return fail_arg(c, "chunk must be a positive multiple of 1024");
+  c->chunk = chunk_rows;
+  return ZIGP_OK;
+}
+
+int zigp_set_data(zigp_ctx* c, const double* X, const double* Y, int64_t N, int32_t D) {
+  if (!c) return ZIGP_EARG;
+  if (!X || !Y || N <= 0 || D <= 0 || D > MAXD) return fail_arg(c, "zigp_set_data: bad arguments (need X, Y, N>0, 1<=D<=8)");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  ZIGP_ENSURE(c, c->ownX, (size_t)N * D);
+  ZIGP_ENSURE(c, c->ownY, (size_t)N);
+  ZIGP_HIP(c, hipMemcpyAsync(c->ownX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice, c->stream));
+  ZIGP_HIP(c, hipMemcpyAsync(c->ownY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+  c->dX = c->ownX.p; c->dY = c->ownY.p; c->N = N; c->D = D;
+  return ZIGP_OK;
+}
+
+int zigp_set_data_device(zigp_ctx* c, const double* dX, const double* dY, int64_t N, int32_t D) {
+  if (!c) return ZIGP_EARG;
+  if (!dX || !dY || N <= 0 || D <= 0 || D > MAXD) return fail_arg(c, "zigp_set_data_device: bad arguments");
+  c->dX = dX; c->dY = dY; c->N = N; c->D = D;
+  return ZIGP_OK;
+}
+
+int zigp_elbo(zigp_ctx* c, const zigp_params* p, double jitter, double scale, double g_offset, int64_t row_begin, int64_t row_end,
+              int32_t include_kl, double* elbo_data, double* kl, zigp_grads* grads) {
+  if (!c) return ZIGP_EARG;
+  ZIGP_TRY(validate_params(c, p));
+  if (!c->dX) return fail_arg(c, "zigp_elbo: no data set (call zigp_set_data first)");
+  if (p->D != c->D) return fail_arg(c, "zigp_elbo: params.D differs from the data's D");
+  if (row_begin < 0 || row_end > c->N || row_begin > row_end) return fail_arg(c, "zigp_elbo: bad row range");
+  if (!(jitter >= 0)) return fail_arg(c, "zigp_elbo: jitter must be >= 0");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  return run_dense(c, p, c->dX, c->dY, c->N, c->D, jitter, scale, g_offset, row_begin, row_end, include_kl, false, nullptr, elbo_data, kl,
+                   grads);
+}
+
+int zigp_predict(zigp_ctx* c, const zigp_params* p, const double* Xnew, int64_t N, double jitter, double g_offset, double* out9) {
+  if (!c) return ZIGP_EARG;
+  ZIGP_TRY(validate_params(c, p));
+  if (N < 0 || (N > 0 && (!Xnew || !out9))) return fail_arg(c, "zigp_predict: bad arguments");
+  if (N == 0) return ZIGP_OK;
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  ZIGP_ENSURE(c, c->scratch, (size_t)N * p->D);
+  ZIGP_ENSURE(c, c->out9, (size_t)9 * N);
+  ZIGP_HIP(c, hipMemcpyAsync(c->scratch.p, Xnew, sizeof(double) * N * p->D, hipMemcpyHostToDevice, c->stream));
+  ZIGP_TRY(run_dense(c, p, c->scratch.p, nullptr, N, p->D, jitter, 1.0, g_offset, 0, N, 0, true, c->out9.p, nullptr, nullptr, nullptr));
+  ZIGP_HIP(c, hipMemcpyAsync(out9, c->out9.p, sizeof(double) * 9 * N, hipMemcpyDeviceToHost, c->stream));
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+  return ZIGP_OK;
+}
+
+int zigp_prior_kl(zigp_ctx* c, const zigp_params* p, double jitter, double* kl2) {
+  if (!c) return ZIGP_EARG;
+  ZIGP_TRY(validate_params(c, p));
+  if (!kl2) return fail_arg(c, "zigp_prior_kl: kl2 is NULL");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
+  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], p->D, jitter, true));
+  ZIGP_TRY(check_info(c, "Kuu"));
+  for (int h = 0; h < 2; ++h) {
+    ZIGP_TRY(latent_kl(c, c->lat[h]));
+    ZIGP_HIP(c, hipMemcpyAsync(&kl2[h], c->lat[h].vec.p + 3 * c->lat[h].Mp, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  }
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  return ZIGP_OK;
+}
+
+int zigp_rbf_K(zigp_ctx* c, const double* X1, int64_t n1, const double* X2, int64_t n2, int32_t D, const double* ell, double var, double* K) {
+  if (!c) return ZIGP_EARG;
+  if (!X1 || n1 <= 0 || D <= 0 || D > MAXD || !ell || !K) return fail_arg(c, "zigp_rbf_K: bad arguments");
+  if (!X2) n2 = n1;
+  if (n2 <= 0) return fail_arg(c, "zigp_rbf_K: bad n2");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  ZIGP_ENSURE(c, c->scratch, (size_t)(n1 + n2) * D);
+  ZIGP_ENSURE(c, c->scratch2, (size_t)n1 * n2);
+  double* d1 = c->scratch.p; double* d2 = d1 + n1 * D;
+  ZIGP_HIP(c, hipMemcpyAsync(d1, X1, sizeof(double) * n1 * D, hipMemcpyHostToDevice, c->stream));
+  ZIGP_HIP(c, hipMemcpyAsync(d2, X2 ? X2 : X1, sizeof(double) * n2 * D, hipMemcpyHostToDevice, c->stream));
+  KernHyp h = make_hyp(ell, var, D);
+  hipLaunchKernelGGL(k_rbf_matrix, dim3(ceil_div(n1 * n2, 256)), dim3(256), 0, c->stream, d1, n1, d2, n2, h, 0.0, c->scratch2.p, n1, n2, n2);
+  ZIGP_HIP(c, hipGetLastError());
+  ZIGP_HIP(c, hipMemcpyAsync(K, c->scratch2.p, sizeof(double) * n1 * n2, hipMemcpyDeviceToHost, c->stream));
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+  return ZIGP_OK;
+}
+
+int zigp_profile_enable(zigp_ctx* c, int32_t on) { if (!c) return ZIGP_EARG; c->prof_on = on != 0; return ZIGP_OK; }
+int zigp_profile_reset(zigp_ctx* c) {
+  if (!c) return ZIGP_EARG;
+  prof_collect(c);
+  for (int i = 0; i < ZIGP_NCLASS; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; c->prof_flops[i] = 0; }
+  return ZIGP_OK;
+}
+int zigp_profile_get(zigp_ctx* c, double* ms, int64_t* launches, double* flops) {
+  if (!c) return ZIGP_EARG;
+  prof_collect(c);
+  for (int i = 0; i < ZIGP_NCLASS; ++i) { if (ms) ms[i] = c->prof_ms[i]; if (launches) launches[i] = c->prof_n[i]; if (flops) flops[i] = c->prof_flops[i]; }
+  return ZIGP_OK;
+}
+
+// ---- diagnostics -------------------------------------------------------------------------------
+int zigp_test_gemm(zigp_ctx* c, int32_t transA, int32_t transB, int64_t m, int64_t n, int64_t k, const double* A, const double* B, double* C) {
+  if (!c) return ZIGP_EARG;
+  if (m <= 0 || n <= 0 || k <= 0 || !A || !B || !C) return fail_arg(c, "zigp_test_gemm: bad arguments");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  const int64_t mp = round_up(m, BM), np = round_up(n, BN), kp = round_up(k, BM);
+  // stored shapes: A is (m,k) or (k,m) if transA; B is (k,n) or (n,k) if transB
+  const int64_t ar = transA ? kp : mp, ac = transA ? mp : kp, br = transB ? np : kp, bc = transB ? kp : np;
+  std::vector<double> ha((size_t)ar * ac, 0.0), hb((size_t)br * bc, 0.0), hc((size_t)mp * np);
+  const int64_t ar0 = transA ? k : m, ac0 = transA ? m : k, br0 = transB ? n : k, bc0 = transB ? k : n;
+  for (int64_t i = 0; i < ar0; ++i) memcpy(&ha[i * ac], &A[i * ac0], sizeof(double) * ac0);
+  for (int64_t i = 0; i < br0; ++i) memcpy(&hb[i * bc], &B[i * bc0], sizeof(double) * bc0);
+  DevBuf da, db, dc;
+  int rc = 0;
+  auto body = [&]() -> int {
+    ZIGP_ENSURE(c, da, ha.size()); ZIGP_ENSURE(c, db, hb.size()); ZIGP_ENSURE(c, dc, hc.size());
+    ZIGP_HIP(c, hipMemcpyAsync(da.p, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice, c->stream));
+    ZIGP_HIP(c, hipMemcpyAsync(db.p, hb.data(), sizeof(double) * hb.size(), hipMemcpyHostToDevice, c->stream));
+    TileList tl;
+    ZIGP_TRY(tiles_full(c, (int)(mp / BM), (int)(np / BN), (int)(kp / BK), tl));
+    GemmArgs g = mk_args(da.p, ac, db.p, bc, dc.p, np);
+    if (!transA && !transB) ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, g, BIdentity(), EpiStore())));
+    if (transA && !transB) ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tl, g, BIdentity(), EpiStore())));
+    if (!transA && transB) ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, tl, g, BIdentity(), EpiStore())));
+    if (transA && transB) ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_KCONTIG>(c, tl, g, BIdentity(), EpiStore())));
+    ZIGP_HIP(c, hipMemcpyAsync(hc.data(), dc.p, sizeof(double) * hc.size(), hipMemcpyDeviceToHost, c->stream));
+    ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+  };
+  rc = body();
+  da.release(); db.release(); dc.release();
+  if (rc) return rc;
+  for (int64_t i = 0; i < m; ++i) memcpy(&C[i * n], &hc[i * np], sizeof(double) * n);
+  return ZIGP_OK;
+}
+
+int zigp_test_potrf_trtri(zigp_ctx* c, int64_t n, const double* A, double* L, double* W) {
+  if (!c) return ZIGP_EARG;
+  if (n <= 0 || !A) return fail_arg(c, "zigp_test_potrf_trtri: bad arguments");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  const int Mp = (int)round_up(n, BM);
+  std::vector<double> ha((size_t)Mp * Mp, 0.0);
+  for (int64_t i = 0; i < Mp; ++i) {
+    if (i < n) memcpy(&ha[i * Mp], &A[i * n], sizeof(double) * n);
+    else ha[i * Mp + i] = 1.0;
+  }
+  DevBuf dl, dw, dt;
+  auto body = [&]() -> int {
+    ZIGP_ENSURE(c, dl, ha.size()); ZIGP_ENSURE(c, dw, ha.size()); ZIGP_ENSURE(c, dt, ha.size());
+    ZIGP_HIP(c, hipMemcpyAsync(dl.p, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice, c->stream));
+    ZIGP_TRY(potrf_trtri(c, dl.p, dw.p, dt.p, Mp, true));
+    ZIGP_TRY(check_info(c, "A"));
+    std::vector<double> ho(ha.size());
+    if (L) {
+      ZIGP_HIP(c, hipMemcpyAsync(ho.data(), dl.p, sizeof(double) * ho.size(), hipMemcpyDeviceToHost, c->stream));
+      ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+      for (int64_t i = 0; i < n; ++i) memcpy(&L[i * n], &ho[i * Mp], sizeof(double) * n);
+    }
+    if (W) {
+      ZIGP_HIP(c, hipMemcpyAsync(ho.data(), dw.p, sizeof(double) * ho.size(), hipMemcpyDeviceToHost, c->stream));
+      ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+      for (int64_t i = 0; i < n; ++i) memcpy(&W[i * n], &ho[i * Mp], sizeof(double) * n);
+    }
+    return 0;
+  };
+  int rc = body();
+  dl.release(); dw.release(); dt.release();
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,465 @@
+// Device kernels of the dense zero-inflated-GP ELBO path (everything that is not the GEMM core).
+// Reference call sites each kernel replaces are cited per kernel (file:line in the reference tree).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace zigp {
+
+constexpr int MAXD = 8;       // max input dimension handled by the fused kernels
+constexpr int MSPLIT = 8;     // m-splits of the column reduction
+constexpr int PW_THREADS = 256;
+
+struct KernHyp { double inv_ell[MAXD]; double var; int D; };
+
+// ---------------------------------------------------------------------------------------------
+// block-wide deterministic sum (fixed order: lanes by xor-shuffle tree, then waves 0..nw-1)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double* sh /*[NW]*/) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) r += sh[w];
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RBF kernel matrix, general (KernSE.K onofftf/main.py:53-57 / kernse_np.K onofftf/utils.py:48-52).
+// out is (r_pad, c_pad) with ld; entries outside (n1,n2) are identity-padded (1 on the diagonal).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rbf_matrix(const double* __restrict__ X1, int64_t n1, const double* __restrict__ X2, int64_t n2,
+                             KernHyp h, double jitter, double* __restrict__ out, int64_t r_pad, int64_t c_pad, int64_t ld) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= r_pad * c_pad) return;
+  int64_t i = idx / c_pad, j = idx - i * c_pad;
+  double v;
+  if (i < n1 && j < n2) {
+    double r2 = 0.0;
+    for (int d = 0; d < h.D; ++d) {
+      double t = (X1[i * h.D + d] - X2[j * h.D + d]) * h.inv_ell[d];
+      r2 = fma(t, t, r2);
+    }
+    v = h.var * exp(-0.5 * r2) + ((i == j) ? jitter : 0.0);
+  } else {
+    v = (i == j) ? 1.0 : 0.0;
+  }
+  out[i * ld + j] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kuf panel for one chunk: K[m][n] = var*exp(-0.5*|(z_m - x_n)/ell|^2), m < M ; 0 for padded rows.
+// (kern.K(X, Xnew), onofftf/main.py:266.)  grid (Nc/256, Mp/16); thread = one column n, 16 rows.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_kuf_build(const double* __restrict__ X, int64_t N, int64_t n0, const double* __restrict__ Z, int M, KernHyp h,
+            double* __restrict__ K, int64_t Nc) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int m0 = blockIdx.y * 16;
+  double xs[MAXD];
+  const bool valid = (n0 + n) < N;
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) xs[d] = (d < h.D && valid) ? X[(n0 + n) * h.D + d] * h.inv_ell[d] : 0.0;
+#pragma unroll 4
+  for (int mm = 0; mm < 16; ++mm) {
+    const int m = m0 + mm;
+    double v = 0.0;
+    if (m < M) {
+      double r2 = 0.0;
+#pragma unroll
+      for (int d = 0; d < MAXD; ++d)
+        if (d < h.D) { double t = Z[m * h.D + d] * h.inv_ell[d] - xs[d]; r2 = fma(t, t, r2); }
+      v = h.var * exp(-0.5 * r2);
+    }
+    K[(int64_t)m * Nc + n] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column reductions of one chunk (GPConditional, onofftf/main.py:278,287,291,302):
+//   part[0][ms][n] = sum_{m in split ms} A2[m,n]*u[m]
+//   part[1][ms][n] = sum_{m in split ms} s2[m]*A2[m,n]^2 - A1[m,n]^2
+// grid (Nc/256, MSPLIT)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_colred(const double* __restrict__ A1, const double* __restrict__ A2, const double* __restrict__ u,
+         const double* __restrict__ s2, int Mp, int64_t Nc, double* __restrict__ part) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int ms = blockIdx.y, mlen = Mp / MSPLIT, mb = ms * mlen;
+  double pm = 0.0, pv = 0.0;
+  for (int m = mb; m < mb + mlen; ++m) {
+    const double a1 = A1[(int64_t)m * Nc + n], a2 = A2[(int64_t)m * Nc + n];
+    pm = fma(a2, u[m], pm);
+    pv = fma(s2[m] * a2, a2, pv);
+    pv = fma(-a1, a1, pv);
+  }
+  part[(int64_t)(0 * MSPLIT + ms) * Nc + n] = pm;
+  part[(int64_t)(1 * MSPLIT + ms) * Nc + n] = pv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Point-wise stage: probit moments (OnOffSVGP.ProbitExpectations onoffgpf/OnOffSVGP.py:168-204),
+// augmentation (:146-148), expected log-likelihood (OnOffLikelihood.py:30-32) and the hand-derived
+// reverse pass to the cotangents of (fmean, fvar, gmean, gvar) and the noise variance.
+// ---------------------------------------------------------------------------------------------
+struct PwArgs {
+  const double* part_f; const double* part_g;    // [2][MSPLIT][Nc]
+  const double* Y; int64_t n0, row_end, Nc;
+  double var_f, var_g, noise, g_offset, scale;
+  double* gm_f; double* gv_f; double* gm_g; double* gv_g;
+  double* acc;      // [gridDim.x][4] running sums: var_exp, dnoise, sum gv_f, sum gv_g
+  double* out9;     // predict: (9, ld9)
+  int64_t ld9;
+};
+
+struct PwOut { double gfmean, gfvar, gfmeanu, e1, e2, ev; double dfm, dfv, dgm, dgv, ve, dnoise; };
+
+__device__ __forceinline__ PwOut pointwise_eval(double fm, double fv, double gmn, double gvr, double y, double noise) {
+  PwOut o;
+  const double c1 = 1.0 - 2.e-3, c0 = 1.e-3;
+  const double inv_sqrt_1pv = 1.0 / sqrt(1.0 + gvr);
+  const double z = gmn * inv_sqrt_1pv;                          // OnOffSVGP.py:190
+  const double a = 1.0 / sqrt(1.0 + 2.0 * gvr);                 // :191
+  const double cdf = 0.5 * (1.0 + erf(z * 0.70710678118654752440)) * c1 + c0;   // :178
+  const double ex = exp(-0.5 * (z * z) * (a * a + 1.0));        // :187
+  const double at = atan(a) * 0.15915494309189533577;           // :186  atan(a)/(2 pi)
+  const double T = at * ex;
+  const double e1 = cdf;                                        // :196
+  const double e2r = cdf - 2.0 * T;                             // :197
+  const double evr = cdf - 2.0 * T - cdf * cdf;                 // :198
+  const double e2 = (e2r + fabs(e2r)) * 0.5;                    // :201
+  const double ev = (evr + fabs(evr)) * 0.5;                    // :202
+  o.e1 = e1; o.e2 = e2; o.ev = ev;
+  o.gfmean = e1 * fm; o.gfvar = e2 * fv; o.gfmeanu = ev * fm * fm;          // :146-148
+  const double inv_noise = 1.0 / noise;
+  const double res = y - o.gfmean;
+  const double q = res * res + o.gfvar + o.gfmeanu;
+  o.ve = -0.5 * 1.8378770664093454836 - 0.5 * log(noise) - 0.5 * q * inv_noise;   // OnOffLikelihood.py:31-32
+  // ---- reverse pass ----
+  const double dFmu = res * inv_noise, dFv = -0.5 * inv_noise;
+  o.dnoise = -0.5 * inv_noise + 0.5 * q * inv_noise * inv_noise;
+  o.dfm = dFmu * e1 + dFv * ev * 2.0 * fm;
+  o.dfv = dFv * e2;
+  const double de1 = dFmu * fm, de2 = dFv * fv, dev = dFv * fm * fm;
+  const double m2 = (e2r > 0.0) ? 1.0 : ((e2r < 0.0) ? 0.0 : 0.5);
+  const double mv = (evr > 0.0) ? 1.0 : ((evr < 0.0) ? 0.0 : 0.5);
+  const double dcdf = de1 + de2 * m2 + dev * mv * (1.0 - 2.0 * cdf);
+  const double dT = -2.0 * (de2 * m2 + dev * mv);
+  const double phi = 0.39894228040143267794 * exp(-0.5 * z * z);
+  const double dTdz = -z * (a * a + 1.0) * T;
+  const double dTda = 0.15915494309189533577 / (1.0 + a * a) * ex - z * z * a * T;
+  const double dz = dcdf * c1 * phi + dT * dTdz;
+  const double da = dT * dTda;
+  o.dgm = dz * inv_sqrt_1pv;
+  o.dgv = dz * (-0.5 * z / (1.0 + gvr)) + da * (-(a * a * a));
+  return o;
+}
+
+template <bool PREDICT>
+__global__ void __launch_bounds__(PW_THREADS)
+k_pointwise(PwArgs p) {
+  __shared__ double sh[4];
+  const int64_t n = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  double fm = 0.0, fv = p.var_f, gmn = 0.0, gvr = p.var_g;
+#pragma unroll
+  for (int ms = 0; ms < MSPLIT; ++ms) {
+    fm += p.part_f[(int64_t)(0 * MSPLIT + ms) * p.Nc + n];
+    fv += p.part_f[(int64_t)(1 * MSPLIT + ms) * p.Nc + n];
+    gmn += p.part_g[(int64_t)(0 * MSPLIT + ms) * p.Nc + n];
+    gvr += p.part_g[(int64_t)(1 * MSPLIT + ms) * p.Nc + n];
+  }
+  gmn += p.g_offset;
+  const bool valid = (p.n0 + n) < p.row_end;
+  const double y = (valid && p.Y) ? p.Y[p.n0 + n] : 0.0;
+  PwOut o = pointwise_eval(fm, fv, gmn, gvr, y, p.noise);
+  if (PREDICT) {
+    if (valid) {
+      double* q = p.out9 + (p.n0 + n);
+      q[0 * p.ld9] = o.gfmean; q[1 * p.ld9] = o.gfvar; q[2 * p.ld9] = o.gfmeanu;
+      q[3 * p.ld9] = fm; q[4 * p.ld9] = fv; q[5 * p.ld9] = gmn; q[6 * p.ld9] = gvr;
+      q[7 * p.ld9] = o.e1; q[8 * p.ld9] = o.ev;
+    }
+    return;
+  }
+  const double sc = valid ? p.scale : 0.0;
+  if (p.gm_f) {
+    p.gm_f[n] = sc * o.dfm; p.gv_f[n] = sc * o.dfv; p.gm_g[n] = sc * o.dgm; p.gv_g[n] = sc * o.dgv;
+  }
+  double s0 = block_sum<4>(valid ? p.scale * o.ve : 0.0, sh);
+  double s1 = block_sum<4>(sc * o.dnoise, sh);
+  double s2 = block_sum<4>(sc * o.dfv, sh);
+  double s3 = block_sum<4>(sc * o.dgv, sh);
+  if (threadIdx.x == 0) {
+    double* a = p.acc + (int64_t)blockIdx.x * 4;
+    a[0] += s0; a[1] += s1; a[2] += s2; a[3] += s3;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row reductions for d/du and d/ds (cotangents of main.py:287 and :291,302): block per row m.
+//   du[m]  += sum_n A2[m,n] gm[n] ;  dsq[m] += sum_n gv[n] A2[m,n]^2
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rowred(const double* __restrict__ A2, const double* __restrict__ gm, const double* __restrict__ gv, int64_t Nc,
+         double* __restrict__ du, double* __restrict__ dsq) {
+  __shared__ double sh[4];
+  const int m = blockIdx.x;
+  const double* row = A2 + (int64_t)m * Nc;
+  double a = 0.0, b = 0.0;
+  for (int64_t n = threadIdx.x; n < Nc; n += 256) {
+    const double v = row[n];
+    a = fma(v, gm[n], a);
+    b = fma(gv[n] * v, v, b);
+  }
+  a = block_sum<4>(a, sh);
+  b = block_sum<4>(b, sh);
+  if (threadIdx.x == 0) { du[m] += a; dsq[m] += b; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kuf -> (Z, ell, var) cotangent reductions, block per row m of F (= dK) and K:
+//   krow[m][0]     += sum_n F K
+//   krow[m][1+d]   += sum_n F K (x_nd - z_md)
+//   krow[m][1+D+d] += sum_n F K (x_nd - z_md)^2
+// (reverse of KernSE.K, onofftf/main.py:41-57)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_kgrad(const double* __restrict__ F, const double* __restrict__ K, const double* __restrict__ X, int64_t N, int64_t n0,
+        const double* __restrict__ Z, int M, int D, int64_t Nc, double* __restrict__ krow) {
+  __shared__ double sh[4];
+  const int m = blockIdx.x;
+  if (m >= M) return;
+  double zz[MAXD];
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) zz[d] = (d < D) ? Z[m * D + d] : 0.0;
+  double s0 = 0.0, s1[MAXD], s2[MAXD];
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) { s1[d] = 0.0; s2[d] = 0.0; }
+  const double* fr = F + (int64_t)m * Nc;
+  const double* kr = K + (int64_t)m * Nc;
+  for (int64_t n = threadIdx.x; n < Nc; n += 256) {
+    if (n0 + n >= N) break;
+    const double t = fr[n] * kr[n];
+    s0 += t;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d)
+      if (d < D) {
+        const double df = X[(n0 + n) * D + d] - zz[d];
+        const double td = t * df;
+        s1[d] += td;
+        s2[d] = fma(td, df, s2[d]);
+      }
+  }
+  const int W = 1 + 2 * D;
+  s0 = block_sum<4>(s0, sh);
+  if (threadIdx.x == 0) krow[(int64_t)m * W] += s0;
+  for (int d = 0; d < D; ++d) {
+    double a = block_sum<4>(s1[d], sh);
+    double b = block_sum<4>(s2[d], sh);
+    if (threadIdx.x == 0) { krow[(int64_t)m * W + 1 + d] += a; krow[(int64_t)m * W + 1 + D + d] += b; }
+  }
+}
+
+// Kuu -> (Z, ell, var) cotangent reductions with a symmetric G = dELBO/dKuu, block per row i:
+//   krow[i][0] += sum_j G Kz ; krow[i][1+d] += sum_j 2 G Kz (z_jd - z_id) ; krow[i][1+D+d] += sum_j G Kz (z_id-z_jd)^2
+// where Kz = Kuu - jitter*I.
+__global__ void __launch_bounds__(256)
+k_kuu_grad(const double* __restrict__ G, const double* __restrict__ Kuu, double jitter, const double* __restrict__ Z,
+           int M, int D, int64_t ld, double* __restrict__ krow) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x;
+  if (i >= M) return;
+  double zz[MAXD];
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) zz[d] = (d < D) ? Z[i * D + d] : 0.0;
+  double s0 = 0.0, s1[MAXD], s2[MAXD];
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) { s1[d] = 0.0; s2[d] = 0.0; }
+  for (int j = threadIdx.x; j < M; j += 256) {
+    double kz = Kuu[(int64_t)i * ld + j] - ((i == j) ? jitter : 0.0);
+    const double t = G[(int64_t)i * ld + j] * kz;
+    s0 += t;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d)
+      if (d < D) {
+        const double df = Z[j * D + d] - zz[d];
+        const double td = t * df;
+        s1[d] = fma(2.0, td, s1[d]);
+        s2[d] = fma(td, df, s2[d]);
+      }
+  }
+  const int W = 1 + 2 * D;
+  s0 = block_sum<4>(s0, sh);
+  if (threadIdx.x == 0) krow[(int64_t)i * W] += s0;
+  for (int d = 0; d < D; ++d) {
+    double a = block_sum<4>(s1[d], sh);
+    double b = block_sum<4>(s2[d], sh);
+    if (threadIdx.x == 0) { krow[(int64_t)i * W + 1 + d] += a; krow[(int64_t)i * W + 1 + D + d] += b; }
+  }
+}
+
+// dL[idx] = -sum_s part[s][idx] on/below the diagonal, 0 above  (L-bar of the two triangular solves)
+__global__ void k_reduce_planes_tril(const double* __restrict__ part, int S, int64_t Mp, double* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mp * Mp) return;
+  int64_t i = idx / Mp, j = idx - i * Mp;
+  double v = 0.0;
+  if (j <= i) {
+    for (int s = 0; s < S; ++s) v += part[(int64_t)s * Mp * Mp + idx];
+    v = -v;
+  }
+  out[idx] = v;
+}
+
+// G = 0.5*(S + S^T) - 0.5*(P - alpha alpha^T - PSP)   (KL part only if with_kl)
+__global__ void k_sym_combine(const double* __restrict__ S, const double* __restrict__ P, const double* __restrict__ PSP,
+                              const double* __restrict__ alpha, int with_data, int with_kl, int64_t Mp, double* __restrict__ G) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mp * Mp) return;
+  int64_t i = idx / Mp, j = idx - i * Mp;
+  double v = 0.0;
+  if (with_data) v = 0.5 * (S[i * Mp + j] + S[j * Mp + i]);
+  if (with_kl) v -= 0.5 * (0.5 * (P[i * Mp + j] + P[j * Mp + i]) - alpha[i] * alpha[j] - 0.5 * (PSP[i * Mp + j] + PSP[j * Mp + i]));
+  G[idx] = v;
+}
+
+// v = W u  (row-contiguous W), block per row
+__global__ void __launch_bounds__(256)
+k_gemv_rows(const double* __restrict__ W, const double* __restrict__ u, int64_t Mp, double* __restrict__ v) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x;
+  double a = 0.0;
+  for (int k = threadIdx.x; k <= i; k += 256) a = fma(W[(int64_t)i * Mp + k], u[k], a);
+  a = block_sum<4>(a, sh);
+  if (threadIdx.x == 0) v[i] = a;
+}
+// alpha[i] = sum_k W[k][i] v[k] ; dkinv[i] = sum_k W[k][i]^2   (thread per column)
+__global__ void k_kl_cols(const double* __restrict__ W, const double* __restrict__ v, int64_t Mp,
+                          double* __restrict__ alpha, double* __restrict__ dkinv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Mp) return;
+  double a = 0.0, b = 0.0;
+  for (int k = i; k < Mp; ++k) {
+    const double w = W[(int64_t)k * Mp + i];
+    a = fma(w, v[k], a);
+    b = fma(w, w, b);
+  }
+  alpha[i] = a; dkinv[i] = b;
+}
+// KL value (gauss_kl_diag, onofftf/main.py:218-250): one block.
+__global__ void __launch_bounds__(256)
+k_kl_value(const double* __restrict__ v, const double* __restrict__ L, const double* __restrict__ s, const double* __restrict__ dkinv,
+           int M, int64_t Mp, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double mah = 0.0, lq = 0.0, tr = 0.0, lp = 0.0;
+  for (int i = threadIdx.x; i < M; i += 256) {
+    mah = fma(v[i], v[i], mah);
+    const double si = s[i], li = L[(int64_t)i * Mp + i];
+    lq += log(si * si);
+    tr = fma(dkinv[i], si * si, tr);
+    lp += log(li * li);
+  }
+  mah = block_sum<4>(mah, sh); lq = block_sum<4>(lq, sh); tr = block_sum<4>(tr, sh); lp = block_sum<4>(lp, sh);
+  if (threadIdx.x == 0) out[0] = 0.5 * (mah - (double)M - lq + tr + lp);
+}
+
+__global__ void k_fill(double* p, int64_t n, double v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+// s2 = s*s
+__global__ void k_square(const double* s, double* s2, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) s2[i] = s[i] * s[i];
+}
+// Bs[k][j] = s2[k] * P[k][j]
+__global__ void k_rowscale(const double* __restrict__ P, const double* __restrict__ s2, int64_t Mp, double* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mp * Mp) return;
+  out[idx] = s2[idx / Mp] * P[idx];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cholesky of one 128x128 diagonal block + its triangular inverse, one workgroup, all in LDS.
+// (tf.cholesky, onofftf/main.py:200,268; the explicit inverse replaces the two
+// tf.matrix_triangular_solve calls :271,284 by GEMMs -- "W-form")
+// A/L/W point at the (j0,j0) block; ld = leading dimension.  info: first failing 1-based pivot index.
+// ---------------------------------------------------------------------------------------------
+constexpr int PB = 128, PBLD = 129;
+__global__ void __launch_bounds__(1024)
+k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __restrict__ W, int64_t ld, int j0, int* info) {
+  extern __shared__ double S[];   // [128][129]
+  __shared__ double dinv[PB];
+  const int t = threadIdx.x;
+  for (int idx = t; idx < PB * PB; idx += 1024) {
+    const int i = idx >> 7, j = idx & 127;
+    S[i * PBLD + j] = (j <= i) ? A[(int64_t)i * ld + j] : 0.0;
+  }
+  __syncthreads();
+  const int ti = t >> 5, tk = t & 31;   // 32 x 32 thread grid over (row, col) pairs
+  for (int j = 0; j < PB; ++j) {
+    const double d = S[j * PBLD + j];
+    if (!(d > 0.0)) {  // non-positive or NaN pivot: uniform across the block
+      if (t == 0) atomicCAS(info, 0, j0 + j + 1);
+      return;
+    }
+    const double rd = 1.0 / sqrt(d);
+    __syncthreads();
+    if (t > j && t < PB) S[t * PBLD + j] *= rd;
+    if (t == j) { S[j * PBLD + j] = sqrt(d); dinv[j] = rd; }
+    __syncthreads();
+    for (int i = j + 1 + ti; i < PB; i += 32) {
+      const double lij = S[i * PBLD + j];
+      for (int k = j + 1 + tk; k <= i; k += 32) S[i * PBLD + k] = fma(-lij, S[k * PBLD + j], S[i * PBLD + k]);
+    }
+    // next iteration's first __syncthreads orders these updates before the scaling writes
+    __syncthreads();
+  }
+  if (L) {
+    for (int idx = t; idx < PB * PB; idx += 1024) {
+      const int i = idx >> 7, j = idx & 127;
+      L[(int64_t)i * ld + j] = (j <= i) ? S[i * PBLD + j] : 0.0;
+    }
+  }
+  __syncthreads();
+  // Inverse: column c of Winv by forward substitution, 8 lanes per column; W[i][c] (i>c) kept at S[c][i].
+  const int c = t >> 3, q = t & 7;
+  for (int i = 0; i < PB; ++i) {
+    // all lanes iterate uniformly; only columns with c < i do work
+    double part = 0.0;
+    if (c < i) {
+      // sum_{k=c}^{i-1} L[i][k] * W[k][c];  W[c][c] = dinv[c]; W[k][c] at S[c][k] for k>c
+      for (int k = c + q; k < i; k += 8) {
+        const double wkc = (k == c) ? dinv[c] : S[c * PBLD + k];
+        part = fma(S[i * PBLD + k], wkc, part);
+      }
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if (c < i && q == 0) S[c * PBLD + i] = -part * dinv[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __syncthreads();
+  if (W) {
+    for (int idx = t; idx < PB * PB; idx += 1024) {
+      const int i = idx >> 7, j = idx & 127;
+      double v = 0.0;
+      if (j < i) v = S[j * PBLD + i]; else if (j == i) v = dinv[i];
+      W[(int64_t)i * ld + j] = v;
+    }
+  }
+}
+
+}  // namespace zigp

@@ -1,0 +1,104 @@
+"""ctypes binding of libzigp.so (include/zigp.h).  No CPU fallback: a missing library is an error."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, 'lib', 'libzigp.so')
+
+ZIGP_OK, ZIGP_EARG, ZIGP_EHIP, ZIGP_ENOTPD = 0, -1, -2, -3
+NCLASS = 7
+PROF_CLASSES = ('gemm_tri', 'syr2k', 'kuf_build', 'colred_pointwise', 'rowred_kgrad', 'mxm_stage', 'other')
+
+dp = C.POINTER(C.c_double)
+
+
+class ZigpError(RuntimeError):
+    pass
+
+
+class NotPositiveDefiniteError(ZigpError):
+    """Cholesky failed (the reference raises tf.errors.InvalidArgumentError at this point)."""
+
+
+class zigp_params(C.Structure):
+    _fields_ = [('Mf', C.c_int32), ('Mg', C.c_int32), ('D', C.c_int32), ('reserved', C.c_int32),
+                ('Zf', dp), ('Zg', dp), ('u_fm', dp), ('u_gm', dp), ('u_fs_sqrt', dp), ('u_gs_sqrt', dp),
+                ('ell_f', dp), ('ell_g', dp), ('var_f', C.c_double), ('var_g', C.c_double), ('noise', C.c_double)]
+
+
+class zigp_grads(C.Structure):
+    _fields_ = [('Zf', dp), ('Zg', dp), ('u_fm', dp), ('u_gm', dp), ('u_fs_sqrt', dp), ('u_gs_sqrt', dp),
+                ('ell_f', dp), ('ell_g', dp), ('var_f', C.c_double), ('var_g', C.c_double), ('noise', C.c_double)]
+
+
+class zigp_kron_params(C.Structure):
+    _fields_ = [('M0f', C.c_int32), ('M1f', C.c_int32), ('M0g', C.c_int32), ('M1g', C.c_int32),
+                ('D0', C.c_int32), ('D1', C.c_int32), ('reserved0', C.c_int32), ('reserved1', C.c_int32),
+                ('Z0f', dp), ('Z1f', dp), ('Z0g', dp), ('Z1g', dp),
+                ('ell0f', dp), ('ell1f', dp), ('ell0g', dp), ('ell1g', dp),
+                ('var0f', C.c_double), ('var1f', C.c_double), ('var0g', C.c_double), ('var1g', C.c_double),
+                ('u_fm', dp), ('u_gm', dp), ('u_fs_sqrt', dp), ('u_gs_sqrt', dp), ('noise', C.c_double)]
+
+
+class zigp_kron_grads(C.Structure):
+    _fields_ = [('Z0f', dp), ('Z1f', dp), ('Z0g', dp), ('Z1g', dp),
+                ('ell0f', dp), ('ell1f', dp), ('ell0g', dp), ('ell1g', dp),
+                ('var0f', C.c_double), ('var1f', C.c_double), ('var0g', C.c_double), ('var1g', C.c_double),
+                ('u_fm', dp), ('u_gm', dp), ('u_fs_sqrt', dp), ('u_gs_sqrt', dp), ('noise', C.c_double)]
+
+
+# name -> (restype, argtypes); mirrors include/zigp.h exactly (tests check every symbol resolves)
+SIGNATURES = {
+    'zigp_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    'zigp_destroy': (C.c_int, [C.c_void_p]),
+    'zigp_last_error': (C.c_char_p, [C.c_void_p]),
+    'zigp_last_info': (C.c_int, [C.c_void_p]),
+    'zigp_set_chunk': (C.c_int, [C.c_void_p, C.c_int64]),
+    'zigp_set_data': (C.c_int, [C.c_void_p, dp, dp, C.c_int64, C.c_int32]),
+    'zigp_set_data_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    'zigp_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                            C.c_int32, dp, dp, C.POINTER(zigp_grads)]),
+    'zigp_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), dp, C.c_int64, C.c_double, C.c_double, dp]),
+    'zigp_prior_kl': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), C.c_double, dp]),
+    'zigp_rbf_K': (C.c_int, [C.c_void_p, dp, C.c_int64, dp, C.c_int64, C.c_int32, dp, C.c_double, dp]),
+    'zigp_kron_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, dp, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                 C.c_int32, dp, dp, C.POINTER(zigp_kron_grads)]),
+    'zigp_kron_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, C.c_int64, C.c_double, C.c_double, dp]),
+    'zigp_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),
+    'zigp_profile_get': (C.c_int, [C.c_void_p, dp, C.POINTER(C.c_int64), dp]),
+    'zigp_profile_reset': (C.c_int, [C.c_void_p]),
+    'zigp_test_gemm': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, dp, dp, dp]),
+    'zigp_test_potrf_trtri': (C.c_int, [C.c_void_p, C.c_int64, dp, dp, dp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libzigp.so; raises ZigpError when it has not been built (there is NO CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZigpError('libzigp.so not found at %s: build it first (python __graft_entry__.py / zigp.build.build()). '
+                        'This engine has no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def as_f64(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def ptr(a):
+    return a.ctypes.data_as(dp)

@@ -1,0 +1,180 @@
+"""Host-side engine objects over the C-ABI (one context per GPU).
+
+DenseEngine drives the dense (OnOffSVGP) path: data is made resident in HBM once (`set_data`), then every
+`elbo` call is one ELBO value (+ gradient) = one optimiser step of the reference
+(GPflow Model.optimize function evaluation / sess.run(train_op), scripts/onoff.py:379).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ZigpError, NotPositiveDefiniteError, as_f64, ptr
+
+PARAM_KEYS = ('Zf', 'Zg', 'u_fm', 'u_gm', 'u_fs_sqrt', 'u_gs_sqrt', 'ell_f', 'ell_g', 'var_f', 'var_g', 'noise')
+
+
+def _check(lib, ctx, rc):
+    if rc == 0:
+        return
+    msg = lib.zigp_last_error(ctx)
+    msg = msg.decode() if msg else 'unknown error'
+    if rc == _lib.ZIGP_ENOTPD:
+        raise NotPositiveDefiniteError(msg)
+    if rc == _lib.ZIGP_EARG:
+        raise ValueError(msg)
+    raise ZigpError('libzigp error %d: %s' % (rc, msg))
+
+
+class _Packed:
+    """Keeps the numpy arrays behind a zigp_params struct alive."""
+
+    def __init__(self, p):
+        Zf, Zg = as_f64(p['Zf']), as_f64(p['Zg'])
+        if Zf.ndim != 2 or Zg.ndim != 2 or Zf.shape[1] != Zg.shape[1]:
+            raise ValueError('Zf and Zg must be (M,D) with equal D')
+        D = Zf.shape[1]
+        self.D, self.Mf, self.Mg = D, Zf.shape[0], Zg.shape[0]
+
+        def ell(v):
+            v = as_f64(v).reshape(-1)
+            if v.size == 1:
+                v = np.full(D, float(v[0]))
+            if v.size != D:
+                raise ValueError('lengthscales must be scalar or have D entries')
+            return np.ascontiguousarray(v)
+
+        self.arr = dict(Zf=Zf, Zg=Zg, u_fm=as_f64(p['u_fm']).reshape(-1), u_gm=as_f64(p['u_gm']).reshape(-1),
+                        u_fs_sqrt=as_f64(p['u_fs_sqrt']).reshape(-1), u_gs_sqrt=as_f64(p['u_gs_sqrt']).reshape(-1),
+                        ell_f=ell(p['ell_f']), ell_g=ell(p['ell_g']))
+        for k, M in (('u_fm', self.Mf), ('u_fs_sqrt', self.Mf), ('u_gm', self.Mg), ('u_gs_sqrt', self.Mg)):
+            if self.arr[k].size != M:
+                raise ValueError('%s must have %d entries' % (k, M))
+        s = _lib.zigp_params()
+        s.Mf, s.Mg, s.D = self.Mf, self.Mg, D
+        for k, a in self.arr.items():
+            setattr(s, k, ptr(a))
+        s.var_f, s.var_g, s.noise = float(np.squeeze(p['var_f'])), float(np.squeeze(p['var_g'])), float(np.squeeze(p['noise']))
+        self.struct = s
+
+
+class DenseEngine:
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        self.ctx = C.c_void_p()
+        rc = self.lib.zigp_create(C.byref(self.ctx), int(device))
+        if rc != 0:
+            raise ZigpError('zigp_create failed (rc=%d): no usable HIP device %d' % (rc, device))
+        self.N = 0
+        self.D = 0
+        self._keep = None
+
+    def close(self):
+        if self.ctx:
+            self.lib.zigp_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_chunk(self, rows):
+        _check(self.lib, self.ctx, self.lib.zigp_set_chunk(self.ctx, int(rows)))
+
+    def set_data(self, X, Y):
+        X = as_f64(X)
+        if X.ndim != 2:
+            raise ValueError('X must be (N,D)')
+        Y = as_f64(Y).reshape(-1)
+        if Y.size != X.shape[0]:
+            raise ValueError('Y must have N entries')
+        _check(self.lib, self.ctx, self.lib.zigp_set_data(self.ctx, ptr(X), ptr(Y), X.shape[0], X.shape[1]))
+        self.N, self.D = X.shape
+
+    def set_data_device(self, X_t, Y_t):
+        """Adopt torch CUDA float64 tensors (no copy); they are kept alive by this object."""
+        N, D = X_t.shape
+        assert X_t.is_contiguous() and Y_t.is_contiguous() and str(X_t.dtype) == 'torch.float64'
+        self._keep = (X_t, Y_t)
+        _check(self.lib, self.ctx, self.lib.zigp_set_data_device(self.ctx, C.c_void_p(X_t.data_ptr()), C.c_void_p(Y_t.data_ptr()), N, D))
+        self.N, self.D = N, D
+
+    def elbo(self, p, jitter=1e-6, scale=1.0, g_offset=0.0, rows=None, include_kl=True, need_grad=True):
+        """Returns (elbo_data, kl, grads or None); ELBO = elbo_data - kl."""
+        pk = _Packed(p)
+        r0, r1 = (0, self.N) if rows is None else rows
+        ed, kl = C.c_double(0), C.c_double(0)
+        gs, g = None, None
+        if need_grad:
+            g = dict(Zf=np.zeros((pk.Mf, pk.D)), Zg=np.zeros((pk.Mg, pk.D)), u_fm=np.zeros(pk.Mf), u_gm=np.zeros(pk.Mg),
+                     u_fs_sqrt=np.zeros(pk.Mf), u_gs_sqrt=np.zeros(pk.Mg), ell_f=np.zeros(pk.D), ell_g=np.zeros(pk.D))
+            gs = _lib.zigp_grads()
+            for k, a in g.items():
+                setattr(gs, k, ptr(a))
+        rc = self.lib.zigp_elbo(self.ctx, C.byref(pk.struct), float(jitter), float(scale), float(g_offset), int(r0), int(r1),
+                                1 if include_kl else 0, C.byref(ed), C.byref(kl), C.byref(gs) if gs is not None else None)
+        _check(self.lib, self.ctx, rc)
+        if need_grad:
+            g['var_f'], g['var_g'], g['noise'] = gs.var_f, gs.var_g, gs.noise
+        return ed.value, kl.value, g
+
+    def predict(self, p, Xnew, jitter=1e-6, g_offset=0.0):
+        """(9,N) array in the order of OnOffSVGP.build_predict (onoffgpf/OnOffSVGP.py:152)."""
+        pk = _Packed(p)
+        Xnew = as_f64(Xnew)
+        if Xnew.ndim != 2 or Xnew.shape[1] != pk.D:
+            raise ValueError('Xnew must be (N,%d)' % pk.D)
+        out = np.zeros((9, Xnew.shape[0]))
+        _check(self.lib, self.ctx, self.lib.zigp_predict(self.ctx, C.byref(pk.struct), ptr(Xnew), Xnew.shape[0], float(jitter),
+                                                          float(g_offset), ptr(out)))
+        return out
+
+    def prior_kl(self, p, jitter=1e-6):
+        pk = _Packed(p)
+        out = np.zeros(2)
+        _check(self.lib, self.ctx, self.lib.zigp_prior_kl(self.ctx, C.byref(pk.struct), float(jitter), ptr(out)))
+        return out
+
+    def rbf_K(self, X1, X2, ell, var):
+        X1 = as_f64(X1)
+        D = X1.shape[1]
+        X2a = X1 if X2 is None else as_f64(X2)
+        ell = as_f64(ell).reshape(-1)
+        if ell.size == 1:
+            ell = np.full(D, float(ell[0]))
+        out = np.zeros((X1.shape[0], X2a.shape[0]))
+        _check(self.lib, self.ctx, self.lib.zigp_rbf_K(self.ctx, ptr(X1), X1.shape[0], None if X2 is None else ptr(X2a), X2a.shape[0], D,
+                                                        ptr(ell), float(np.squeeze(var)), ptr(out)))
+        return out
+
+    # ---- measurement ----
+    def profile_enable(self, on=True):
+        _check(self.lib, self.ctx, self.lib.zigp_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        _check(self.lib, self.ctx, self.lib.zigp_profile_reset(self.ctx))
+
+    def profile_get(self):
+        ms = np.zeros(_lib.NCLASS)
+        n = np.zeros(_lib.NCLASS, dtype=np.int64)
+        fl = np.zeros(_lib.NCLASS)
+        _check(self.lib, self.ctx, self.lib.zigp_profile_get(self.ctx, ptr(ms), n.ctypes.data_as(C.POINTER(C.c_int64)), ptr(fl)))
+        return {name: dict(ms=float(ms[i]), launches=int(n[i]), flops=float(fl[i])) for i, name in enumerate(_lib.PROF_CLASSES)}
+
+    # ---- diagnostics ----
+    def test_gemm(self, A, B, transA=False, transB=False):
+        A, B = as_f64(A), as_f64(B)
+        m, k = (A.shape[1], A.shape[0]) if transA else A.shape
+        n = B.shape[0] if transB else B.shape[1]
+        out = np.zeros((m, n))
+        _check(self.lib, self.ctx, self.lib.zigp_test_gemm(self.ctx, int(transA), int(transB), m, n, k, ptr(A), ptr(B), ptr(out)))
+        return out
+
+    def test_potrf_trtri(self, A):
+        A = as_f64(A)
+        n = A.shape[0]
+        L, W = np.zeros((n, n)), np.zeros((n, n))
+        _check(self.lib, self.ctx, self.lib.zigp_test_potrf_trtri(self.ctx, n, ptr(A), ptr(L), ptr(W)))
+        return L, W
