@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""ELBO steps/sec (fp64) of the zero-inflated GP hot path on MI355X -- BASELINE.json's metric.
+
+Workload (config.workload): synthetic N=1e6 rows per GPU, D=3, M=1024 inducing points per latent
+(BASELINE.json configs[2]; generator of SURVEY.md section 8d).  One step = one full-data ELBO value plus
+its gradient w.r.t. every trainable parameter (= one L-BFGS-B function evaluation / one sess.run(train_op),
+scripts/onoff.py:379).  Data is resident in HBM before the timed region.  With --gpus N (launched by
+torch.distributed.run, one rank per GPU) every rank holds its own 1e6-row shard (weak scaling, = cfg4 at N=8)
+and the packed [ELBO, gradient] vector is all-reduced over RCCL each step; `value` counts 1e6-row ELBO steps
+per second summed over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'zero-inflated-gp_amd'))
+
+PEAK_FP64_MFMA = 78.6e12   # vendor fp64 matrix peak, MI355X (256 CU x 2.4 GHz x 128 flop/clk/CU); see DESIGN.md
+
+
+def synth(N, M, D, rank=0):
+    """SURVEY.md section 8d generator; rank r of a multi-GPU run draws its own shard (seed r)."""
+    rs = np.random.RandomState(rank)
+    X = rs.rand(N, D)
+    f = np.sin(2 * np.pi * X[:, 0]) * np.cos(2 * np.pi * X[:, 1]) + X[:, 2]
+    g = 2 * np.sin(2 * np.pi * (X[:, 0] + X[:, 2]))
+    Y = np.where(g + rs.randn(N) > 0, f + 0.1 * rs.randn(N), 0.0)
+    Z = np.random.RandomState(1001).rand(M, D)
+    ru = np.random.RandomState(1002)
+    p = dict(Zf=Z.copy(), Zg=Z.copy(), u_fm=0.01 * ru.randn(M, 1), u_gm=0.01 * ru.randn(M, 1),
+             u_fs_sqrt=np.ones((M, 1)), u_gs_sqrt=np.ones((M, 1)), ell_f=np.full(D, 0.1), ell_g=np.full(D, 0.1),
+             var_f=1.0, var_g=5.0, noise=0.01)
+    return X, Y, p
+
+
+def cpu_baseline(X, Y, p, jitter, sample_rows, threads):
+    """The CPU oracle (reference op order + autograd) timed on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import torch
+    import zigp_oracle_torch as ot
+    torch.set_num_threads(threads)
+    Xs, Ys = X[:sample_rows], Y[:sample_rows]
+    ot.elbo_and_grad(Xs[:2000], Ys[:2000], p, jitter, chunk=2000)          # warm-up
+    t0 = time.time()
+    elbo, data, kl, g = ot.elbo_and_grad(Xs, Ys, p, jitter, chunk=20000)
+    dt = time.time() - t0
+    return dt, data
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--rows', type=int, default=1000000, help='rows per GPU')
+    ap.add_argument('--M', type=int, default=1024)
+    ap.add_argument('--D', type=int, default=3)
+    ap.add_argument('--chunk', type=int, default=16384)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-rows', type=int, default=60000)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        dist = dist_mod
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+
+    import zigp
+    from zigp.parallel import ShardedELBO
+    N, M, D, jitter = args.rows, args.M, args.D, 1e-6
+    X, Y, p = synth(N, M, D, rank)
+    eng = zigp.DenseEngine(local_rank)        # raises if libzigp.so is missing: no CPU fallback
+    eng.set_chunk(args.chunk)
+    Xd = torch.from_numpy(X).to('cuda:%d' % local_rank)
+    Yd = torch.from_numpy(Y).to('cuda:%d' % local_rank)
+    eng.set_data_device(Xd, Yd)               # inputs resident in HBM before timing
+    sh = ShardedELBO(eng, dist, device='cuda:%d' % local_rank)
+    scale = 1.0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = sh.elbo(p, jitter=jitter, scale=scale)
+    eng.profile_enable(True)
+    eng.profile_reset()
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        out = sh.elbo(p, jitter=jitter, scale=scale)
+    barrier()
+    dt = time.time() - t0
+    prof = eng.profile_get()
+    eng.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda:%d' % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    elbo_gpu = out[0] - out[1]
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * args.steps / dt * (N / 1e6)
+        gk = prof['gemm_tri']
+        avg_launch_s = gk['ms'] * 1e-3 / max(gk['launches'], 1)
+        flops_per_launch = gk['flops'] / max(gk['launches'], 1)
+        achieved = flops_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
+        res = {
+            'metric': 'elbo_steps_per_sec', 'value': value, 'unit': 'ELBO steps/s (value+gradient, 1e6-row steps, fp64)',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'dense zero-inflated GP ELBO step, N=%d rows/GPU, D=%d, M=%d per latent, full batch' % (N, D, M),
+                       'rows_per_gpu': N, 'M': M, 'D': D, 'chunk_rows': args.chunk, 'jitter': jitter,
+                       'parallelism': 'row-shard x%d, 1 all-reduce/step' % world},
+            'elbo': elbo_gpu,
+            'roofline': {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': PEAK_FP64_MFMA / 1e12, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP64_MFMA, 'traffic': None,
+                         'kernel': 'gemm_f64_kernel (triangular A1/A2/E/F products)',
+                         'flops_per_launch': flops_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
+                         'step_frac_algorithmic': (12.0 * M * M * N / (dt / args.steps)) / PEAK_FP64_MFMA},
+            'kernel_ms_per_step': {k: v['ms'] / args.steps for k, v in prof.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            threads = min(16, os.cpu_count() or 1)
+            srows = min(args.cpu_sample_rows, N)
+            cdt, cdata = cpu_baseline(X, Y, p, jitter, srows, threads)
+            gdata = eng.elbo(p, jitter=jitter, rows=(0, srows), include_kl=False, need_grad=False)[0]
+            res['cpu_baseline'] = {'value': 1.0 / (cdt * N / srows), 'unit': 'ELBO steps/s (extrapolated to %d rows)' % N,
+                                   'cores': threads, 'kind': 'port',
+                                   'sample': 'oracle (torch CPU fp64, reference op order + autograd) on the first %d rows in 20000-row chunks: %.2f s' % (srows, cdt),
+                                   'elbo_data_rel_diff_on_sample': abs(gdata - cdata) / abs(cdata)}
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()
