@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--rows', type=int, default=1000000, help='rows per GPU')
     ap.add_argument('--M', type=int, default=1024)
     ap.add_argument('--D', type=int, default=3)
-    ap.add_argument('--chunk', type=int, default=16384)
+    ap.add_argument('--chunk', type=int, default=32768)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-rows', type=int, default=60000)
     args = ap.parse_args()

@@ -1,0 +1,119 @@
+"""CPU suite, part 1: the oracle itself (NumPy restatement, torch twin) against the golden fixtures,
+extended-precision evaluations and finite differences.  No GPU, no reference tree needed."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_problem, relerr
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_rbf_matches_reference_kernse_np_golden():
+    """G1: fixtures produced by the reference's own kernse_np (onofftf/utils.py:26-58)."""
+    import zigp_oracle as o
+    g = np.load(os.path.join(GOLD, 'g1_kernse_np.npz'))
+    for tag in ('d1', 'd3s', 'd3ard'):
+        Z, X, ell, var = g[tag + '_Z'], g[tag + '_X'], g[tag + '_ell'], g[tag + '_var']
+        assert np.array_equal(o.rbf_K(Z, X, ell, var), g[tag + '_Kzx'])      # same op order -> bitwise
+        assert np.array_equal(o.rbf_K(Z, None, ell, var), g[tag + '_Kzz'])
+        assert np.array_equal(o.rbf_Kdiag(X, var), g[tag + '_Kdiag'])
+
+
+def test_oracle_frozen_against_g2():
+    """G2 freezes the restatement (values produced by this repo's oracle, not by the reference)."""
+    import zigp_oracle as o
+    g = np.load(os.path.join(GOLD, 'g2_dense_oracle.npz'))
+    for tag in ('toy', 'd3'):
+        p = {k[len(tag) + 3:]: g[k] for k in g.files if k.startswith(tag + '_p_')}
+        pred = o.build_predict(g[tag + '_X'], p, 1e-6, 0.0)
+        assert relerr(np.stack([q.reshape(-1) for q in pred]), g[tag + '_pred']) < 1e-12
+        e, d, klf, klg = o.elbo(g[tag + '_X'], g[tag + '_Y'], p, 1e-6, scale=1.3)
+        assert abs(e - float(g[tag + '_elbo'])) < 1e-8 * abs(e)   # fixture value came from the torch twin
+        assert abs(klf - float(g[tag + '_klf'])) < 1e-10 * abs(klf)
+
+
+def test_torch_twin_matches_numpy_and_chunking_is_exact():
+    import zigp_oracle as o
+    import zigp_oracle_torch as ot
+    X, Y, p = make_problem(700, 30, 3, seed=3)
+    e, d, klf, klg = o.elbo(X, Y, p, 1e-6, scale=2.0, g_offset=-0.25)
+    et, dt, klt, g = ot.elbo_and_grad(X, Y, p, 1e-6, scale=2.0, g_offset=-0.25, chunk=256)
+    assert abs(e - et) < 1e-11 * abs(e) and abs(klt - (klf + klg)) < 1e-11 * abs(klt) and abs(d - dt) < 1e-11 * abs(d)
+    ec = o.elbo_chunked(X, Y, p, 1e-6, chunk=100, scale=2.0, g_offset=-0.25)[0]
+    assert abs(ec - e) < 1e-12 * abs(e)
+
+
+def test_gradient_matches_central_differences():
+    import zigp_oracle as o
+    import zigp_oracle_torch as ot
+    X, Y, p = make_problem(200, 12, 2, seed=9, ell=0.6)     # well conditioned -> FD is meaningful
+    _, _, _, g = ot.elbo_and_grad(X, Y, p, 1e-6, scale=1.5)
+
+    def f(pp):
+        return o.elbo(X, Y, pp, 1e-6, scale=1.5)[0]
+
+    rs = np.random.RandomState(0)
+    for key in ot.PARAM_KEYS:
+        base = np.array(p[key], dtype=np.float64)
+        for _ in range(2):
+            idx = tuple(rs.randint(s) for s in base.shape) if base.ndim else ()
+            h = 1e-5 * max(1.0, abs(float(base[idx]) if base.ndim else float(base)))
+            pp, pm = dict(p), dict(p)
+            bp, bm = base.copy(), base.copy()
+            if base.ndim:
+                bp[idx] += h
+                bm[idx] -= h
+            else:
+                bp, bm = base + h, base - h
+            pp[key], pm[key] = bp, bm
+            fd = (f(pp) - f(pm)) / (2 * h)
+            an = float(np.asarray(g[key])[idx]) if base.ndim else float(g[key])
+            assert abs(fd - an) <= 2e-5 * max(abs(an), 1.0), (key, idx, fd, an)
+
+
+def test_probit_moments_against_mpmath():
+    """OnOffSVGP.ProbitExpectations (onoffgpf/OnOffSVGP.py:168-204) evaluated with 40 digits."""
+    import mpmath as mp
+    import zigp_oracle as o
+    mp.mp.dps = 40
+    rs = np.random.RandomState(1)
+    gm, gv = rs.randn(50) * 3, rs.rand(50) * 4 + 1e-3
+    e1, e2, ev = o.probit_expectations(gm, gv)
+    for i in range(50):
+        z = mp.mpf(gm[i]) / mp.sqrt(1 + mp.mpf(gv[i]))
+        a = 1 / mp.sqrt(1 + 2 * mp.mpf(gv[i]))
+        cdf = mp.mpf('0.5') * (1 + mp.erf(z / mp.sqrt(2))) * (1 - mp.mpf('2e-3')) + mp.mpf('1e-3')
+        T = mp.atan(a) / (2 * mp.pi) * mp.exp(-mp.mpf('0.5') * z * z * (a * a + 1))
+        r2, rv = cdf - 2 * T, cdf - 2 * T - cdf * cdf
+        assert abs(e1[i] - float(cdf)) < 1e-14
+        assert abs(e2[i] - float(max(r2, 0))) < 1e-14 and abs(ev[i] - float(max(rv, 0))) < 1e-14
+
+
+def test_kronecker_literal_equals_factored_identities():
+    """The identities the HIP Kronecker kernels rely on, checked on the literal oracle."""
+    import zigp_oracle as o
+    from scipy.linalg import cholesky
+    rs = np.random.RandomState(4)
+    Ms, Mt, Nb = 6, 5, 40
+    Zl = [rs.rand(Ms, 2) * 10, np.linspace(0, 1, Mt)[:, None]]
+    ell, var = [np.array([3.0, 4.0]), np.array([0.3])], [np.array([2.0]), np.array([1.5])]
+    X = np.hstack([rs.rand(Nb, 2) * 10, rs.rand(Nb, 1)])
+    u, s = rs.randn(Ms * Mt, 1), 0.5 + rs.rand(Ms * Mt, 1)
+    mu, v = o.kron_inf(X, Zl, ell, var, u, s, 1e-5)
+    Ks = o.rbf_K(Zl[0], None, ell[0], var[0]) + 1e-5 * np.eye(Ms)
+    Kt = o.rbf_K(Zl[1], None, ell[1], var[1]) + 1e-5 * np.eye(Mt)
+    ks, kt = o.rbf_K(Zl[0], X[:, :2], ell[0], var[0]), o.rbf_K(Zl[1], X[:, 2:], ell[1], var[1])
+    a_s, a_t = np.linalg.solve(Ks, ks), np.linalg.solve(Kt, kt)
+    alpha = (np.linalg.inv(Ks) @ u.reshape(Ms, Mt) @ np.linalg.inv(Kt).T)
+    mu_f = np.einsum('in,ij,jn->n', ks, alpha, kt)
+    var_f = var[0] * var[1] - (ks * a_s).sum(0) * (kt * a_t).sum(0) + np.einsum('in,ij,jn->n', a_s ** 2, (s ** 2).reshape(Ms, Mt), a_t ** 2)
+    assert relerr(mu_f, mu.reshape(-1)) < 1e-9 and relerr(var_f, v.reshape(-1)) < 1e-8
+    kl = o.gauss_kl_kron(u, s, [Ks, Kt])
+    Ls, Lt = cholesky(Ks, lower=True), cholesky(Kt, lower=True)
+    dk = np.outer(np.diag(np.linalg.inv(Ks)), np.diag(np.linalg.inv(Kt))).reshape(-1, 1)
+    logdet = Mt * 2 * np.log(np.diag(Ls)).sum() + Ms * 2 * np.log(np.diag(Lt)).sum()
+    al = np.linalg.solve(Ls, u.reshape(Ms, Mt)) @ np.linalg.inv(Lt).T
+    kl_f = 0.5 * ((al ** 2).sum() - Ms * Mt - np.log(s ** 2).sum() + (dk * s ** 2).sum() + logdet)
+    assert abs(kl - kl_f) < 1e-10 * abs(kl)

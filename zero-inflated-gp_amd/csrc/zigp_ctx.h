@@ -56,7 +56,7 @@ struct zigp_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   int info = 0;
-  int64_t chunk = 16384;
+  int64_t chunk = 32768;
   // data
   const double* dX = nullptr; const double* dY = nullptr;
   zigp::DevBuf ownX, ownY;

@@ -46,11 +46,20 @@ inline GemmTile mk_tile(int bi, int bj, int kbeg, int kend, int slice = 0) {
   GemmTile t; t.bi = bi; t.bj = bj; t.kbeg = kbeg; t.kend = kend; t.slice = slice; t.pad0 = t.pad1 = t.pad2 = 0; return t;
 }
 
-template <int AL, int BL, class BP, class EP>
-int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, BP bp, EP ep) {
+constexpr int NST = ZIGP_NSTAGE;   // LDS ring depth of the GEMM core (2 -> 64 KB, 2 workgroups/CU; 3-4 -> 1 workgroup/CU)
+
+template <int AL, int BL, class EP>
+int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
   if (tl.n == 0) return 0;
   g.tiles = tl.d;
-  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, BP, EP>), dim3(tl.n), dim3(GEMM_THREADS), 0, c->stream, g, bp, ep);
+  constexpr size_t shm = sizeof(double) * NST * STAGE_DOUBLES;
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<AL, BL, NST, EP>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, EP>), dim3(tl.n), dim3(GEMM_THREADS), shm, c->stream, g, ep);
   ZIGP_HIP(c, hipGetLastError());
   return 0;
 }
@@ -115,7 +124,7 @@ int check_info(zigp_ctx* c, const char* what) {
 int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool want_W) {
   const int nb = Mp / BM;
   const int kb = BM / BK;  // k-steps per block
-  ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+  // c->d_info is cleared by the caller (several factorizations may share one check_info)
   ZIGP_HIP(c, hipMemsetAsync(Wb, 0, sizeof(double) * Mp * Mp, c->stream));
   const size_t shm = sizeof(double) * PB * PBLD;
   for (int j = 0; j < nb; ++j) {
@@ -129,13 +138,13 @@ int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool wa
         for (int bi = j + 1; bi < nb; ++bi) v.push_back(mk_tile(bi, j, j * kb, (j + 1) * kb));
       }, tp));
       // L[bi][j] = A[bi][j] * W_jj^T   (in place: each tile reads only itself and W_jj)
-      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, tp, mk_args(Lb, Mp, Wb, Mp, Lb, Mp), BIdentity(), EpiStore())));
+      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, tp, mk_args(Lb, Mp, Wb, Mp, Lb, Mp), EpiStore())));
       ZIGP_TRY(get_tiles(c, "po_s:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
         for (int bi = j + 1; bi < nb; ++bi)
           for (int bj = j + 1; bj <= bi; ++bj) v.push_back(mk_tile(bi, bj, j * kb, (j + 1) * kb));
       }, ts));
       // A[bi][bj] -= L[bi][j] L[bj][j]^T
-      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, ts, mk_args(Lb, Mp, Lb, Mp, Lb, Mp, -1.0), BIdentity(), EpiAccum())));
+      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, ts, mk_args(Lb, Mp, Lb, Mp, Lb, Mp, -1.0), EpiAccum())));
     }
   }
   // zero the strictly-upper blocks of L (they still hold the copy of A)
@@ -154,7 +163,7 @@ int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool wa
           for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, mid * kb));
       }
     }, t1));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t1, mk_args(Lb, Mp, Wb, Mp, Tb, Mp), BIdentity(), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t1, mk_args(Lb, Mp, Wb, Mp, Tb, Mp), EpiStore())));
     ZIGP_TRY(get_tiles(c, "tri2:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
       for (int lo = 0; lo < nb; lo += 2 * b) {
         const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
@@ -163,7 +172,7 @@ int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool wa
           for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, mid * kb, (bi + 1) * kb));
       }
     }, t2));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t2, mk_args(Wb, Mp, Tb, Mp, Wb, Mp, -1.0), BIdentity(), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t2, mk_args(Wb, Mp, Tb, Mp, Wb, Mp, -1.0), EpiStore())));
   }
   return 0;
 }
@@ -246,11 +255,11 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {
     ProfScope ps(c, PC_GEMM, fl);
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), BIdentity(), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), EpiStore())));
   }
   {
     ProfScope ps(c, PC_GEMM, fl);
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), BIdentity(), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), EpiStore())));
   }
   {
     ProfScope ps(c, PC_POINT);
@@ -274,18 +283,22 @@ int latent_chunk_backward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nro
   ZIGP_TRY(tiles_syr2k(c, nbm, (int)(Nc / BK), SYR_SLICES, ts));
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {
-    ProfScope ps(c, PC_GEMM, fl);
-    BProdDA2 bp{lt.gm.p, lt.gv.p, lt.u.p, lt.s2.p};
-    EpiDA1 ep{lt.A1.p, c->dA1.p, lt.gv.p};
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, mk_args(lt.W.p, Mp, lt.A2.p, Nc, c->E.p, Nc), bp, ep)));
+    ProfScope ps(c, PC_RED);   // du, ds partials and dA2 (into the F panel, consumed by the E product below)
+    hipLaunchKernelGGL(k_rowred_da2, dim3(Mp), dim3(256), 0, c->stream, lt.A2.p, lt.gm.p, lt.gv.p, Nc, lt.u.p, lt.s2.p, lt.du.p,
+                       lt.dsq.p, c->F.p);
+    ZIGP_HIP(c, hipGetLastError());
   }
   {
     ProfScope ps(c, PC_GEMM, fl);
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tu, mk_args(lt.W.p, Mp, c->dA1.p, Nc, c->F.p, Nc), BIdentity(), EpiStore())));
+    EpiDA1 ep{lt.A1.p, c->dA1.p, lt.gv.p};
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, mk_args(lt.W.p, Mp, c->F.p, Nc, c->E.p, Nc), ep)));
+  }
+  {
+    ProfScope ps(c, PC_GEMM, fl);
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tu, mk_args(lt.W.p, Mp, c->dA1.p, Nc, c->F.p, Nc), EpiStore())));
   }
   {
     ProfScope ps(c, PC_RED);
-    hipLaunchKernelGGL(k_rowred, dim3(Mp), dim3(256), 0, c->stream, lt.A2.p, lt.gm.p, lt.gv.p, Nc, lt.du.p, lt.dsq.p);
     hipLaunchKernelGGL(k_kgrad, dim3(Mp), dim3(256), 0, c->stream, c->F.p, lt.K.p, dX, Nrows, n0, lt.Z.p, lt.M, D, Nc, lt.krow.p);
     ZIGP_HIP(c, hipGetLastError());
   }
@@ -294,7 +307,7 @@ int latent_chunk_backward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nro
     GemmArgs g = mk_args(c->F.p, Nc, lt.A1.p, Nc, lt.dLpart.p, Mp);
     g.seg[1].A = lt.A2.p; g.seg[1].B = c->E.p; g.seg[1].lda = Nc; g.seg[1].ldb = Nc;
     g.nseg = 2; g.slice_stride = (int64_t)Mp * Mp;
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, ts, g, BIdentity(), EpiAccum())));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, ts, g, EpiAccum())));
   }
   return 0;
 }
@@ -315,19 +328,19 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
       for (int bi = 0; bi < nb; ++bi)
         for (int bj = 0; bj < nb; ++bj) v.push_back(bj <= bi ? mk_tile(bi, bj, bi * kb, nb * kb) : mk_tile(bi, bj, 0, 0));
     }, t1));
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t1, mk_args(lt.L.p, Mp, lt.T1.p, Mp, lt.T2.p, Mp), BIdentity(), EpiPhi())));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t1, mk_args(lt.L.p, Mp, lt.T1.p, Mp, lt.T2.p, Mp), EpiPhi())));
     // T = Q W -> T3 (lower)
     ZIGP_TRY(get_tiles(c, "bw_t:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
       for (int bi = 0; bi < nb; ++bi)
         for (int bj = 0; bj < nb; ++bj) v.push_back(bj <= bi ? mk_tile(bi, bj, bj * kb, (bi + 1) * kb) : mk_tile(bi, bj, 0, 0));
     }, t2));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t2, mk_args(lt.T2.p, Mp, lt.W.p, Mp, lt.T3.p, Mp), BIdentity(), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t2, mk_args(lt.T2.p, Mp, lt.W.p, Mp, lt.T3.p, Mp), EpiStore())));
     // S = W^T T -> T1
     ZIGP_TRY(get_tiles(c, "bw_s:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
       for (int bi = 0; bi < nb; ++bi)
         for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, std::max(bi, bj) * kb, nb * kb));
     }, t3));
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t3, mk_args(lt.W.p, Mp, lt.T3.p, Mp, lt.T1.p, Mp), BIdentity(), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t3, mk_args(lt.W.p, Mp, lt.T3.p, Mp, lt.T1.p, Mp), EpiStore())));
   }
   double* P = lt.T2.p; double* PSP = lt.G.p;
   if (with_kl) {
@@ -337,11 +350,11 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
         for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, std::max(bi, bj) * kb, nb * kb));
     }, t3));
     // P = W^T W -> T2
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t3, mk_args(lt.W.p, Mp, lt.W.p, Mp, lt.T2.p, Mp), BIdentity(), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t3, mk_args(lt.W.p, Mp, lt.W.p, Mp, lt.T2.p, Mp), EpiStore())));
     // Ps = diag(s2) P -> T3 ; PSP = P Ps -> G
     hipLaunchKernelGGL(k_rowscale, dim3(gridmm), dim3(256), 0, c->stream, lt.T2.p, lt.s2.p, (int64_t)Mp, lt.T3.p);
     ZIGP_TRY(tiles_full(c, nb, nb, nb * kb, tf));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tf, mk_args(lt.T2.p, Mp, lt.T3.p, Mp, lt.G.p, Mp), BIdentity(), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tf, mk_args(lt.T2.p, Mp, lt.T3.p, Mp, lt.G.p, Mp), EpiStore())));
   }
   // G = sym(S) - dKL/dKuu -> T3 (T3 free again)
   hipLaunchKernelGGL(k_sym_combine, dim3(gridmm), dim3(256), 0, c->stream, S, P, PSP, lt.vec.p + Mp, with_data ? 1 : 0, with_kl ? 1 : 0,
@@ -371,6 +384,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   const bool has_rows = row_end > row_begin;
   HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
   const double* ell_h[2] = {p->ell_f, p->ell_g};
+  ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
   for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], D, jitter, true));
   ZIGP_TRY(check_info(c, "Kuu"));
   if (include_kl && !predict)
@@ -395,7 +409,10 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
       if (has_rows) ZIGP_HIP(c, hipMemsetAsync(lt.dLpart.p, 0, sizeof(double) * SYR_SLICES * Mp * Mp, c->stream));
     }
   }
-  for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc) {
+  const int64_t Nc_full = Nc;
+  for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc_full) {
+    // the last (partial) chunk shrinks to the next multiple of 1024 rows
+    Nc = std::min<int64_t>(Nc_full, round_up(row_end - n0, 1024));
     for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], dX, Nrows, n0, Nc, D, ell_h[h]));
     {
       ProfScope ps(c, PC_POINT);
@@ -404,8 +421,9 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
       a.var_f = p->var_f; a.var_g = p->var_g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
       a.gm_f = need_grad ? c->lat[0].gm.p : nullptr; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
       a.acc = c->pw_part.p; a.out9 = d_out9 ? d_out9 - row_begin : nullptr; a.ld9 = row_end - row_begin;
-      if (predict) hipLaunchKernelGGL(k_pointwise<true>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
-      else hipLaunchKernelGGL(k_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
+      const int nblk = (int)(Nc / PW_THREADS);
+      if (predict) hipLaunchKernelGGL(k_pointwise<true>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
+      else hipLaunchKernelGGL(k_pointwise<false>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
       ZIGP_HIP(c, hipGetLastError());
     }
     if (need_grad)
@@ -586,6 +604,7 @@ int zigp_prior_kl(zigp_ctx* c, const zigp_params* p, double jitter, double* kl2)
   if (!kl2) return fail_arg(c, "zigp_prior_kl: kl2 is NULL");
   ZIGP_HIP(c, hipSetDevice(c->device));
   HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
+  ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
   for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], p->D, jitter, true));
   ZIGP_TRY(check_info(c, "Kuu"));
   for (int h = 0; h < 2; ++h) {
@@ -651,10 +670,10 @@ int zigp_test_gemm(zigp_ctx* c, int32_t transA, int32_t transB, int64_t m, int64
     TileList tl;
     ZIGP_TRY(tiles_full(c, (int)(mp / BM), (int)(np / BN), (int)(kp / BK), tl));
     GemmArgs g = mk_args(da.p, ac, db.p, bc, dc.p, np);
-    if (!transA && !transB) ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, g, BIdentity(), EpiStore())));
-    if (transA && !transB) ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tl, g, BIdentity(), EpiStore())));
-    if (!transA && transB) ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, tl, g, BIdentity(), EpiStore())));
-    if (transA && transB) ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_KCONTIG>(c, tl, g, BIdentity(), EpiStore())));
+    if (!transA && !transB) ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, g, EpiStore())));
+    if (transA && !transB) ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tl, g, EpiStore())));
+    if (!transA && transB) ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, tl, g, EpiStore())));
+    if (transA && transB) ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_KCONTIG>(c, tl, g, EpiStore())));
     ZIGP_HIP(c, hipMemcpyAsync(hc.data(), dc.p, sizeof(double) * hc.size(), hipMemcpyDeviceToHost, c->stream));
     ZIGP_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -680,6 +699,7 @@ int zigp_test_potrf_trtri(zigp_ctx* c, int64_t n, const double* A, double* L, do
   auto body = [&]() -> int {
     ZIGP_ENSURE(c, dl, ha.size()); ZIGP_ENSURE(c, dw, ha.size()); ZIGP_ENSURE(c, dt, ha.size());
     ZIGP_HIP(c, hipMemcpyAsync(dl.p, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice, c->stream));
+    ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
     ZIGP_TRY(potrf_trtri(c, dl.p, dw.p, dt.p, Mp, true));
     ZIGP_TRY(check_info(c, "A"));
     std::vector<double> ho(ha.size());

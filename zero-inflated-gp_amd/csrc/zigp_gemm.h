@@ -11,8 +11,11 @@
 //     acc[r] of lane l = C[4r + l/16][l%16].
 //   * workgroup = 256 threads = 4 waves (2x2), tile 128x128, BK = 16; wave tile 64x64 = 16 sub-tiles,
 //     64 independent accumulators per lane (128 VGPRs) -> MFMA issue is never dependency-bound.
-//   * operand tiles are staged global -> registers -> LDS (padded rows: conflict-free ds_read_b64),
-//     next tile's global loads are in flight during the MFMAs of the current one.
+//   * operand tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into an
+//     NSTAGE-deep ring; the LDS image is lane-linear, so bank conflicts are removed by an XOR swizzle of
+//     the 16-byte granule index applied on the SOURCE address and again on every ds_read
+//     (cdna_hip_programming.md rule 21).  One s_barrier per BK step; counted vmcnt keeps NSTAGE-2
+//     stages in flight across it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,9 +23,8 @@
 namespace zigp {
 
 constexpr int BM = 128, BN = 128, BK = 16, GEMM_THREADS = 256;
-constexpr int LDK = BK + 2;     // row stride (doubles) of a k-contiguous tile  [128][18]
-constexpr int LDMN = BM + 16;   // row stride (doubles) of an m/n-contiguous tile [16][144]
-constexpr int TILE_DOUBLES = 128 * LDK;  // == 16*LDMN == 2304
+constexpr int TILE_DOUBLES = 128 * BK;            // 2048 doubles = 16 KB per operand tile
+constexpr int STAGE_DOUBLES = 2 * TILE_DOUBLES;   // A tile + B tile
 
 // Operand layouts: element (i,k) of A / (k,j) of B
 enum { LAY_KCONTIG = 0,   // A[i*ld + k]   /  B[j*ld + k]
@@ -47,20 +49,6 @@ struct GemmArgs {
   double alpha;
 };
 
-// ---- B-operand producers: transform values as they are staged (k = row of B, n = column of B) ----
-struct BIdentity {
-  __device__ __forceinline__ double2 operator()(int64_t, int64_t, double2 v) const { return v; }
-};
-// dA2[m,n] = gm[n]*u[m] + 2*gv[n]*s2[m]*A2[m,n]   (cotangent of A2 = L^-T A1: mean = A2^T u, var += sum (s A2)^2;
-// onofftf/main.py:287,291,302 differentiated).  B is n-contiguous: v = (A2[k][n], A2[k][n+1]).
-struct BProdDA2 {
-  const double* gm; const double* gv; const double* u; const double* s2;
-  __device__ __forceinline__ double2 operator()(int64_t k, int64_t n, double2 v) const {
-    double uk = u[k], sk = 2.0 * s2[k];
-    double2 r; r.x = gm[n] * uk + gv[n] * sk * v.x; r.y = gm[n + 1] * uk + gv[n + 1] * sk * v.y; return r;
-  }
-};
-
 // ---- epilogues: called once per accumulator element with its global (row, col) ----
 struct EpiStore {   // C = alpha*acc
   __device__ __forceinline__ void operator()(double* C, int64_t ldc, int64_t i, int64_t j, double v) const { C[i * ldc + j] = v; }
@@ -75,45 +63,41 @@ struct EpiDA1 {
     C[i * ldc + j] = v; dA1[i * ldc + j] = v - 2.0 * gv[j] * A1[i * ldc + j];
   }
 };
-// C = alpha*acc on/below the diagonal, 0 above (used where only tril is meaningful)
-struct EpiStoreTril {
-  __device__ __forceinline__ void operator()(double* C, int64_t ldc, int64_t i, int64_t j, double v) const { C[i * ldc + j] = (j <= i) ? v : 0.0; }
-};
 
+// LDS index (in doubles) of tile element; `mn` = row of A / column of B within the tile, k in [0,16)
 template <int LAY>
-__device__ __forceinline__ void load_tile_regs(double2 (&r)[4], const double* __restrict__ P, int64_t ld,
-                                               int64_t mn0, int64_t k0, int t) {
-  if (LAY == LAY_KCONTIG) {            // 128 rows x 16 k ; thread: row = t/8 + 32p, kk = (t%8)*2
-    const int kk = (t & 7) * 2, row = t >> 3;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      r[p] = *reinterpret_cast<const double2*>(P + (mn0 + row + 32 * p) * ld + k0 + kk);
-  } else {                              // 16 k-rows x 128 mn ; thread: krow = t/64 + 4p, mm = (t%64)*2
-    const int mm = (t & 63) * 2, krow = t >> 6;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      r[p] = *reinterpret_cast<const double2*>(P + (k0 + krow + 4 * p) * ld + mn0 + mm);
-  }
+__device__ __forceinline__ int lds_idx(int mn, int k) {
+  if (LAY == LAY_KCONTIG) return mn * 16 + 2 * ((k >> 1) ^ ((mn >> 1) & 7)) + (k & 1);
+  return k * 128 + 2 * ((mn >> 1) ^ (10 * (k & 1))) + (mn & 1);
 }
+
+// Issue the 4 global_load_lds_dwordx4 of this wave for one 16 KB operand tile.
 template <int LAY>
-__device__ __forceinline__ void store_tile_lds(double* __restrict__ S, const double2 (&r)[4], int t) {
-  if (LAY == LAY_KCONTIG) {
-    const int kk = (t & 7) * 2, row = t >> 3;
+__device__ __forceinline__ void glds_tile(double* tile, const double* __restrict__ P, int64_t ld, int64_t mn0, int64_t k0,
+                                          int wave, int lane) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<double2*>(S + (row + 32 * p) * LDK + kk) = r[p];
-  } else {
-    const int mm = (t & 63) * 2, krow = t >> 6;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<double2*>(S + (krow + 4 * p) * LDMN + mm) = r[p];
+  for (int p = 0; p < 4; ++p) {
+    const int c = 4 * p + wave;                         // 1 KB chunk id (0..15)
+    const double* src;
+    if (LAY == LAY_KCONTIG) {                           // chunk = rows 8c..8c+7, lane -> (row, granule position)
+      const int row = 8 * c + (lane >> 3), gp = lane & 7;
+      const int g = gp ^ ((row >> 1) & 7);
+      src = P + (mn0 + row) * ld + k0 + 2 * g;
+    } else {                                            // chunk = k-row c, lane -> granule position
+      const int g = lane ^ (10 * (c & 1));
+      src = P + (k0 + c) * ld + mn0 + 2 * g;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(tile + c * 128), 16, 0, 0);
   }
 }
 
-template <int ALAY, int BLAY, class BProd, class Epi>
-__global__ void __launch_bounds__(GEMM_THREADS, 2)
-gemm_f64_kernel(GemmArgs g, BProd bprod, Epi epi) {
-  __shared__ double lds[2 * TILE_DOUBLES];
-  double* As = lds;
-  double* Bs = lds + TILE_DOUBLES;
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int ALAY, int BLAY, int NSTAGE, class Epi>
+__global__ void __launch_bounds__(GEMM_THREADS, (NSTAGE <= 2) ? 2 : 1)
+gemm_f64_kernel(GemmArgs g, Epi epi) {
+  extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
   const GemmTile tl = g.tiles[blockIdx.x];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -129,46 +113,39 @@ gemm_f64_kernel(GemmArgs g, BProd bprod, Epi epi) {
 
   const int nk = tl.kend - tl.kbeg;
   const int total = nk * g.nseg;
-  double2 ra[4], rb[4];
 
-  auto issue_loads = [&](int it) {
-    const int sg = it / nk, kb = tl.kbeg + (it - sg * nk);
+  auto issue = [&](int it) {
+    const int sg = (it >= nk) ? 1 : 0;
+    const int kb = tl.kbeg + (it - sg * nk);
     const GemmSeg& s = g.seg[sg];
     const int64_t k0 = (int64_t)kb * BK;
-    load_tile_regs<ALAY>(ra, s.A, s.lda, row0, k0, t);
-    load_tile_regs<BLAY>(rb, s.B, s.ldb, col0, k0, t);
-    // B producer (applied on registers; k / n of this thread's elements)
-    if (BLAY == LAY_MNCONTIG) {
-      const int mm = (t & 63) * 2, krow = t >> 6;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) rb[p] = bprod(k0 + krow + 4 * p, col0 + mm, rb[p]);
-    }
+    double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
+    glds_tile<ALAY>(st, s.A, s.lda, row0, k0, wave, lane);
+    glds_tile<BLAY>(st + TILE_DOUBLES, s.B, s.ldb, col0, k0, wave, lane);
   };
 
-  if (total > 0) issue_loads(0);
-  // per-lane LDS read offsets
-  const int a_i = lane & 3, a_k = lane >> 4, b_j = lane & 15;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < total) issue(s);
+
+  const int a_i = lane & 3, kq = lane >> 4, b_j = lane & 15;
   for (int it = 0; it < total; ++it) {
-    store_tile_lds<ALAY>(As, ra, t);
-    store_tile_lds<BLAY>(Bs, rb, t);
-    __syncthreads();
-    if (it + 1 < total) issue_loads(it + 1);
+    // stage `it` must have landed: at most NSTAGE-2 younger stages (8 glds each) may stay in flight
+    if (it + NSTAGE - 2 < total) wait_vmcnt<8 * (NSTAGE - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (it + NSTAGE - 1 < total) issue(it + NSTAGE - 1);
+    const double* As = lds + (it % NSTAGE) * STAGE_DOUBLES;
+    const double* Bs = As + TILE_DOUBLES;
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-      const int k = ks * 4 + a_k;
+      const int k = ks * 4 + kq;
       double af[4][4], bf[4];
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        const int col = wn * 64 + tn * 16 + b_j;
-        bf[tn] = (BLAY == LAY_MNCONTIG) ? Bs[k * LDMN + col] : Bs[col * LDK + k];
-      }
+      for (int tn = 0; tn < 4; ++tn) bf[tn] = Bs[lds_idx<BLAY>(wn * 64 + tn * 16 + b_j, k)];
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wm * 64 + tm * 16 + 4 * r + a_i;
-          af[tm][r] = (ALAY == LAY_KCONTIG) ? As[row * LDK + k] : As[k * LDMN + row];
-        }
+        for (int r = 0; r < 4; ++r) af[tm][r] = As[lds_idx<ALAY>(wm * 64 + tm * 16 + 4 * r + a_i, k)];
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -177,7 +154,6 @@ gemm_f64_kernel(GemmArgs g, BProd bprod, Epi epi) {
           for (int r = 0; r < 4; ++r)
             acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
     }
-    __syncthreads();
   }
 
   double* C = g.C + (int64_t)tl.slice * g.slice_stride;

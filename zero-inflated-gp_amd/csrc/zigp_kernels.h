@@ -205,20 +205,28 @@ k_pointwise(PwArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row reductions for d/du and d/ds (cotangents of main.py:287 and :291,302): block per row m.
+// Row pass over A2 for one chunk, block per row m (cotangents of main.py:287 and :291,302):
 //   du[m]  += sum_n A2[m,n] gm[n] ;  dsq[m] += sum_n gv[n] A2[m,n]^2
+//   dA2[m,n] = gm[n]*u[m] + 2*gv[n]*s2[m]*A2[m,n]     (cotangent of A2 = L^-T A1; operand of E = W dA2)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_rowred(const double* __restrict__ A2, const double* __restrict__ gm, const double* __restrict__ gv, int64_t Nc,
-         double* __restrict__ du, double* __restrict__ dsq) {
+k_rowred_da2(const double* __restrict__ A2, const double* __restrict__ gm, const double* __restrict__ gv, int64_t Nc,
+             const double* __restrict__ u, const double* __restrict__ s2, double* __restrict__ du, double* __restrict__ dsq,
+             double* __restrict__ dA2) {
   __shared__ double sh[4];
   const int m = blockIdx.x;
-  const double* row = A2 + (int64_t)m * Nc;
+  const double2* row = reinterpret_cast<const double2*>(A2 + (int64_t)m * Nc);
+  const double2* gm2 = reinterpret_cast<const double2*>(gm);
+  const double2* gv2 = reinterpret_cast<const double2*>(gv);
+  double2* out = reinterpret_cast<double2*>(dA2 + (int64_t)m * Nc);
+  const double um = u[m], sm = 2.0 * s2[m];
   double a = 0.0, b = 0.0;
-  for (int64_t n = threadIdx.x; n < Nc; n += 256) {
-    const double v = row[n];
-    a = fma(v, gm[n], a);
-    b = fma(gv[n] * v, v, b);
+  for (int64_t n = threadIdx.x; n < Nc / 2; n += 256) {
+    const double2 v = row[n], g1 = gm2[n], g2 = gv2[n];
+    a = fma(v.x, g1.x, a); a = fma(v.y, g1.y, a);
+    b = fma(g2.x * v.x, v.x, b); b = fma(g2.y * v.y, v.y, b);
+    double2 o; o.x = fma(g2.x * sm, v.x, g1.x * um); o.y = fma(g2.y * sm, v.y, g1.y * um);
+    out[n] = o;
   }
   a = block_sum<4>(a, sh);
   b = block_sum<4>(b, sh);
