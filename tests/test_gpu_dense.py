@@ -95,7 +95,7 @@ def test_row_shards_sum_to_full(engine):
     assert parts[0][1] == kl and parts[1][1] == 0.0
     for k in g:
         s = np.asarray(parts[0][2][k]) + np.asarray(parts[1][2][k])
-        assert np.max(np.abs(s - np.asarray(g[k]))) <= 1e-9 * max(np.max(np.abs(np.asarray(g[k]))), 1e-300), k
+        assert np.max(np.abs(s - np.asarray(g[k]))) <= 1e-8 * max(np.max(np.abs(np.asarray(g[k]))), 1e-300), k   # summation order x cond(Kuu)
 
 
 def test_bit_stable_run_to_run(engine):

@@ -40,7 +40,8 @@ struct Latent {
   DevBuf Z, ell, u, s, s2;              // Z (Mp,D) zero padded; u,s,s2 (Mp) zero padded
   double var = 1.0;
   DevBuf Kuu, L, W;                      // (Mp,Mp)
-  DevBuf K, A1, A2;                      // chunk panels [Mp][Nc]
+  DevBuf K, A1, A2, H, Jp;               // chunk panels [Mp][Nc]: Kuf, A1 = W K, A2 = W^T A1, H = W diag(s^2) A2, J' = W^T H - A2
+  DevBuf Wp, a1gm;                       // W diag(s^2) (Mp,Mp); running sum of A1 gm [Mp]
   DevBuf part;                           // colred partials [2][MSPLIT][Nc]
   DevBuf gm, gv;                         // cotangents of mean / var per column [Nc]
   DevBuf du, dsq, krow;                  // row accumulators: du[Mp], dsq[Mp], krow[Mp][1+2D]

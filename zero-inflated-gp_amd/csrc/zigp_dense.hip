@@ -3,9 +3,16 @@
 // Per ELBO step (value + gradient), for each latent h in {f, g}:
 //   MxM stage   Kuu = k(Z,Z)+jitter I ; L = chol(Kuu) ; W = L^-1                    (OnOffSVGP.py:96-97, main.py:267-268)
 //   per chunk   K = k(Z, Xc) ; A1 = W K ; A2 = W^T A1 ; column sums -> mean, var      (main.py:266-303)
-//               point-wise probit / likelihood / reverse pass                         (OnOffSVGP.py:168-204, OnOffLikelihood.py:30-32)
-//               E = W dA2 ; dA1 = E - 2 gv A1 ; F = W^T dA1                           (reverse of the two triangular solves)
-//               dL -= tril(F A1^T + A2 E^T) ; du, ds, (dZ, dell, dvar)|Kuf            (rank-N updates, split-K, fixed order)
+//               H = (W diag(s^2)) A2 ; J' = W^T H - A2                                (gradient panels, independent of the cotangents)
+//               point-wise probit / likelihood / reverse pass -> gm, gv               (OnOffSVGP.py:168-204, OnOffLikelihood.py:30-32)
+//               reverse of the two triangular solves, with G = diag(gv), v = W u, alpha = W^T v:
+//                 E = W dA2 = v gm^T + 2 H G ;  F = dK = W^T(E - 2 A1 G) = alpha gm^T + 2 J' G
+//                 dL = -tril(F A1^T + A2 E^T) = -tril(alpha (A1 gm)^T + (A2 gm) v^T + 2 [J' G A1^T + A2 G H^T])
+//               and, with T = W diag(s^2) W^T (so H = T A1, J' = W^T (T - I) A1) and C1 = A1 G A1^T:
+//                 J' G A1^T + A2 G H^T = W^T (T C1 + C1 T - C1)
+//               so all four O(M^2 N) triangular products run back to back before the point-wise stage, and ONE
+//               gv-weighted symmetric rank-N update C1 (gv applied as a k-scale inside the GEMM core, split-K,
+//               fixed order) replaces the two rank-N updates of the literal reverse pass; the rest is O(M^3).
 //   MxM stage   Kuu-bar = sym(W^T Phi(L^T dL) W) - dKL/dKuu ; -> dZ, dell, dvar        (Cholesky reverse, Murray 2016 / TF CholeskyGrad)
 #include "zigp_ctx.h"
 #include "zigp_kernels.h"
@@ -17,8 +24,9 @@ using namespace zigp;
 namespace {
 
 struct EpiPhi {  // Phi: keep strictly-lower, halve the diagonal, zero above
-  __device__ __forceinline__ void operator()(double* C, int64_t ldc, int64_t i, int64_t j, double v) const {
-    C[i * ldc + j] = (j < i) ? v : ((j == i) ? 0.5 * v : 0.0);
+  __device__ __forceinline__ void operator()(const double (&acc)[4][4][4], const EpiCtx& e) const {
+    double* __restrict__ C = e.C; const int64_t ld = e.ldc;
+    epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = (j < i) ? v : ((j == i) ? 0.5 * v : 0.0); });
   }
 };
 
@@ -48,18 +56,18 @@ inline GemmTile mk_tile(int bi, int bj, int kbeg, int kend, int slice = 0) {
 
 constexpr int NST = ZIGP_NSTAGE;   // LDS ring depth of the GEMM core (2 -> 64 KB, 2 workgroups/CU; 3-4 -> 1 workgroup/CU)
 
-template <int AL, int BL, class EP>
+template <int AL, int BL, bool KS, int TRI = TRI_NONE, class EP>
 int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
   if (tl.n == 0) return 0;
   g.tiles = tl.d;
   constexpr size_t shm = sizeof(double) * NST * STAGE_DOUBLES;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
-    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<AL, BL, NST, EP>),
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<AL, BL, NST, KS, TRI, EP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, EP>), dim3(tl.n), dim3(GEMM_THREADS), shm, c->stream, g, ep);
+  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, KS, TRI, EP>), dim3(tl.n), dim3(GEMM_THREADS), shm, c->stream, g, ep);
   ZIGP_HIP(c, hipGetLastError());
   return 0;
 }
@@ -68,7 +76,7 @@ inline GemmArgs mk_args(const double* A, int64_t lda, const double* B, int64_t l
   GemmArgs g;
   g.seg[0].A = A; g.seg[0].B = B; g.seg[0].lda = lda; g.seg[0].ldb = ldb;
   g.seg[1] = g.seg[0];
-  g.nseg = 1; g.tiles = nullptr; g.C = C; g.ldc = ldc; g.slice_stride = 0; g.alpha = alpha;
+  g.nseg = 1; g.tiles = nullptr; g.C = C; g.ldc = ldc; g.slice_stride = 0; g.alpha = alpha; g.kscale = nullptr;
   return g;
 }
 
@@ -138,13 +146,13 @@ int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool wa
         for (int bi = j + 1; bi < nb; ++bi) v.push_back(mk_tile(bi, j, j * kb, (j + 1) * kb));
       }, tp));
       // L[bi][j] = A[bi][j] * W_jj^T   (in place: each tile reads only itself and W_jj)
-      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, tp, mk_args(Lb, Mp, Wb, Mp, Lb, Mp), EpiStore())));
+      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, tp, mk_args(Lb, Mp, Wb, Mp, Lb, Mp), EpiStore())));
       ZIGP_TRY(get_tiles(c, "po_s:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
         for (int bi = j + 1; bi < nb; ++bi)
           for (int bj = j + 1; bj <= bi; ++bj) v.push_back(mk_tile(bi, bj, j * kb, (j + 1) * kb));
       }, ts));
       // A[bi][bj] -= L[bi][j] L[bj][j]^T
-      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, ts, mk_args(Lb, Mp, Lb, Mp, Lb, Mp, -1.0), EpiAccum())));
+      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, ts, mk_args(Lb, Mp, Lb, Mp, Lb, Mp, -1.0), EpiAccum())));
     }
   }
   // zero the strictly-upper blocks of L (they still hold the copy of A)
@@ -163,7 +171,7 @@ int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool wa
           for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, mid * kb));
       }
     }, t1));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t1, mk_args(Lb, Mp, Wb, Mp, Tb, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t1, mk_args(Lb, Mp, Wb, Mp, Tb, Mp), EpiStore())));
     ZIGP_TRY(get_tiles(c, "tri2:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
       for (int lo = 0; lo < nb; lo += 2 * b) {
         const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
@@ -172,7 +180,7 @@ int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool wa
           for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, mid * kb, (bi + 1) * kb));
       }
     }, t2));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t2, mk_args(Wb, Mp, Tb, Mp, Wb, Mp, -1.0), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t2, mk_args(Wb, Mp, Tb, Mp, Wb, Mp, -1.0), EpiStore())));
   }
   return 0;
 }
@@ -221,6 +229,16 @@ int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double j
   return 0;
 }
 
+// Gradient-side MxM pieces: W' = W diag(s^2) (operand of H = W' A2)
+int latent_forward_grad(zigp_ctx* c, Latent& lt) {
+  ProfScope ps(c, PC_MXM);
+  const int Mp = lt.Mp;
+  ZIGP_ENSURE(c, lt.Wp, (size_t)Mp * Mp);
+  hipLaunchKernelGGL(k_colscale, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.W.p, lt.s2.p, (int64_t)Mp, lt.Wp.p);
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+
 // KL value pieces: v = W u, alpha = W^T v, dkinv = diag(K^-1), kl -> vec[3*Mp]
 int latent_kl(zigp_ctx* c, Latent& lt) {
   ProfScope ps(c, PC_MXM);
@@ -234,9 +252,9 @@ int latent_kl(zigp_ctx* c, Latent& lt) {
   return 0;
 }
 
-// Forward panels of one latent for the chunk starting at row n0: K, A1, A2, column partials.
+// Forward panels of one latent for the chunk starting at row n0: K, A1, A2 (+ H, J' when a gradient is wanted), column partials.
 int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D,
-                         const double* ell_host) {
+                         const double* ell_host, bool need_grad) {
   const int Mp = lt.Mp, nbm = Mp / BM, nbn = (int)(Nc / BN);
   ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc);
   ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc);
@@ -254,12 +272,24 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
   ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu));
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {
-    ProfScope ps(c, PC_GEMM, fl);
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), EpiStore())));
+    ProfScope ps(c, PC_GEMM, fl);   // A1 = W K
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), EpiStore())));
   }
   {
-    ProfScope ps(c, PC_GEMM, fl);
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), EpiStore())));
+    ProfScope ps(c, PC_GEMM, fl);   // A2 = W^T A1
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), EpiStore())));
+  }
+  if (need_grad) {
+    ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc);
+    ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc);
+    {
+      ProfScope ps(c, PC_GEMM, fl);   // H = (W diag(s^2)) A2
+      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wp.p, Mp, lt.A2.p, Nc, lt.H.p, Nc), EpiStore())));
+    }
+    {
+      ProfScope ps(c, PC_GEMM, fl);   // J' = W^T H - A2
+      ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.H.p, Nc, lt.Jp.p, Nc), EpiSubLoad{lt.A2.p})));
+    }
   }
   {
     ProfScope ps(c, PC_POINT);
@@ -270,44 +300,38 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
   return 0;
 }
 
-constexpr int SYR_SLICES = 16;
+// Number of split-K slices of the rank-N update: smallest S >= 4 whose tile count fills whole waves of the
+// 2 x 256 resident workgroups to >= 95 % (e.g. 36 lower tiles at M = 1024 -> S = 14 -> 504 of 512 slots).
+int syr_slices(int nbm) {
+  const int ntl = nbm * (nbm + 1) / 2, slots = 512;
+  int best = 4; double best_eff = 0.0;
+  for (int S = 4; S <= 64; ++S) {
+    const int t = ntl * S;
+    const double eff = (double)t / (double)(((t + slots - 1) / slots) * slots);
+    if (eff > best_eff + 1e-12) { best_eff = eff; best = S; }
+    if (eff >= 0.95) { best = S; break; }
+  }
+  return best;
+}
 
 int latent_chunk_backward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D) {
-  const int Mp = lt.Mp, nbm = Mp / BM, nbn = (int)(Nc / BN);
-  ZIGP_ENSURE(c, c->E, (size_t)Mp * Nc);
-  ZIGP_ENSURE(c, c->dA1, (size_t)Mp * Nc);
-  ZIGP_ENSURE(c, c->F, (size_t)Mp * Nc);
-  TileList tl, tu, ts;
-  ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, tl));
-  ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu));
-  ZIGP_TRY(tiles_syr2k(c, nbm, (int)(Nc / BK), SYR_SLICES, ts));
+  const int Mp = lt.Mp, nbm = Mp / BM;
+  TileList ts;
+  ZIGP_TRY(tiles_syr2k(c, nbm, (int)(Nc / BK), syr_slices(nbm), ts));
   const double fl = (double)lt.M * lt.M * (double)Nc;
-  {
-    ProfScope ps(c, PC_RED);   // du, ds partials and dA2 (into the F panel, consumed by the E product below)
-    hipLaunchKernelGGL(k_rowred_da2, dim3(Mp), dim3(256), 0, c->stream, lt.A2.p, lt.gm.p, lt.gv.p, Nc, lt.u.p, lt.s2.p, lt.du.p,
-                       lt.dsq.p, c->F.p);
-    ZIGP_HIP(c, hipGetLastError());
-  }
-  {
-    ProfScope ps(c, PC_GEMM, fl);
-    EpiDA1 ep{lt.A1.p, c->dA1.p, lt.gv.p};
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, mk_args(lt.W.p, Mp, c->F.p, Nc, c->E.p, Nc), ep)));
-  }
-  {
-    ProfScope ps(c, PC_GEMM, fl);
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tu, mk_args(lt.W.p, Mp, c->dA1.p, Nc, c->F.p, Nc), EpiStore())));
-  }
+  double* alpha = lt.vec.p + Mp;
   {
     ProfScope ps(c, PC_RED);
-    hipLaunchKernelGGL(k_kgrad, dim3(Mp), dim3(256), 0, c->stream, c->F.p, lt.K.p, dX, Nrows, n0, lt.Z.p, lt.M, D, Nc, lt.krow.p);
+    hipLaunchKernelGGL(k_rowred, dim3(Mp), dim3(256), 0, c->stream, lt.A1.p, lt.A2.p, lt.gm.p, lt.gv.p, Nc, lt.du.p, lt.dsq.p, lt.a1gm.p);
+    hipLaunchKernelGGL(k_kgrad, dim3(Mp), dim3(256), 0, c->stream, lt.Jp.p, lt.K.p, alpha, lt.gm.p, lt.gv.p, dX, Nrows, n0, lt.Z.p, lt.M, D,
+                       Nc, lt.krow.p);
     ZIGP_HIP(c, hipGetLastError());
   }
   {
-    ProfScope ps(c, PC_SYR2K, 2.0 * fl);
-    GemmArgs g = mk_args(c->F.p, Nc, lt.A1.p, Nc, lt.dLpart.p, Mp);
-    g.seg[1].A = lt.A2.p; g.seg[1].B = c->E.p; g.seg[1].lda = Nc; g.seg[1].ldb = Nc;
-    g.nseg = 2; g.slice_stride = (int64_t)Mp * Mp;
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, ts, g, EpiAccum())));
+    ProfScope ps(c, PC_SYR2K, fl);   // planes += tril(A1 G A1^T)   (G = diag(gv) applied as k-scale on the B operand)
+    GemmArgs g = mk_args(lt.A1.p, Nc, lt.A1.p, Nc, lt.dLpart.p, Mp);
+    g.slice_stride = (int64_t)Mp * Mp; g.kscale = lt.gv.p;
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, true, TRI_C_LOWER>(c, ts, g, EpiAccum())));
   }
   return 0;
 }
@@ -321,26 +345,47 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
   const int gridmm = ceil_div((int64_t)mm, 256);
   double* S = lt.T1.p;
   if (with_data) {
-    hipLaunchKernelGGL(k_reduce_planes_tril, dim3(gridmm), dim3(256), 0, c->stream, lt.dLpart.p, SYR_SLICES, (int64_t)Mp, lt.T1.p);
+    TileList ta, tb, tc;
+    // C1 = sym(sum_s planes) -> T1
+    hipLaunchKernelGGL(k_sym_from_planes, dim3(gridmm), dim3(256), 0, c->stream, lt.dLpart.p, syr_slices(nb), (int64_t)Mp, lt.T1.p);
+    // T = (W diag(s^2)) W^T -> T2   (both factors lower triangular: k <= min(i,j))
+    ZIGP_TRY(get_tiles(c, "bw_tt:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
+      for (int bi = 0; bi < nb; ++bi)
+        for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, 0, (std::min(bi, bj) + 1) * kb));
+    }, ta));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, ta, mk_args(lt.Wp.p, Mp, lt.W.p, Mp, lt.T2.p, Mp), EpiStore())));
+    // U = T C1 -> T3 ; V = U + U^T - C1 -> G
+    ZIGP_TRY(tiles_full(c, nb, nb, nb * kb, tb));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, tb, mk_args(lt.T2.p, Mp, lt.T1.p, Mp, lt.T3.p, Mp), EpiStore())));
+    hipLaunchKernelGGL(k_uut_minus, dim3(gridmm), dim3(256), 0, c->stream, lt.T3.p, lt.T1.p, (int64_t)Mp, lt.G.p);
+    // R = W^T V (lower part) -> T2
+    ZIGP_TRY(get_tiles(c, "bw_r:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
+      for (int bi = 0; bi < nb; ++bi)
+        for (int bj = 0; bj < nb; ++bj) v.push_back(bj <= bi ? mk_tile(bi, bj, bi * kb, nb * kb) : mk_tile(bi, bj, 0, 0));
+    }, tc));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, tc, mk_args(lt.W.p, Mp, lt.G.p, Mp, lt.T2.p, Mp), EpiStore())));
+    // dL = -tril(alpha (A1 gm)^T + (A2 gm) v^T + 2 R) -> T1
+    hipLaunchKernelGGL(k_dl_assemble, dim3(gridmm), dim3(256), 0, c->stream, lt.T2.p, (int64_t)Mp, lt.vec.p + Mp, lt.a1gm.p, lt.du.p,
+                       lt.vec.p, lt.T1.p);
     TileList t1, t2, t3;
     // Q = Phi(L^T dL) -> T2  (upper tiles get an empty k range -> zeros)
     ZIGP_TRY(get_tiles(c, "bw_q:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
       for (int bi = 0; bi < nb; ++bi)
         for (int bj = 0; bj < nb; ++bj) v.push_back(bj <= bi ? mk_tile(bi, bj, bi * kb, nb * kb) : mk_tile(bi, bj, 0, 0));
     }, t1));
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t1, mk_args(lt.L.p, Mp, lt.T1.p, Mp, lt.T2.p, Mp), EpiPhi())));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, t1, mk_args(lt.L.p, Mp, lt.T1.p, Mp, lt.T2.p, Mp), EpiPhi())));
     // T = Q W -> T3 (lower)
     ZIGP_TRY(get_tiles(c, "bw_t:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
       for (int bi = 0; bi < nb; ++bi)
         for (int bj = 0; bj < nb; ++bj) v.push_back(bj <= bi ? mk_tile(bi, bj, bj * kb, (bi + 1) * kb) : mk_tile(bi, bj, 0, 0));
     }, t2));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, t2, mk_args(lt.T2.p, Mp, lt.W.p, Mp, lt.T3.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t2, mk_args(lt.T2.p, Mp, lt.W.p, Mp, lt.T3.p, Mp), EpiStore())));
     // S = W^T T -> T1
     ZIGP_TRY(get_tiles(c, "bw_s:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
       for (int bi = 0; bi < nb; ++bi)
         for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, std::max(bi, bj) * kb, nb * kb));
     }, t3));
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t3, mk_args(lt.W.p, Mp, lt.T3.p, Mp, lt.T1.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, t3, mk_args(lt.W.p, Mp, lt.T3.p, Mp, lt.T1.p, Mp), EpiStore())));
   }
   double* P = lt.T2.p; double* PSP = lt.G.p;
   if (with_kl) {
@@ -350,11 +395,11 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
         for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, std::max(bi, bj) * kb, nb * kb));
     }, t3));
     // P = W^T W -> T2
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, t3, mk_args(lt.W.p, Mp, lt.W.p, Mp, lt.T2.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, t3, mk_args(lt.W.p, Mp, lt.W.p, Mp, lt.T2.p, Mp), EpiStore())));
     // Ps = diag(s2) P -> T3 ; PSP = P Ps -> G
     hipLaunchKernelGGL(k_rowscale, dim3(gridmm), dim3(256), 0, c->stream, lt.T2.p, lt.s2.p, (int64_t)Mp, lt.T3.p);
     ZIGP_TRY(tiles_full(c, nb, nb, nb * kb, tf));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tf, mk_args(lt.T2.p, Mp, lt.T3.p, Mp, lt.G.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, tf, mk_args(lt.T2.p, Mp, lt.T3.p, Mp, lt.G.p, Mp), EpiStore())));
   }
   // G = sym(S) - dKL/dKuu -> T3 (T3 free again)
   hipLaunchKernelGGL(k_sym_combine, dim3(gridmm), dim3(256), 0, c->stream, S, P, PSP, lt.vec.p + Mp, with_data ? 1 : 0, with_kl ? 1 : 0,
@@ -387,8 +432,11 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
   for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], D, jitter, true));
   ZIGP_TRY(check_info(c, "Kuu"));
-  if (include_kl && !predict)
+  // v = W u and alpha = W^T v are needed by the KL value AND by the rank-1 parts of the data-term gradient
+  if ((include_kl || need_grad) && !predict)
     for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_kl(c, c->lat[h]));
+  if (need_grad)
+    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward_grad(c, c->lat[h]));
 
   int64_t Nc = c->chunk;
   const int64_t span = has_rows ? (row_end - row_begin) : 0;
@@ -402,18 +450,21 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     ZIGP_ENSURE(c, lt.gm, Nc); ZIGP_ENSURE(c, lt.gv, Nc);
     if (need_grad) {
       ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)Mp * (1 + 2 * D));
-      ZIGP_ENSURE(c, lt.dLpart, (size_t)SYR_SLICES * Mp * Mp);
+      const int S = syr_slices(Mp / BM);
+      ZIGP_ENSURE(c, lt.dLpart, (size_t)S * Mp * Mp);
+      ZIGP_ENSURE(c, lt.a1gm, Mp);
+      ZIGP_HIP(c, hipMemsetAsync(lt.a1gm.p, 0, sizeof(double) * Mp, c->stream));
       ZIGP_HIP(c, hipMemsetAsync(lt.du.p, 0, sizeof(double) * Mp, c->stream));
       ZIGP_HIP(c, hipMemsetAsync(lt.dsq.p, 0, sizeof(double) * Mp, c->stream));
       ZIGP_HIP(c, hipMemsetAsync(lt.krow.p, 0, sizeof(double) * Mp * (1 + 2 * D), c->stream));
-      if (has_rows) ZIGP_HIP(c, hipMemsetAsync(lt.dLpart.p, 0, sizeof(double) * SYR_SLICES * Mp * Mp, c->stream));
+      if (has_rows) ZIGP_HIP(c, hipMemsetAsync(lt.dLpart.p, 0, sizeof(double) * S * Mp * Mp, c->stream));
     }
   }
   const int64_t Nc_full = Nc;
   for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc_full) {
     // the last (partial) chunk shrinks to the next multiple of 1024 rows
     Nc = std::min<int64_t>(Nc_full, round_up(row_end - n0, 1024));
-    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], dX, Nrows, n0, Nc, D, ell_h[h]));
+    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], dX, Nrows, n0, Nc, D, ell_h[h], need_grad));
     {
       ProfScope ps(c, PC_POINT);
       PwArgs a;
@@ -439,7 +490,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   std::vector<double> hvec[2], hdu[2], hdsq[2], hkrow[2];
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
-    if (include_kl) {
+    if (include_kl || need_grad) {
       hvec[h].resize((size_t)3 * lt.Mp + 8);
       ZIGP_HIP(c, hipMemcpyAsync(hvec[h].data(), lt.vec.p, sizeof(double) * hvec[h].size(), hipMemcpyDeviceToHost, c->stream));
     }
@@ -526,7 +577,7 @@ int zigp_destroy(zigp_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (int h = 0; h < 2; ++h) {
     Latent& l = c->lat[h];
-    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
+    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.H, &l.Jp, &l.Wp, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
                     &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec};
     for (DevBuf* b : bs) b->release();
   }
@@ -670,10 +721,10 @@ int zigp_test_gemm(zigp_ctx* c, int32_t transA, int32_t transB, int64_t m, int64
     TileList tl;
     ZIGP_TRY(tiles_full(c, (int)(mp / BM), (int)(np / BN), (int)(kp / BK), tl));
     GemmArgs g = mk_args(da.p, ac, db.p, bc, dc.p, np);
-    if (!transA && !transB) ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG>(c, tl, g, EpiStore())));
-    if (transA && !transB) ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG>(c, tl, g, EpiStore())));
-    if (!transA && transB) ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG>(c, tl, g, EpiStore())));
-    if (transA && transB) ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_KCONTIG>(c, tl, g, EpiStore())));
+    if (!transA && !transB) ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, tl, g, EpiStore())));
+    if (transA && !transB) ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, tl, g, EpiStore())));
+    if (!transA && transB) ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, tl, g, EpiStore())));
+    if (transA && transB) ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_KCONTIG, false>(c, tl, g, EpiStore())));
     ZIGP_HIP(c, hipMemcpyAsync(hc.data(), dc.p, sizeof(double) * hc.size(), hipMemcpyDeviceToHost, c->stream));
     ZIGP_HIP(c, hipStreamSynchronize(c->stream));
     return 0;

@@ -24,7 +24,7 @@ namespace zigp {
 
 constexpr int BM = 128, BN = 128, BK = 16, GEMM_THREADS = 256;
 constexpr int TILE_DOUBLES = 128 * BK;            // 2048 doubles = 16 KB per operand tile
-constexpr int STAGE_DOUBLES = 2 * TILE_DOUBLES;   // A tile + B tile
+constexpr int STAGE_DOUBLES = 2 * TILE_DOUBLES + BK;   // A tile + B tile + one BK-slice of the k-scale vector
 
 // Operand layouts: element (i,k) of A / (k,j) of B
 enum { LAY_KCONTIG = 0,   // A[i*ld + k]   /  B[j*ld + k]
@@ -47,20 +47,46 @@ struct GemmArgs {
   const GemmTile* tiles;
   double* C; int64_t ldc; int64_t slice_stride;  // C plane stride for split-K partials
   double alpha;
+  const double* kscale;   // KSCALE kernels: B[k][j] is multiplied by kscale[k] (k = global reduction index)
 };
 
-// ---- epilogues: called once per accumulator element with its global (row, col) ----
+// ---- epilogues --------------------------------------------------------------------------------
+// acc[tm][tn][r] of lane l is C[row0 + wm*64 + tm*16 + 4r + l/16][col0 + wn*64 + tn*16 + l%16].
+// An epilogue is `void operator()(const double (&acc)[4][4][4], const EpiCtx&) const`.
+struct EpiCtx {
+  double* C; int64_t ldc; double alpha;
+  int64_t row0, col0;   // of this wave's 64x64 sub-tile
+  int lane;
+};
+template <class F>
+__device__ __forceinline__ void epi_foreach(const double (&acc)[4][4][4], const EpiCtx& e, F f) {
+  const int c_i = e.lane >> 4, c_j = e.lane & 15;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t gi = e.row0 + tm * 16 + 4 * r + c_i;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) f(gi, e.col0 + tn * 16 + c_j, e.alpha * acc[tm][tn][r]);
+    }
+}
 struct EpiStore {   // C = alpha*acc
-  __device__ __forceinline__ void operator()(double* C, int64_t ldc, int64_t i, int64_t j, double v) const { C[i * ldc + j] = v; }
+  __device__ __forceinline__ void operator()(const double (&acc)[4][4][4], const EpiCtx& e) const {
+    double* __restrict__ C = e.C; const int64_t ld = e.ldc;
+    epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = v; });
+  }
 };
 struct EpiAccum {   // C += alpha*acc
-  __device__ __forceinline__ void operator()(double* C, int64_t ldc, int64_t i, int64_t j, double v) const { C[i * ldc + j] += v; }
+  __device__ __forceinline__ void operator()(const double (&acc)[4][4][4], const EpiCtx& e) const {
+    double* C = e.C; const int64_t ld = e.ldc;
+    epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] += v; });
+  }
 };
-// E = W dA2 stored to C; dA1 = E - 2 gv[n] A1[m,n] stored to dA1  (fvar = Kdiag - sum A1^2, main.py:278)
-struct EpiDA1 {
-  const double* A1; double* dA1; const double* gv;
-  __device__ __forceinline__ void operator()(double* C, int64_t ldc, int64_t i, int64_t j, double v) const {
-    C[i * ldc + j] = v; dA1[i * ldc + j] = v - 2.0 * gv[j] * A1[i * ldc + j];
+struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
+  const double* __restrict__ S;
+  __device__ __forceinline__ void operator()(const double (&acc)[4][4][4], const EpiCtx& e) const {
+    double* __restrict__ C = e.C; const int64_t ld = e.ldc; const double* __restrict__ Sp = S;
+    epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = v - Sp[i * ld + j]; });
   }
 };
 
@@ -94,7 +120,14 @@ __device__ __forceinline__ void glds_tile(double* tile, const double* __restrict
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int ALAY, int BLAY, int NSTAGE, class Epi>
+// TRI: triangular structure exploited at wave (64-row) granularity inside diagonal blocks
+enum { TRI_NONE = 0,
+       TRI_A_LOWER = 1,   // A(i,k) = 0 for k > i   (W * B)
+       TRI_A_UPPER = 2,   // A(i,k) = 0 for k < i   (W^T * B)
+       TRI_C_LOWER = 3    // only C(i,j), j <= i, is used (rank-N update of a lower-triangular cotangent)
+};
+
+template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, class Epi>
 __global__ void __launch_bounds__(GEMM_THREADS, (NSTAGE <= 2) ? 2 : 1)
 gemm_f64_kernel(GemmArgs g, Epi epi) {
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
@@ -122,7 +155,13 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
     double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
     glds_tile<ALAY>(st, s.A, s.lda, row0, k0, wave, lane);
     glds_tile<BLAY>(st + TILE_DOUBLES, s.B, s.ldb, col0, k0, wave, lane);
+    if (KSCALE) {   // 16 doubles of the scale vector; every wave issues the same 128 B (uniform vmcnt accounting)
+      if (lane < 8)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.kscale + k0 + 2 * lane),
+                                         (__attribute__((address_space(3))) void*)(st + 2 * TILE_DOUBLES), 16, 0, 0);
+    }
   };
+  constexpr int GLDS_PER_STAGE = KSCALE ? 9 : 8;
 
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
@@ -131,44 +170,51 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   const int a_i = lane & 3, kq = lane >> 4, b_j = lane & 15;
   for (int it = 0; it < total; ++it) {
     // stage `it` must have landed: at most NSTAGE-2 younger stages (8 glds each) may stay in flight
-    if (it + NSTAGE - 2 < total) wait_vmcnt<8 * (NSTAGE - 2)>(); else wait_vmcnt<0>();
+    if (it + NSTAGE - 2 < total) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (it + NSTAGE - 1 < total) issue(it + NSTAGE - 1);
     const double* As = lds + (it % NSTAGE) * STAGE_DOUBLES;
     const double* Bs = As + TILE_DOUBLES;
+    // Triangular structure at wave (64-row) granularity: a wave whose rows cannot touch this BK step of a
+    // triangular A, or whose whole 64x64 output lies above the diagonal of a lower-triangular C, issues no MFMAs
+    // (it still takes part in staging and barriers; the co-resident workgroup gets the matrix pipe).
+    const int sgc = (it >= nk) ? 1 : 0;
+    const int krel = (tl.kbeg + (it - sgc * nk)) * BK - tl.bi * BM;   // k offset of this step relative to the row block
+    bool skip = false;
+    if (TRI == TRI_A_LOWER) skip = krel > wm * 64 + 63;
+    if (TRI == TRI_A_UPPER) skip = krel + BK - 1 < wm * 64;
+    if (TRI == TRI_C_LOWER) skip = (tl.bi == tl.bj) && (wn > wm);
+    if (!skip) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      const int k = ks * 4 + kq;
-      double af[4][4], bf[4];
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        const int k = ks * 4 + kq;
+        double af[4][4], bf[4];
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) bf[tn] = Bs[lds_idx<BLAY>(wn * 64 + tn * 16 + b_j, k)];
+        for (int tn = 0; tn < 4; ++tn) bf[tn] = Bs[lds_idx<BLAY>(wn * 64 + tn * 16 + b_j, k)];
+        if (KSCALE) {
+          const double sc = As[2 * TILE_DOUBLES + k];
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+          for (int tn = 0; tn < 4; ++tn) bf[tn] *= sc;
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) af[tm][r] = As[lds_idx<ALAY>(wm * 64 + tm * 16 + 4 * r + a_i, k)];
+        for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+          for (int r = 0; r < 4; ++r) af[tm][r] = As[lds_idx<ALAY>(wm * 64 + tm * 16 + 4 * r + a_i, k)];
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
+          for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
+      }
     }
   }
 
-  double* C = g.C + (int64_t)tl.slice * g.slice_stride;
-  const int c_i = lane >> 4, c_j = lane & 15;
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t gi = row0 + wm * 64 + tm * 16 + 4 * r + c_i;
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        const int64_t gj = col0 + wn * 64 + tn * 16 + c_j;
-        epi(C, g.ldc, gi, gj, g.alpha * acc[tm][tn][r]);
-      }
-    }
+  EpiCtx e;
+  e.C = g.C + (int64_t)tl.slice * g.slice_stride; e.ldc = g.ldc; e.alpha = g.alpha;
+  e.row0 = row0 + wm * 64; e.col0 = col0 + wn * 64; e.lane = lane;
+  epi(acc, e);
 }
 
 }  // namespace zigp

@@ -205,43 +205,42 @@ k_pointwise(PwArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row pass over A2 for one chunk, block per row m (cotangents of main.py:287 and :291,302):
-//   du[m]  += sum_n A2[m,n] gm[n] ;  dsq[m] += sum_n gv[n] A2[m,n]^2
-//   dA2[m,n] = gm[n]*u[m] + 2*gv[n]*s2[m]*A2[m,n]     (cotangent of A2 = L^-T A1; operand of E = W dA2)
+// Row reductions over one chunk, block per row m (cotangents of main.py:287 and :291,302 + rank-1 parts of dL):
+//   du[m] += sum_n A2[m,n] gm[n] ; dsq[m] += sum_n gv[n] A2[m,n]^2 ; a1gm[m] += sum_n A1[m,n] gm[n]
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_rowred_da2(const double* __restrict__ A2, const double* __restrict__ gm, const double* __restrict__ gv, int64_t Nc,
-             const double* __restrict__ u, const double* __restrict__ s2, double* __restrict__ du, double* __restrict__ dsq,
-             double* __restrict__ dA2) {
+k_rowred(const double* __restrict__ A1, const double* __restrict__ A2, const double* __restrict__ gm, const double* __restrict__ gv,
+         int64_t Nc, double* __restrict__ du, double* __restrict__ dsq, double* __restrict__ a1gm) {
   __shared__ double sh[4];
   const int m = blockIdx.x;
-  const double2* row = reinterpret_cast<const double2*>(A2 + (int64_t)m * Nc);
+  const double2* r1 = reinterpret_cast<const double2*>(A1 + (int64_t)m * Nc);
+  const double2* r2 = reinterpret_cast<const double2*>(A2 + (int64_t)m * Nc);
   const double2* gm2 = reinterpret_cast<const double2*>(gm);
   const double2* gv2 = reinterpret_cast<const double2*>(gv);
-  double2* out = reinterpret_cast<double2*>(dA2 + (int64_t)m * Nc);
-  const double um = u[m], sm = 2.0 * s2[m];
-  double a = 0.0, b = 0.0;
+  double a = 0.0, b = 0.0, c = 0.0;
   for (int64_t n = threadIdx.x; n < Nc / 2; n += 256) {
-    const double2 v = row[n], g1 = gm2[n], g2 = gv2[n];
+    const double2 v = r2[n], w = r1[n], g1 = gm2[n], g2 = gv2[n];
     a = fma(v.x, g1.x, a); a = fma(v.y, g1.y, a);
     b = fma(g2.x * v.x, v.x, b); b = fma(g2.y * v.y, v.y, b);
-    double2 o; o.x = fma(g2.x * sm, v.x, g1.x * um); o.y = fma(g2.y * sm, v.y, g1.y * um);
-    out[n] = o;
+    c = fma(w.x, g1.x, c); c = fma(w.y, g1.y, c);
   }
   a = block_sum<4>(a, sh);
   b = block_sum<4>(b, sh);
-  if (threadIdx.x == 0) { du[m] += a; dsq[m] += b; }
+  c = block_sum<4>(c, sh);
+  if (threadIdx.x == 0) { du[m] += a; dsq[m] += b; a1gm[m] += c; }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kuf -> (Z, ell, var) cotangent reductions, block per row m of F (= dK) and K:
+// Kuf -> (Z, ell, var) cotangent reductions, block per row m of K, with the Kuf cotangent formed on the fly
+//   F[m,n] = dK = alpha[m] gm[n] + 2 gv[n] J'[m,n]:
 //   krow[m][0]     += sum_n F K
 //   krow[m][1+d]   += sum_n F K (x_nd - z_md)
 //   krow[m][1+D+d] += sum_n F K (x_nd - z_md)^2
 // (reverse of KernSE.K, onofftf/main.py:41-57)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_kgrad(const double* __restrict__ F, const double* __restrict__ K, const double* __restrict__ X, int64_t N, int64_t n0,
+k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const double* __restrict__ alpha,
+        const double* __restrict__ gm, const double* __restrict__ gv, const double* __restrict__ X, int64_t N, int64_t n0,
         const double* __restrict__ Z, int M, int D, int64_t Nc, double* __restrict__ krow) {
   __shared__ double sh[4];
   const int m = blockIdx.x;
@@ -252,11 +251,12 @@ k_kgrad(const double* __restrict__ F, const double* __restrict__ K, const double
   double s0 = 0.0, s1[MAXD], s2[MAXD];
 #pragma unroll
   for (int d = 0; d < MAXD; ++d) { s1[d] = 0.0; s2[d] = 0.0; }
-  const double* fr = F + (int64_t)m * Nc;
+  const double* fr = Jp + (int64_t)m * Nc;
   const double* kr = K + (int64_t)m * Nc;
+  const double am = alpha[m];
   for (int64_t n = threadIdx.x; n < Nc; n += 256) {
     if (n0 + n >= N) break;
-    const double t = fr[n] * kr[n];
+    const double t = fma(2.0 * gv[n], fr[n], am * gm[n]) * kr[n];
     s0 += t;
 #pragma unroll
     for (int d = 0; d < MAXD; ++d)
@@ -315,17 +315,32 @@ k_kuu_grad(const double* __restrict__ G, const double* __restrict__ Kuu, double 
   }
 }
 
-// dL[idx] = -sum_s part[s][idx] on/below the diagonal, 0 above  (L-bar of the two triangular solves)
-__global__ void k_reduce_planes_tril(const double* __restrict__ part, int S, int64_t Mp, double* __restrict__ out) {
+// C1[i][j] = sum_s part[s][max(i,j)][min(i,j)]   (planes hold the lower triangle of A1 G A1^T; fixed summation order)
+__global__ void k_sym_from_planes(const double* __restrict__ part, int S, int64_t Mp, double* __restrict__ out) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= Mp * Mp) return;
   int64_t i = idx / Mp, j = idx - i * Mp;
-  double v = 0.0;
-  if (j <= i) {
-    for (int s = 0; s < S; ++s) v += part[(int64_t)s * Mp * Mp + idx];
-    v = -v;
-  }
-  out[idx] = v;
+  const int64_t src = (j <= i) ? idx : (j * Mp + i);
+  double a = 0.0;
+  for (int s = 0; s < S; ++s) a += part[(int64_t)s * Mp * Mp + src];
+  out[idx] = a;
+}
+// V = U + U^T - C
+__global__ void k_uut_minus(const double* __restrict__ U, const double* __restrict__ C, int64_t Mp, double* __restrict__ V) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mp * Mp) return;
+  int64_t i = idx / Mp, j = idx - i * Mp;
+  V[idx] = U[idx] + U[j * Mp + i] - C[idx];
+}
+// dL[i][j] = -(alpha[i] a1gm[j] + a2gm[i] v[j] + 2 R[i][j]) on/below the diagonal, 0 above
+// (L-bar of the two triangular solves; the rank-1 terms are the gm-parts of F A1^T + A2 E^T)
+__global__ void k_dl_assemble(const double* __restrict__ R, int64_t Mp, const double* __restrict__ alpha,
+                              const double* __restrict__ a1gm, const double* __restrict__ a2gm, const double* __restrict__ v,
+                              double* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mp * Mp) return;
+  int64_t i = idx / Mp, j = idx - i * Mp;
+  out[idx] = (j <= i) ? -(2.0 * R[idx] + alpha[i] * a1gm[j] + a2gm[i] * v[j]) : 0.0;
 }
 
 // G = 0.5*(S + S^T) - 0.5*(P - alpha alpha^T - PSP)   (KL part only if with_kl)
@@ -388,6 +403,12 @@ __global__ void k_fill(double* p, int64_t n, double v) {
 __global__ void k_square(const double* s, double* s2, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) s2[i] = s[i] * s[i];
+}
+// out[i][j] = W[i][j] * s2[j]
+__global__ void k_colscale(const double* __restrict__ W, const double* __restrict__ s2, int64_t Mp, double* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mp * Mp) return;
+  out[idx] = s2[idx % Mp] * W[idx];
 }
 // Bs[k][j] = s2[k] * P[k][j]
 __global__ void k_rowscale(const double* __restrict__ P, const double* __restrict__ s2, int64_t Mp, double* __restrict__ out) {
