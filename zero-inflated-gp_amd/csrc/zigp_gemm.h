@@ -10,20 +10,34 @@
 //     16-lane groups (LDS broadcast is free).  The accumulator layout then equals the 16x16x4 one:
 //     acc[r] of lane l = C[4r + l/16][l%16].
 //   * workgroup = 256 threads = 4 waves (2x2), tile 128x128, BK = 16; wave tile 64x64 = 16 sub-tiles,
-//     64 independent accumulators per lane (128 VGPRs) -> MFMA issue is never dependency-bound.
+//     64 independent accumulators per lane (128 VGPRs) -> MFMA issue is never dependency-bound; two
+//     workgroups share a CU (2 waves/SIMD).  (An 8-wave 2x4 variant with 64x32 wave tiles and 4 waves/SIMD
+//     is kept behind ZIGP_GEMM_WAVES=8; it measured 10 % slower.)
 //   * operand tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into an
-//     NSTAGE-deep ring; the LDS image is lane-linear, so bank conflicts are removed by an XOR swizzle of
-//     the 16-byte granule index applied on the SOURCE address and again on every ds_read
-//     (cdna_hip_programming.md rule 21).  One s_barrier per BK step; counted vmcnt keeps NSTAGE-2
-//     stages in flight across it.
+//     NSTAGE-deep ring.  One wave-instruction writes 1 KB linearly, so bank conflicts are removed
+//     (a) for k-contiguous tiles ([128 rows][16 k], 8 rows per instruction) by an XOR swizzle of the 16-byte
+//         granule index with (row>>1)&7, applied on the SOURCE address and again on every ds_read
+//         (cdna_hip_programming.md rule 21); the swizzle separates into a per-lane base plus compile-time
+//         offsets, so reads need one (A) / four (B) address registers;
+//     (b) for m/n-contiguous tiles ([16 k][128], one k-row per instruction) by giving each row its own
+//         M0 base with a 144-double stride (odd k rows land 128 B further round the banks).
+//     One s_barrier per BK step; counted vmcnt keeps NSTAGE-2 stages in flight across it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace zigp {
 
-constexpr int BM = 128, BN = 128, BK = 16, GEMM_THREADS = 256;
-constexpr int TILE_DOUBLES = 128 * BK;            // 2048 doubles = 16 KB per operand tile
+constexpr int BM = 128, BN = 128, BK = 16;
+#ifndef ZIGP_GEMM_WAVES
+#define ZIGP_GEMM_WAVES 4     // measured on MI355X: 4 waves (64x64 wave tiles, 2 waves/SIMD) 170 ms/step vs 8 waves (64x32, 4 waves/SIMD) 187 ms
+#endif
+constexpr int GEMM_WAVES = ZIGP_GEMM_WAVES, GEMM_THREADS = 64 * GEMM_WAVES;   // 2 (M) x GEMM_WAVES/2 (N) waves
+constexpr int WNW = GEMM_WAVES / 2;          // waves along N
+constexpr int WTN = BN / WNW;                // wave tile width: 64 (4 waves) or 32 (8 waves)
+constexpr int TNW = WTN / 16;                // 16-column sub-tiles per wave
+constexpr int LDMN = 128 + 16;                    // row stride (doubles) of an m/n-contiguous tile image: odd k rows shift 128 B
+constexpr int TILE_DOUBLES = BK * LDMN;           // 2304 doubles (18 KB) holds either image: [128][16] swizzled or [16][144]
 constexpr int STAGE_DOUBLES = 2 * TILE_DOUBLES + BK;   // A tile + B tile + one BK-slice of the k-scale vector
 
 // Operand layouts: element (i,k) of A / (k,j) of B
@@ -51,15 +65,15 @@ struct GemmArgs {
 };
 
 // ---- epilogues --------------------------------------------------------------------------------
-// acc[tm][tn][r] of lane l is C[row0 + wm*64 + tm*16 + 4r + l/16][col0 + wn*64 + tn*16 + l%16].
-// An epilogue is `void operator()(const double (&acc)[4][4][4], const EpiCtx&) const`.
+// acc[tm][tn][r] of lane l is C[row0 + wm*64 + tm*16 + 4r + l/16][col0 + wn*WTN + tn*16 + l%16].
+// An epilogue is `void operator()(const double (&acc)[4][TNW][4], const EpiCtx&) const`.
 struct EpiCtx {
   double* C; int64_t ldc; double alpha;
-  int64_t row0, col0;   // of this wave's 64x64 sub-tile
+  int64_t row0, col0;   // of this wave's 64 x WTN sub-tile
   int lane;
 };
 template <class F>
-__device__ __forceinline__ void epi_foreach(const double (&acc)[4][4][4], const EpiCtx& e, F f) {
+__device__ __forceinline__ void epi_foreach(const double (&acc)[4][TNW][4], const EpiCtx& e, F f) {
   const int c_i = e.lane >> 4, c_j = e.lane & 15;
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm)
@@ -67,24 +81,24 @@ __device__ __forceinline__ void epi_foreach(const double (&acc)[4][4][4], const 
     for (int r = 0; r < 4; ++r) {
       const int64_t gi = e.row0 + tm * 16 + 4 * r + c_i;
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) f(gi, e.col0 + tn * 16 + c_j, e.alpha * acc[tm][tn][r]);
+      for (int tn = 0; tn < TNW; ++tn) f(gi, e.col0 + tn * 16 + c_j, e.alpha * acc[tm][tn][r]);
     }
 }
 struct EpiStore {   // C = alpha*acc
-  __device__ __forceinline__ void operator()(const double (&acc)[4][4][4], const EpiCtx& e) const {
+  __device__ __forceinline__ void operator()(const double (&acc)[4][TNW][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = v; });
   }
 };
 struct EpiAccum {   // C += alpha*acc
-  __device__ __forceinline__ void operator()(const double (&acc)[4][4][4], const EpiCtx& e) const {
+  __device__ __forceinline__ void operator()(const double (&acc)[4][TNW][4], const EpiCtx& e) const {
     double* C = e.C; const int64_t ld = e.ldc;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] += v; });
   }
 };
 struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
   const double* __restrict__ S;
-  __device__ __forceinline__ void operator()(const double (&acc)[4][4][4], const EpiCtx& e) const {
+  __device__ __forceinline__ void operator()(const double (&acc)[4][TNW][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc; const double* __restrict__ Sp = S;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = v - Sp[i * ld + j]; });
   }
@@ -94,27 +108,29 @@ struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
 template <int LAY>
 __device__ __forceinline__ int lds_idx(int mn, int k) {
   if (LAY == LAY_KCONTIG) return mn * 16 + 2 * ((k >> 1) ^ ((mn >> 1) & 7)) + (k & 1);
-  return k * 128 + 2 * ((mn >> 1) ^ (10 * (k & 1))) + (mn & 1);
+  return k * LDMN + mn;
 }
 
-// Issue the 4 global_load_lds_dwordx4 of this wave for one 16 KB operand tile.
+// Issue this wave's share (16 / GEMM_WAVES) of the 16 global_load_lds_dwordx4 of one operand tile.
 template <int LAY>
 __device__ __forceinline__ void glds_tile(double* tile, const double* __restrict__ P, int64_t ld, int64_t mn0, int64_t k0,
                                           int wave, int lane) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int c = 4 * p + wave;                         // 1 KB chunk id (0..15)
+  for (int p = 0; p < 16 / GEMM_WAVES; ++p) {
+    const int c = GEMM_WAVES * p + wave;                // 1 KB chunk id (0..15)
     const double* src;
+    double* dst;
     if (LAY == LAY_KCONTIG) {                           // chunk = rows 8c..8c+7, lane -> (row, granule position)
       const int row = 8 * c + (lane >> 3), gp = lane & 7;
       const int g = gp ^ ((row >> 1) & 7);
       src = P + (mn0 + row) * ld + k0 + 2 * g;
-    } else {                                            // chunk = k-row c, lane -> granule position
-      const int g = lane ^ (10 * (c & 1));
-      src = P + (k0 + c) * ld + mn0 + 2 * g;
+      dst = tile + c * 128;
+    } else {                                            // chunk = k-row c, lane -> granule
+      src = P + (k0 + c) * ld + mn0 + 2 * lane;
+      dst = tile + c * LDMN;
     }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(tile + c * 128), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
 }
 
@@ -128,19 +144,19 @@ enum { TRI_NONE = 0,
 };
 
 template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, class Epi>
-__global__ void __launch_bounds__(GEMM_THREADS, (NSTAGE <= 2) ? 2 : 1)
+__global__ void __launch_bounds__(GEMM_THREADS, ((NSTAGE <= 2) ? 2 : 1) * GEMM_WAVES / 4)
 gemm_f64_kernel(GemmArgs g, Epi epi) {
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
   const GemmTile tl = g.tiles[blockIdx.x];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
   const int64_t row0 = (int64_t)tl.bi * BM, col0 = (int64_t)tl.bj * BN;
 
-  double acc[4][4][4];
+  double acc[4][TNW][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < TNW; ++b)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.0;
 
@@ -161,13 +177,21 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
                                          (__attribute__((address_space(3))) void*)(st + 2 * TILE_DOUBLES), 16, 0, 0);
     }
   };
-  constexpr int GLDS_PER_STAGE = KSCALE ? 9 : 8;
+  constexpr int GLDS_PER_STAGE = 2 * (16 / GEMM_WAVES) + (KSCALE ? 1 : 0);
 
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < total) issue(s);
 
   const int a_i = lane & 3, kq = lane >> 4, b_j = lane & 15;
+  // per-lane LDS read bases; the (tm, r, tn, ks) parts are compile-time offsets (see header comment)
+  const int a_base = (ALAY == LAY_KCONTIG) ? ((wm * 64 + a_i) * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1))
+                                           : (kq * LDMN + wm * 64 + a_i);
+  int b_base[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    b_base[ks] = (BLAY == LAY_KCONTIG) ? ((wn * WTN + b_j) * 16 + 2 * (((2 * ks) | (kq >> 1)) ^ (b_j >> 1)) + (kq & 1))
+                                       : (kq * LDMN + wn * WTN + b_j + ks * 4 * LDMN);
   for (int it = 0; it < total; ++it) {
     // stage `it` must have landed: at most NSTAGE-2 younger stages (8 glds each) may stay in flight
     if (it + NSTAGE - 2 < total) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>();
@@ -183,27 +207,32 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
     bool skip = false;
     if (TRI == TRI_A_LOWER) skip = krel > wm * 64 + 63;
     if (TRI == TRI_A_UPPER) skip = krel + BK - 1 < wm * 64;
-    if (TRI == TRI_C_LOWER) skip = (tl.bi == tl.bj) && (wn > wm);
+    if (TRI == TRI_C_LOWER) skip = (tl.bi == tl.bj) && (wn * WTN > wm * 64 + 63);
     if (!skip) {
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {
         const int k = ks * 4 + kq;
-        double af[4][4], bf[4];
+        double bf[TNW];
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) bf[tn] = Bs[lds_idx<BLAY>(wn * 64 + tn * 16 + b_j, k)];
+        for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * 256 : tn * 16)];
         if (KSCALE) {
           const double sc = As[2 * TILE_DOUBLES + k];
 #pragma unroll
-          for (int tn = 0; tn < 4; ++tn) bf[tn] *= sc;
+          for (int tn = 0; tn < TNW; ++tn) bf[tn] *= sc;
         }
+        // all 16 A fragments of this k-step are requested before the first MFMA (the 64 MFMAs that follow
+        // cover the LDS latency of the next k-step's reads, which the compiler hoists above them)
+        double af[4][4];
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) af[tm][r] = As[lds_idx<ALAY>(wm * 64 + tm * 16 + 4 * r + a_i, k)];
+          for (int r = 0; r < 4; ++r)
+            af[tm][r] = As[a_base + ((ALAY == LAY_KCONTIG) ? ((tm * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r)))
+                                                             : (ks * 4 * LDMN + tm * 16 + 4 * r))];
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < 4; ++tn)
+          for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
@@ -213,7 +242,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
 
   EpiCtx e;
   e.C = g.C + (int64_t)tl.slice * g.slice_stride; e.ldc = g.ldc; e.alpha = g.alpha;
-  e.row0 = row0 + wm * 64; e.col0 = col0 + wn * 64; e.lane = lane;
+  e.row0 = row0 + wm * 64; e.col0 = col0 + wn * WTN; e.lane = lane;
   epi(acc, e);
 }
 
