@@ -243,7 +243,7 @@ int latent_forward_grad(zigp_ctx* c, Latent& lt) {
 int latent_kl(zigp_ctx* c, Latent& lt) {
   ProfScope ps(c, PC_MXM);
   const int Mp = lt.Mp;
-  ZIGP_ENSURE(c, lt.vec, (size_t)3 * Mp + 8);
+  ZIGP_ENSURE(c, lt.vec, (size_t)4 * Mp + 8);
   double* v = lt.vec.p; double* alpha = v + Mp; double* dkinv = v + 2 * Mp; double* klv = v + 3 * Mp;
   hipLaunchKernelGGL(k_gemv_rows, dim3(Mp), dim3(256), 0, c->stream, lt.W.p, lt.u.p, (int64_t)Mp, v);
   hipLaunchKernelGGL(k_kl_cols, dim3(ceil_div(Mp, 64)), dim3(64), 0, c->stream, lt.W.p, v, (int64_t)Mp, alpha, dkinv);
@@ -322,7 +322,6 @@ int latent_chunk_backward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nro
   double* alpha = lt.vec.p + Mp;
   {
     ProfScope ps(c, PC_RED);
-    hipLaunchKernelGGL(k_rowred, dim3(Mp), dim3(256), 0, c->stream, lt.A1.p, lt.A2.p, lt.gm.p, lt.gv.p, Nc, lt.du.p, lt.dsq.p, lt.a1gm.p);
     hipLaunchKernelGGL(k_kgrad, dim3(Mp), dim3(256), 0, c->stream, lt.Jp.p, lt.K.p, alpha, lt.gm.p, lt.gv.p, dX, Nrows, n0, lt.Z.p, lt.M, D,
                        Nc, lt.krow.p);
     ZIGP_HIP(c, hipGetLastError());
@@ -345,9 +344,23 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
   const int gridmm = ceil_div((int64_t)mm, 256);
   double* S = lt.T1.p;
   if (with_data) {
-    TileList ta, tb, tc;
+    TileList ta, tb, tc, td;
+    // rank-1 seeds from K gm (accumulated by k_kgrad): A1 gm = W (K gm), A2 gm = du = W^T (A1 gm)
+    {
+      double* kgm = lt.vec.p + 3 * Mp + 8;
+      hipLaunchKernelGGL(k_gather, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.krow.p, 2 + 2 * D, 1 + 2 * D, Mp, kgm);
+      hipLaunchKernelGGL(k_gemv_rows, dim3(Mp), dim3(256), 0, c->stream, lt.W.p, kgm, (int64_t)Mp, lt.a1gm.p);
+      hipLaunchKernelGGL(k_gemv_cols, dim3(ceil_div(Mp, 64)), dim3(64), 0, c->stream, lt.W.p, lt.a1gm.p, (int64_t)Mp, lt.du.p);
+    }
     // C1 = sym(sum_s planes) -> T1
     hipLaunchKernelGGL(k_sym_from_planes, dim3(gridmm), dim3(256), 0, c->stream, lt.dLpart.p, syr_slices(nb), (int64_t)Mp, lt.T1.p);
+    // dsq = diag(A2 G A2^T) = diag(W^T C1 W): Y = C1 W -> T3 ; dsq[m] = sum_k W[k][m] Y[k][m]
+    ZIGP_TRY(get_tiles(c, "bw_y:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
+      for (int bi = 0; bi < nb; ++bi)
+        for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, nb * kb));
+    }, td));
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, td, mk_args(lt.T1.p, Mp, lt.W.p, Mp, lt.T3.p, Mp), EpiStore())));
+    hipLaunchKernelGGL(k_coldot, dim3(ceil_div(Mp, 64)), dim3(64), 0, c->stream, lt.W.p, lt.T3.p, (int64_t)Mp, lt.dsq.p);
     // T = (W diag(s^2)) W^T -> T2   (both factors lower triangular: k <= min(i,j))
     ZIGP_TRY(get_tiles(c, "bw_tt:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
       for (int bi = 0; bi < nb; ++bi)
@@ -449,14 +462,14 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     const int Mp = lt.Mp;
     ZIGP_ENSURE(c, lt.gm, Nc); ZIGP_ENSURE(c, lt.gv, Nc);
     if (need_grad) {
-      ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)Mp * (1 + 2 * D));
+      ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)Mp * (2 + 2 * D));
       const int S = syr_slices(Mp / BM);
       ZIGP_ENSURE(c, lt.dLpart, (size_t)S * Mp * Mp);
       ZIGP_ENSURE(c, lt.a1gm, Mp);
       ZIGP_HIP(c, hipMemsetAsync(lt.a1gm.p, 0, sizeof(double) * Mp, c->stream));
       ZIGP_HIP(c, hipMemsetAsync(lt.du.p, 0, sizeof(double) * Mp, c->stream));
       ZIGP_HIP(c, hipMemsetAsync(lt.dsq.p, 0, sizeof(double) * Mp, c->stream));
-      ZIGP_HIP(c, hipMemsetAsync(lt.krow.p, 0, sizeof(double) * Mp * (1 + 2 * D), c->stream));
+      ZIGP_HIP(c, hipMemsetAsync(lt.krow.p, 0, sizeof(double) * Mp * (2 + 2 * D), c->stream));
       if (has_rows) ZIGP_HIP(c, hipMemsetAsync(lt.dLpart.p, 0, sizeof(double) * S * Mp * Mp, c->stream));
     }
   }
@@ -495,7 +508,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
       ZIGP_HIP(c, hipMemcpyAsync(hvec[h].data(), lt.vec.p, sizeof(double) * hvec[h].size(), hipMemcpyDeviceToHost, c->stream));
     }
     if (need_grad) {
-      hdu[h].resize(lt.Mp); hdsq[h].resize(lt.Mp); hkrow[h].resize((size_t)lt.Mp * (1 + 2 * D));
+      hdu[h].resize(lt.Mp); hdsq[h].resize(lt.Mp); hkrow[h].resize((size_t)lt.Mp * (2 + 2 * D));
       ZIGP_HIP(c, hipMemcpyAsync(hdu[h].data(), lt.du.p, sizeof(double) * lt.Mp, hipMemcpyDeviceToHost, c->stream));
       ZIGP_HIP(c, hipMemcpyAsync(hdsq[h].data(), lt.dsq.p, sizeof(double) * lt.Mp, hipMemcpyDeviceToHost, c->stream));
       ZIGP_HIP(c, hipMemcpyAsync(hkrow[h].data(), lt.krow.p, sizeof(double) * hkrow[h].size(), hipMemcpyDeviceToHost, c->stream));
@@ -518,7 +531,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     const double sgv[2] = {s_gvf, s_gvg};
     for (int h = 0; h < 2; ++h) {
       Latent& lt = c->lat[h];
-      const int M = lt.M, W = 1 + 2 * D;
+      const int M = lt.M, W = 2 + 2 * D;
       const double* ell = ell_h[h];
       double dv = 0.0;
       std::vector<double> dl(D, 0.0);

@@ -205,37 +205,12 @@ k_pointwise(PwArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row reductions over one chunk, block per row m (cotangents of main.py:287 and :291,302 + rank-1 parts of dL):
-//   du[m] += sum_n A2[m,n] gm[n] ; dsq[m] += sum_n gv[n] A2[m,n]^2 ; a1gm[m] += sum_n A1[m,n] gm[n]
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_rowred(const double* __restrict__ A1, const double* __restrict__ A2, const double* __restrict__ gm, const double* __restrict__ gv,
-         int64_t Nc, double* __restrict__ du, double* __restrict__ dsq, double* __restrict__ a1gm) {
-  __shared__ double sh[4];
-  const int m = blockIdx.x;
-  const double2* r1 = reinterpret_cast<const double2*>(A1 + (int64_t)m * Nc);
-  const double2* r2 = reinterpret_cast<const double2*>(A2 + (int64_t)m * Nc);
-  const double2* gm2 = reinterpret_cast<const double2*>(gm);
-  const double2* gv2 = reinterpret_cast<const double2*>(gv);
-  double a = 0.0, b = 0.0, c = 0.0;
-  for (int64_t n = threadIdx.x; n < Nc / 2; n += 256) {
-    const double2 v = r2[n], w = r1[n], g1 = gm2[n], g2 = gv2[n];
-    a = fma(v.x, g1.x, a); a = fma(v.y, g1.y, a);
-    b = fma(g2.x * v.x, v.x, b); b = fma(g2.y * v.y, v.y, b);
-    c = fma(w.x, g1.x, c); c = fma(w.y, g1.y, c);
-  }
-  a = block_sum<4>(a, sh);
-  b = block_sum<4>(b, sh);
-  c = block_sum<4>(c, sh);
-  if (threadIdx.x == 0) { du[m] += a; dsq[m] += b; a1gm[m] += c; }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Kuf -> (Z, ell, var) cotangent reductions, block per row m of K, with the Kuf cotangent formed on the fly
 //   F[m,n] = dK = alpha[m] gm[n] + 2 gv[n] J'[m,n]:
 //   krow[m][0]     += sum_n F K
 //   krow[m][1+d]   += sum_n F K (x_nd - z_md)
 //   krow[m][1+D+d] += sum_n F K (x_nd - z_md)^2
+//   krow[m][1+2D]  += sum_n K[m,n] gm[n]          (K gm: seeds A1 gm = W (K gm) and A2 gm = W^T W (K gm))
 // (reverse of KernSE.K, onofftf/main.py:41-57)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -248,7 +223,7 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
   double zz[MAXD];
 #pragma unroll
   for (int d = 0; d < MAXD; ++d) zz[d] = (d < D) ? Z[m * D + d] : 0.0;
-  double s0 = 0.0, s1[MAXD], s2[MAXD];
+  double s0 = 0.0, s1[MAXD], s2[MAXD], skg = 0.0;
 #pragma unroll
   for (int d = 0; d < MAXD; ++d) { s1[d] = 0.0; s2[d] = 0.0; }
   const double* fr = Jp + (int64_t)m * Nc;
@@ -256,7 +231,9 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
   const double am = alpha[m];
   for (int64_t n = threadIdx.x; n < Nc; n += 256) {
     if (n0 + n >= N) break;
-    const double t = fma(2.0 * gv[n], fr[n], am * gm[n]) * kr[n];
+    const double kk = kr[n], gmn = gm[n];
+    const double t = fma(2.0 * gv[n], fr[n], am * gmn) * kk;
+    skg = fma(kk, gmn, skg);
     s0 += t;
 #pragma unroll
     for (int d = 0; d < MAXD; ++d)
@@ -267,9 +244,10 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
         s2[d] = fma(td, df, s2[d]);
       }
   }
-  const int W = 1 + 2 * D;
+  const int W = 2 + 2 * D;
   s0 = block_sum<4>(s0, sh);
-  if (threadIdx.x == 0) krow[(int64_t)m * W] += s0;
+  skg = block_sum<4>(skg, sh);
+  if (threadIdx.x == 0) { krow[(int64_t)m * W] += s0; krow[(int64_t)m * W + 1 + 2 * D] += skg; }
   for (int d = 0; d < D; ++d) {
     double a = block_sum<4>(s1[d], sh);
     double b = block_sum<4>(s2[d], sh);
@@ -305,7 +283,7 @@ k_kuu_grad(const double* __restrict__ G, const double* __restrict__ Kuu, double 
         s2[d] = fma(td, df, s2[d]);
       }
   }
-  const int W = 1 + 2 * D;
+  const int W = 2 + 2 * D;
   s0 = block_sum<4>(s0, sh);
   if (threadIdx.x == 0) krow[(int64_t)i * W] += s0;
   for (int d = 0; d < D; ++d) {
@@ -364,6 +342,27 @@ k_gemv_rows(const double* __restrict__ W, const double* __restrict__ u, int64_t 
   for (int k = threadIdx.x; k <= i; k += 256) a = fma(W[(int64_t)i * Mp + k], u[k], a);
   a = block_sum<4>(a, sh);
   if (threadIdx.x == 0) v[i] = a;
+}
+// strided gather x[i] = src[i*stride + off]
+__global__ void k_gather(const double* __restrict__ src, int stride, int off, int n, double* __restrict__ x) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = src[(int64_t)i * stride + off];
+}
+// y[i] = sum_{k>=i} W[k][i] x[k]   (W^T x, W lower triangular; thread per column)
+__global__ void k_gemv_cols(const double* __restrict__ W, const double* __restrict__ x, int64_t Mp, double* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Mp) return;
+  double a = 0.0;
+  for (int k = i; k < Mp; ++k) a = fma(W[(int64_t)k * Mp + i], x[k], a);
+  y[i] = a;
+}
+// d[i] = sum_{k>=i} W[k][i] Y[k][i]   (diag(W^T Y); thread per column)
+__global__ void k_coldot(const double* __restrict__ W, const double* __restrict__ Y, int64_t Mp, double* __restrict__ d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Mp) return;
+  double a = 0.0;
+  for (int k = i; k < Mp; ++k) a = fma(W[(int64_t)k * Mp + i], Y[(int64_t)k * Mp + i], a);
+  d[i] = a;
 }
 // alpha[i] = sum_k W[k][i] v[k] ; dkinv[i] = sum_k W[k][i]^2   (thread per column)
 __global__ void k_kl_cols(const double* __restrict__ W, const double* __restrict__ v, int64_t Mp,
