@@ -127,10 +127,13 @@ int zigp_kron_predict(zigp_ctx* ctx, const zigp_kron_params* p, const double* Xn
                       double g_offset, double* out9);
 
 /* ---- measurement hooks (bench.py) ---- */
-/* Accumulated HIP-event time (ms) and launch count per kernel class since the last reset, measured on
- * the stream the kernels run on.  Classes: 0 gemm_tri (A1,A2,E,F products), 1 syr2k (rank-N updates),
- * 2 kuf_build, 3 colred+pointwise, 4 rowred+kgrad, 5 MxM stage (all kernels), 6 everything else. */
-#define ZIGP_NCLASS 7
+/* Accumulated HIP-event time (ms), launch count and algorithmic flops per kernel class since the last reset,
+ * measured with HIP events on the stream the kernels run on.  Classes:
+ * 0 gemm_lower  (A1 = W K and H = W diag(s^2) A2: gemm_f64_kernel<KCONTIG,MNCONTIG,..,TRI_A_LOWER,EpiStore>)
+ * 1 gemm_upper  (A2 = W^T A1 and J' = W^T H - A2: gemm_f64_kernel<MNCONTIG,MNCONTIG,..,TRI_A_UPPER,..>)
+ * 2 syrk        (gv-weighted symmetric rank-N update C1 += A1 G A1^T)
+ * 3 kuf_build   4 colred+pointwise   5 kgrad   6 MxM stage (all kernels)   7 everything else. */
+#define ZIGP_NCLASS 8
 int zigp_profile_enable(zigp_ctx* ctx, int32_t on);
 int zigp_profile_get(zigp_ctx* ctx, double* ms /*[ZIGP_NCLASS]*/, int64_t* launches /*[ZIGP_NCLASS]*/,
                      double* flops /*[ZIGP_NCLASS] algorithmic*/);

@@ -27,7 +27,7 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-enum ProfClass { PC_GEMM = 0, PC_SYR2K = 1, PC_KUF = 2, PC_POINT = 3, PC_RED = 4, PC_MXM = 5, PC_OTHER = 6 };
+enum ProfClass { PC_GEMM_LO = 0, PC_GEMM_UP = 1, PC_SYR2K = 2, PC_KUF = 3, PC_POINT = 4, PC_RED = 5, PC_MXM = 6, PC_OTHER = 7 };
 
 struct TileList {
   GemmTile* d = nullptr;

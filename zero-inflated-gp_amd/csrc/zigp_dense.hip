@@ -272,22 +272,22 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
   ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu));
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {
-    ProfScope ps(c, PC_GEMM, fl);   // A1 = W K
+    ProfScope ps(c, PC_GEMM_LO, fl);   // A1 = W K
     ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), EpiStore())));
   }
   {
-    ProfScope ps(c, PC_GEMM, fl);   // A2 = W^T A1
+    ProfScope ps(c, PC_GEMM_UP, fl);   // A2 = W^T A1
     ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), EpiStore())));
   }
   if (need_grad) {
     ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc);
     ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc);
     {
-      ProfScope ps(c, PC_GEMM, fl);   // H = (W diag(s^2)) A2
+      ProfScope ps(c, PC_GEMM_LO, fl);   // H = (W diag(s^2)) A2
       ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wp.p, Mp, lt.A2.p, Nc, lt.H.p, Nc), EpiStore())));
     }
     {
-      ProfScope ps(c, PC_GEMM, fl);   // J' = W^T H - A2
+      ProfScope ps(c, PC_GEMM_UP, fl);   // J' = W^T H - A2
       ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.H.p, Nc, lt.Jp.p, Nc), EpiSubLoad{lt.A2.p})));
     }
   }

@@ -8,8 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(ROOT, 'lib', 'libzigp.so')
 
 ZIGP_OK, ZIGP_EARG, ZIGP_EHIP, ZIGP_ENOTPD = 0, -1, -2, -3
-NCLASS = 7
-PROF_CLASSES = ('gemm_tri', 'syr2k', 'kuf_build', 'colred_pointwise', 'rowred_kgrad', 'mxm_stage', 'other')
+NCLASS = 8
+PROF_CLASSES = ('gemm_lower', 'gemm_upper', 'syrk', 'kuf_build', 'colred_pointwise', 'kgrad', 'mxm_stage', 'other')
 
 dp = C.POINTER(C.c_double)
 
