@@ -217,4 +217,4 @@ def kron_elbo_and_grad(X, Y, p_np, jitter, scale=1.0, g_offset=0.0, include_kl=T
             grads[k] = [v.grad.numpy().copy() for v in p[k]]
         for k in KRON_VEC_KEYS:
             grads[k] = p[k].grad.numpy().copy()
-    return float(elbo), float(data), float(kl), grads
+    return float(elbo.detach()), float(data.detach()), float(kl.detach()), grads

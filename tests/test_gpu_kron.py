@@ -1,0 +1,140 @@
+"""GPU parity of the Kronecker (space x time) path against the LITERAL dense restatement of
+scripts/onoff.py:143-319 / onofftf/main.py:350-387 (oracle/zigp_oracle*.py)."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def make_kron_problem(N, M0, M1, seed=0, M0g=None, M1g=None, ell_s=3.0, ell_t=None, u_scale=0.1):
+    """pptr-like: 2 spatial columns, 1 temporal column; ~60 % exact zeros in Y."""
+    # temporal lengthscale ~ 1.5x the inducing spacing, as in the reference's init (linspace grid, scripts/onoff.py:57,68)
+    ell_t = ell_t if ell_t is not None else 1.5 / max(M1 - 1, 1)
+    rs = np.random.RandomState(seed)
+    X = np.hstack([rs.rand(N, 2) * 10.0, rs.rand(N, 1)])
+    f = np.sin(X[:, 0]) + np.cos(3 * X[:, 2])
+    Y = np.where(rs.rand(N) > 0.6, np.abs(f + 0.3 * rs.randn(N)), 0.0)[:, None]
+    M0g, M1g = M0g or M0, M1g or M1
+    p = dict(Zf=[rs.rand(M0, 2) * 10.0, np.linspace(0, 1, M1)[:, None]], Zg=[rs.rand(M0g, 2) * 10.0, np.linspace(0, 1, M1g)[:, None]],
+             ell_f=[np.array([ell_s, ell_s * 1.2]), np.array([ell_t])], ell_g=[np.array([ell_s * 0.8, ell_s]), np.array([ell_t * 1.5])],
+             var_f=[np.array([2.0]), np.array([1.5])], var_g=[np.array([1.2]), np.array([0.9])],
+             u_fm=u_scale * rs.randn(M0 * M1, 1), u_gm=u_scale * rs.randn(M0g * M1g, 1),
+             u_fs_sqrt=0.5 + rs.rand(M0 * M1, 1), u_gs_sqrt=0.5 + rs.rand(M0g * M1g, 1), noise=0.05)
+    return X, Y, p
+
+
+ELL_T_HARD = 0.3   # 32 inducing times on [0,1] with this lengthscale: cond(K_t) ~ 1e7 at jitter 1e-5
+CASES = [(200, 6, 5, None, None), (1000, 10, 12, 8, 9), (700, 32, 32, None, None), (1500, 10, 100, None, None)]
+
+
+def _mp_kron_inf(X, Zl, ell, var, u, s, jitter, npts):
+    """40-digit evaluation of kron_inf (scripts/onoff.py:186-213) for the first npts rows: 'truth' when the factor
+    matrices are so ill-conditioned that the float64 oracle (LU inverse, :192) and the GPU (Cholesky) both drift."""
+    import mpmath as mp
+    mp.mp.dps = 40
+
+    def kmat(A, B, l, v):
+        return mp.matrix([[mp.mpf(float(v)) * mp.exp(-sum(((mp.mpf(float(a[d])) - mp.mpf(float(b[d]))) / mp.mpf(float(l[d]))) ** 2
+                                                           for d in range(len(l))) / 2) for b in B] for a in A])
+    P, ks = [], []
+    c0 = 0
+    for q in range(2):
+        Z = Zl[q]
+        K = kmat(Z, Z, ell[q], var[q])
+        for i in range(Z.shape[0]):
+            K[i, i] += mp.mpf(jitter)
+        P.append(K ** -1)
+        ks.append(kmat(Z, X[:npts, c0:c0 + Z.shape[1]], ell[q], var[q]))
+        c0 += Z.shape[1]
+    M0, M1 = Zl[0].shape[0], Zl[1].shape[0]
+    U = mp.matrix(M0, M1)
+    S2 = mp.matrix(M0, M1)
+    for i in range(M0):
+        for j in range(M1):
+            U[i, j] = mp.mpf(float(u[i * M1 + j, 0]))
+            S2[i, j] = mp.mpf(float(s[i * M1 + j, 0])) ** 2
+    Al = P[0] * U * P[1]
+    a0, a1 = P[0] * ks[0], P[1] * ks[1]
+    mu, vv = [], []
+    knn = mp.mpf(float(var[0])) * mp.mpf(float(var[1]))
+    for n in range(npts):
+        k0, k1 = ks[0][:, n], ks[1][:, n]
+        m = (k0.T * Al * k1)[0]
+        q0 = sum(k0[i] * a0[i, n] for i in range(M0))
+        q1 = sum(k1[j] * a1[j, n] for j in range(M1))
+        t0 = mp.matrix([a0[i, n] ** 2 for i in range(M0)])
+        t1 = mp.matrix([a1[j, n] ** 2 for j in range(M1)])
+        st = (t0.T * S2 * t1)[0]
+        mu.append(float(m))
+        vv.append(float(knn - q0 * q1 + st))
+    return np.array(mu), np.array(vv)
+
+
+@pytest.mark.parametrize('N,M0,M1,M0g,M1g,HARD', [c + (False,) for c in CASES] + [(700, 32, 32, None, None, True)])
+def test_kron_predict_matches_literal_oracle(engine, N, M0, M1, M0g, M1g, HARD):
+    """Well-conditioned factors: GPU == literal oracle to 1e-6.  Ill-conditioned ones (32 / 100 points on a line with a
+    long lengthscale: cond(K_p) ~ 1e7, product ~ 1e13): both are compared with a 40-digit evaluation and the GPU must
+    not be worse than 10x the oracle's own error."""
+    import zigp_oracle as o
+    X, Y, p = make_kron_problem(N, M0, M1, seed=N, M0g=M0g, M1g=M1g, ell_t=ELL_T_HARD if HARD else None)
+    hard = HARD
+    for jit, goff in (((1e-5, 0.0),) if hard else ((1e-5, 0.0), (1e-6, -1.0))):
+        out = engine.kron_predict(p, X, jitter=jit, g_offset=goff)
+        ref = o.kron_build_predict(X, p, jit, goff)
+        names = ('gfmean', 'gfvar', 'gfmeanu', 'fmean', 'fvar', 'gmean', 'gvar', 'ephi_g', 'evar_phi_g')
+        if not hard:
+            errs = [relerr(out[i], ref[i].reshape(-1)) for i in range(9)]
+            for name, e in zip(names, errs):
+                print('jitter %g %s relerr %.2e' % (jit, name, e))
+            if max(errs) < 1e-6:
+                continue
+            # cond-limited (prediction jitter 1e-6 on a long-lengthscale spatial factor): judge against 40 digits instead
+            assert max(errs) < 1e-4
+        npts = 12 if hard else 6
+        npts = 12
+        for tag, (im, iv) in (('f', (3, 4)), ('g', (5, 6))):
+            tm, tv = _mp_kron_inf(X, p['Z' + tag], p['ell_' + tag], [float(np.squeeze(v)) for v in p['var_' + tag]],
+                                  p['u_%sm' % tag], p['u_%ss_sqrt' % tag], jit, npts)
+            if tag == 'g':
+                tm = tm + goff
+            for nm, idx, truth in (('mean', im, tm), ('var', iv, tv)):
+                e_gpu = relerr(out[idx][:npts], truth)
+                e_orc = relerr(ref[idx].reshape(-1)[:npts], truth)
+                print('jitter %g %s%s: gpu vs 40-digit %.2e, oracle vs 40-digit %.2e' % (jit, tag, nm, e_gpu, e_orc))
+                assert e_gpu < max(1e-6, 10 * e_orc), (tag, nm, e_gpu, e_orc)
+        # and the GPU stays within the oracle's own accuracy band of the oracle on every output
+        for i, name in enumerate(names):
+            assert relerr(out[i], ref[i].reshape(-1)) < 1e-3, name
+
+
+@pytest.mark.parametrize('N,M0,M1,M0g,M1g', CASES[:3])
+def test_kron_elbo_and_gradient_match_literal_oracle(engine, N, M0, M1, M0g, M1g):
+    import zigp_oracle_torch as ot
+    X, Y, p = make_kron_problem(N, M0, M1, seed=N + 1, M0g=M0g, M1g=M1g)
+    scale = 105280.0 / N
+    ed, kl, g = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=scale)
+    e_r, d_r, kl_r, g_r = ot.kron_elbo_and_grad(X, Y, p, 1e-5, scale=scale)
+    print('elbo %.10e ref %.10e  kl %.8e ref %.8e' % (ed - kl, e_r, kl, kl_r))
+    assert abs(ed - scale * d_r) <= 1e-7 * abs(scale * d_r)
+    assert abs(kl - kl_r) <= 1e-7 * abs(kl_r)
+    for k in ('Zf', 'Zg', 'ell_f', 'ell_g', 'var_f', 'var_g'):
+        for q in range(2):
+            a, b = np.asarray(g[k][q]).reshape(-1), np.asarray(g_r[k][q]).reshape(-1)
+            e = np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+            print('  grad %s[%d] relerr %.2e (max |ref| %.3e)' % (k, q, e, np.max(np.abs(b))))
+            assert e < 1e-6, (k, q, e)
+    for k in ('u_fm', 'u_gm', 'u_fs_sqrt', 'u_gs_sqrt', 'noise'):
+        a, b = np.asarray(g[k]).reshape(-1), np.asarray(g_r[k]).reshape(-1)
+        e = np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+        print('  grad %s relerr %.2e' % (k, e))
+        assert e < 1e-6, (k, e)
+
+
+def test_kron_value_only_and_no_kl(engine):
+    X, Y, p = make_kron_problem(300, 5, 4, seed=3)
+    ed, kl, g = engine.kron_elbo(p, X, Y, need_grad=False)
+    assert g is None and np.isfinite(ed) and kl > 0
+    ed2, kl2, _ = engine.kron_elbo(p, X, Y, include_kl=False, need_grad=False)
+    assert kl2 == 0.0 and ed2 == ed

@@ -50,6 +50,8 @@ struct Latent {
   DevBuf vec;                            // small vectors: v=W u [Mp], alpha [Mp], dkinv [Mp], scal[8]
 };
 
+struct KronState;   // Kronecker-path buffers (zigp_kron.hip)
+
 }  // namespace zigp
 
 struct zigp_ctx {
@@ -69,6 +71,8 @@ struct zigp_ctx {
   zigp::DevBuf out9;                    // predict outputs (9,Nc)
   zigp::DevBuf scratch, scratch2;       // misc
   int* d_info = nullptr;
+  zigp::KronState* kron = nullptr;
+  void (*kron_free)(zigp::KronState*) = nullptr;
   std::map<std::string, zigp::TileList> tiles;
   // profiling
   bool prof_on = false;

@@ -16,6 +16,7 @@
 //   MxM stage   Kuu-bar = sym(W^T Phi(L^T dL) W) - dKL/dKuu ; -> dZ, dell, dvar        (Cholesky reverse, Murray 2016 / TF CholeskyGrad)
 #include "zigp_ctx.h"
 #include "zigp_kernels.h"
+#include "zigp_host.h"
 #include <algorithm>
 #include <cmath>
 
@@ -23,185 +24,9 @@ using namespace zigp;
 
 namespace {
 
-struct EpiPhi {  // Phi: keep strictly-lower, halve the diagonal, zero above
-  __device__ __forceinline__ void operator()(const double (&acc)[4][TNW][4], const EpiCtx& e) const {
-    double* __restrict__ C = e.C; const int64_t ld = e.ldc;
-    epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = (j < i) ? v : ((j == i) ? 0.5 * v : 0.0); });
-  }
-};
-
-inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
-inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
-
-template <class F>
-int get_tiles(zigp_ctx* c, const std::string& key, F build, TileList& out) {
-  auto it = c->tiles.find(key);
-  if (it != c->tiles.end()) { out = it->second; return 0; }
-  std::vector<GemmTile> v;
-  build(v);
-  TileList tl;
-  tl.n = (int)v.size();
-  if (tl.n > 0) {
-    ZIGP_HIP(c, hipMalloc((void**)&tl.d, sizeof(GemmTile) * v.size()));
-    ZIGP_HIP(c, hipMemcpy(tl.d, v.data(), sizeof(GemmTile) * v.size(), hipMemcpyHostToDevice));
-  }
-  c->tiles[key] = tl;
-  out = tl;
-  return 0;
-}
-
-inline GemmTile mk_tile(int bi, int bj, int kbeg, int kend, int slice = 0) {
-  GemmTile t; t.bi = bi; t.bj = bj; t.kbeg = kbeg; t.kend = kend; t.slice = slice; t.pad0 = t.pad1 = t.pad2 = 0; return t;
-}
-
-constexpr int NST = ZIGP_NSTAGE;   // LDS ring depth of the GEMM core (2 -> 64 KB, 2 workgroups/CU; 3-4 -> 1 workgroup/CU)
-
-template <int AL, int BL, bool KS, int TRI = TRI_NONE, class EP>
-int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
-  if (tl.n == 0) return 0;
-  g.tiles = tl.d;
-  constexpr size_t shm = sizeof(double) * NST * STAGE_DOUBLES;
-  static bool attr_set = false;   // per instantiation
-  if (!attr_set) {
-    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<AL, BL, NST, KS, TRI, EP>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, KS, TRI, EP>), dim3(tl.n), dim3(GEMM_THREADS), shm, c->stream, g, ep);
-  ZIGP_HIP(c, hipGetLastError());
-  return 0;
-}
-
-inline GemmArgs mk_args(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha = 1.0) {
-  GemmArgs g;
-  g.seg[0].A = A; g.seg[0].B = B; g.seg[0].lda = lda; g.seg[0].ldb = ldb;
-  g.seg[1] = g.seg[0];
-  g.nseg = 1; g.tiles = nullptr; g.C = C; g.ldc = ldc; g.slice_stride = 0; g.alpha = alpha; g.kscale = nullptr;
-  return g;
-}
-
-// ------------------------------------------------------------------------------------------------
-// tile lists
-// ------------------------------------------------------------------------------------------------
-// C(Mp x Nc) = W * B, W lower triangular: row block bi needs k blocks [0, bi]; heavy tiles first.
-int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl) {
-  return get_tiles(c, "trl:" + std::to_string(nbm) + ":" + std::to_string(nbn), [&](std::vector<GemmTile>& v) {
-    for (int bi = nbm - 1; bi >= 0; --bi)
-      for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, (bi + 1) * (BM / BK)));
-  }, tl);
-}
-// C = W^T * B: row block bi needs k blocks [bi, nbm)
-int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl) {
-  return get_tiles(c, "tru:" + std::to_string(nbm) + ":" + std::to_string(nbn), [&](std::vector<GemmTile>& v) {
-    for (int bi = 0; bi < nbm; ++bi)
-      for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * (BM / BK), nbm * (BM / BK)));
-  }, tl);
-}
-// lower-triangular output tiles x S split-K slices over nk k-steps
-int tiles_syr2k(zigp_ctx* c, int nbm, int nk, int S, TileList& tl) {
-  return get_tiles(c, "syr:" + std::to_string(nbm) + ":" + std::to_string(nk) + ":" + std::to_string(S), [&](std::vector<GemmTile>& v) {
-    for (int s = 0; s < S; ++s)
-      for (int bi = 0; bi < nbm; ++bi)
-        for (int bj = 0; bj <= bi; ++bj) v.push_back(mk_tile(bi, bj, (int)((int64_t)nk * s / S), (int)((int64_t)nk * (s + 1) / S), s));
-  }, tl);
-}
-int tiles_full(zigp_ctx* c, int nbm, int nbn, int nk, TileList& tl) {
-  return get_tiles(c, "full:" + std::to_string(nbm) + ":" + std::to_string(nbn) + ":" + std::to_string(nk), [&](std::vector<GemmTile>& v) {
-    for (int bi = 0; bi < nbm; ++bi)
-      for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, nk));
-  }, tl);
-}
-
-int check_info(zigp_ctx* c, const char* what) {
-  int h = 0;
-  ZIGP_HIP(c, hipMemcpyAsync(&h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  ZIGP_HIP(c, hipStreamSynchronize(c->stream));
-  if (h != 0) {
-    c->info = h;
-    char b[256];
-    snprintf(b, sizeof(b), "Cholesky decomposition was not successful for %s: the input might not be positive definite (pivot %d)", what, h);
-    c->err = b;
-    return ZIGP_ENOTPD;
-  }
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// L = chol(A) in place in `Lb` (which holds a copy of A on entry), W = L^-1.  Mp multiple of 128.
-// ------------------------------------------------------------------------------------------------
-int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool want_W) {
-  const int nb = Mp / BM;
-  const int kb = BM / BK;  // k-steps per block
-  // c->d_info is cleared by the caller (several factorizations may share one check_info)
-  ZIGP_HIP(c, hipMemsetAsync(Wb, 0, sizeof(double) * Mp * Mp, c->stream));
-  const size_t shm = sizeof(double) * PB * PBLD;
-  for (int j = 0; j < nb; ++j) {
-    double* Ajj = Lb + (int64_t)j * BM * Mp + (int64_t)j * BM;
-    double* Wjj = Wb + (int64_t)j * BM * Mp + (int64_t)j * BM;
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(1024), shm, c->stream, Ajj, Ajj, Wjj, (int64_t)Mp, j * BM, c->d_info);
-    ZIGP_HIP(c, hipGetLastError());
-    if (j + 1 < nb) {
-      TileList tp, ts;
-      ZIGP_TRY(get_tiles(c, "po_p:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
-        for (int bi = j + 1; bi < nb; ++bi) v.push_back(mk_tile(bi, j, j * kb, (j + 1) * kb));
-      }, tp));
-      // L[bi][j] = A[bi][j] * W_jj^T   (in place: each tile reads only itself and W_jj)
-      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, tp, mk_args(Lb, Mp, Wb, Mp, Lb, Mp), EpiStore())));
-      ZIGP_TRY(get_tiles(c, "po_s:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
-        for (int bi = j + 1; bi < nb; ++bi)
-          for (int bj = j + 1; bj <= bi; ++bj) v.push_back(mk_tile(bi, bj, j * kb, (j + 1) * kb));
-      }, ts));
-      // A[bi][bj] -= L[bi][j] L[bj][j]^T
-      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, ts, mk_args(Lb, Mp, Lb, Mp, Lb, Mp, -1.0), EpiAccum())));
-    }
-  }
-  // zero the strictly-upper blocks of L (they still hold the copy of A)
-  for (int bi = 0; bi + 1 < nb; ++bi)
-    ZIGP_HIP(c, hipMemset2DAsync(Lb + (int64_t)bi * BM * Mp + (int64_t)(bi + 1) * BM, sizeof(double) * Mp, 0,
-                                 sizeof(double) * (size_t)(Mp - (bi + 1) * BM), BM, c->stream));
-  if (!want_W) return 0;
-  // W by recursive doubling over diagonal-block groups: W21 = -W22 (L21 W11)
-  for (int b = 1; b < nb; b *= 2) {
-    TileList t1, t2;
-    ZIGP_TRY(get_tiles(c, "tri1:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
-      for (int lo = 0; lo < nb; lo += 2 * b) {
-        const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
-        if (mid >= nb) continue;
-        for (int bi = mid; bi < hi; ++bi)
-          for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, mid * kb));
-      }
-    }, t1));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t1, mk_args(Lb, Mp, Wb, Mp, Tb, Mp), EpiStore())));
-    ZIGP_TRY(get_tiles(c, "tri2:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
-      for (int lo = 0; lo < nb; lo += 2 * b) {
-        const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
-        if (mid >= nb) continue;
-        for (int bi = mid; bi < hi; ++bi)
-          for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, mid * kb, (bi + 1) * kb));
-      }
-    }, t2));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t2, mk_args(Wb, Mp, Tb, Mp, Wb, Mp, -1.0), EpiStore())));
-  }
-  return 0;
-}
-
-KernHyp make_hyp(const double* ell, double var, int D) {
-  KernHyp h;
-  for (int d = 0; d < MAXD; ++d) h.inv_ell[d] = (d < D) ? 1.0 / ell[d] : 0.0;
-  h.var = var; h.D = D;
-  return h;
-}
-
 struct HostLatent {
   int M; const double *Z, *u, *s, *ell; double var;
 };
-
-int upload_padded(zigp_ctx* c, DevBuf& b, const double* src, size_t n, size_t npad) {
-  ZIGP_ENSURE(c, b, npad);
-  ZIGP_HIP(c, hipMemsetAsync(b.p, 0, sizeof(double) * npad, c->stream));
-  if (n) ZIGP_HIP(c, hipMemcpyAsync(b.p, src, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-  return 0;
-}
 
 // MxM forward for one latent: parameters to device, Kuu, L, W.
 int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double jitter, bool want_W) {
@@ -596,6 +421,7 @@ int zigp_destroy(zigp_ctx* c) {
   }
   DevBuf* bs[] = {&c->ownX, &c->ownY, &c->E, &c->dA1, &c->F, &c->pw_part, &c->out9, &c->scratch, &c->scratch2};
   for (DevBuf* b : bs) b->release();
+  if (c->kron && c->kron_free) c->kron_free(c->kron);
   for (auto& kv : c->tiles) if (kv.second.d) (void)hipFree(kv.second.d);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->d_info) (void)hipFree(c->d_info);

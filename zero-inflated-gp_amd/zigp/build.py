@@ -7,8 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'csrc')
 LIBDIR = os.path.join(ROOT, 'lib')
 LIB = os.path.join(LIBDIR, 'libzigp.so')
-SOURCES = ['zigp_dense.hip', 'zigp_kron.hip']
-HEADERS = ['zigp_gemm.h', 'zigp_ctx.h', 'zigp_kernels.h', '../../include/zigp.h']
+SOURCES = ['zigp_lib.hip']
+HEADERS = ['zigp_dense.hip', 'zigp_kron.hip', 'zigp_gemm.h', 'zigp_ctx.h', 'zigp_kernels.h', 'zigp_host.h', '../../include/zigp.h']
 
 
 def needs_build():

@@ -149,6 +149,94 @@ class DenseEngine:
                                                         ptr(ell), float(np.squeeze(var)), ptr(out)))
         return out
 
+    # ---- Kronecker (space x time) variant -------------------------------------------------------
+    @staticmethod
+    def _pack_kron(p):
+        """p: Zf/Zg = [Z0 (M0,D0), Z1 (M1,D1)], ell_f/ell_g = [l0, l1], var_f/var_g = [v0, v1], u_* (M0*M1), noise."""
+        keep = {}
+        s = _lib.zigp_kron_params()
+
+        def ell(v, D):
+            v = as_f64(v).reshape(-1)
+            if v.size == 1:
+                v = np.full(D, float(v[0]))
+            if v.size != D:
+                raise ValueError('lengthscales must be scalar or match the factor dimension')
+            return np.ascontiguousarray(v)
+
+        dims = None
+        for tag in ('f', 'g'):
+            Z0, Z1 = as_f64(p['Z' + tag][0]), as_f64(p['Z' + tag][1])
+            if Z0.ndim != 2 or Z1.ndim != 2:
+                raise ValueError('factor inducing inputs must be 2-D')
+            if dims is None:
+                dims = (Z0.shape[1], Z1.shape[1])
+            elif dims != (Z0.shape[1], Z1.shape[1]):
+                raise ValueError('f and g factors must act on the same input columns')
+            M0, M1 = Z0.shape[0], Z1.shape[0]
+            l0, l1 = ell(p['ell_' + tag][0], dims[0]), ell(p['ell_' + tag][1], dims[1])
+            um = as_f64(p['u_%sm' % tag]).reshape(-1)
+            us = as_f64(p['u_%ss_sqrt' % tag]).reshape(-1)
+            if um.size != M0 * M1 or us.size != M0 * M1:
+                raise ValueError('u_%sm / u_%ss_sqrt must have M0*M1 entries' % (tag, tag))
+            keep[tag] = (Z0, Z1, l0, l1, um, us)
+            setattr(s, 'M0' + tag, M0); setattr(s, 'M1' + tag, M1)
+            setattr(s, 'Z0' + tag, ptr(Z0)); setattr(s, 'Z1' + tag, ptr(Z1))
+            setattr(s, 'ell0' + tag, ptr(l0)); setattr(s, 'ell1' + tag, ptr(l1))
+            setattr(s, 'var0' + tag, float(np.squeeze(p['var_' + tag][0]))); setattr(s, 'var1' + tag, float(np.squeeze(p['var_' + tag][1])))
+            setattr(s, 'u_%sm' % tag, ptr(um)); setattr(s, 'u_%ss_sqrt' % tag, ptr(us))
+        s.D0, s.D1 = dims
+        s.noise = float(np.squeeze(p['noise']))
+        return s, keep, dims
+
+    def kron_elbo(self, p, X, Y, jitter=1e-5, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True):
+        """One Kronecker ELBO (step) on an explicit minibatch; returns (elbo_data, kl, grads or None)."""
+        s, keep, dims = self._pack_kron(p)
+        X = as_f64(X)
+        if X.ndim != 2 or X.shape[1] != dims[0] + dims[1]:
+            raise ValueError('X must be (N,%d)' % (dims[0] + dims[1]))
+        Y = as_f64(Y).reshape(-1)
+        if Y.size != X.shape[0]:
+            raise ValueError('Y must have N entries')
+        ed, kl = C.c_double(0), C.c_double(0)
+        g, gs = None, None
+        if need_grad:
+            g = {}
+            gs = _lib.zigp_kron_grads()
+            for tag in ('f', 'g'):
+                Z0, Z1, l0, l1, um, us = keep[tag]
+                arrs = dict(Z0=np.zeros_like(Z0), Z1=np.zeros_like(Z1), ell0=np.zeros_like(l0), ell1=np.zeros_like(l1),
+                            um=np.zeros_like(um), us=np.zeros_like(us))
+                g[tag] = arrs
+                setattr(gs, 'Z0' + tag, ptr(arrs['Z0'])); setattr(gs, 'Z1' + tag, ptr(arrs['Z1']))
+                setattr(gs, 'ell0' + tag, ptr(arrs['ell0'])); setattr(gs, 'ell1' + tag, ptr(arrs['ell1']))
+                setattr(gs, 'u_%sm' % tag, ptr(arrs['um'])); setattr(gs, 'u_%ss_sqrt' % tag, ptr(arrs['us']))
+        rc = self.lib.zigp_kron_elbo(self.ctx, C.byref(s), ptr(X), ptr(Y), X.shape[0], float(jitter), float(scale), float(g_offset),
+                                     1 if include_kl else 0, C.byref(ed), C.byref(kl), C.byref(gs) if gs is not None else None)
+        _check(self.lib, self.ctx, rc)
+        out = None
+        if need_grad:
+            out = dict(noise=gs.noise)
+            for tag in ('f', 'g'):
+                a = g[tag]
+                out['Z' + tag] = [a['Z0'], a['Z1']]
+                out['ell_' + tag] = [a['ell0'], a['ell1']]
+                out['var_' + tag] = [getattr(gs, 'var0' + tag), getattr(gs, 'var1' + tag)]
+                out['u_%sm' % tag] = a['um']
+                out['u_%ss_sqrt' % tag] = a['us']
+        return ed.value, kl.value, out
+
+    def kron_predict(self, p, Xnew, jitter=1e-6, g_offset=0.0):
+        """(9,N) in the order of build_predict (scripts/onoff.py:184); onofftf/onoffpred.py uses jitter 1e-6, g_offset -1."""
+        s, keep, dims = self._pack_kron(p)
+        Xnew = as_f64(Xnew)
+        if Xnew.ndim != 2 or Xnew.shape[1] != dims[0] + dims[1]:
+            raise ValueError('Xnew must be (N,%d)' % (dims[0] + dims[1]))
+        out = np.zeros((9, Xnew.shape[0]))
+        _check(self.lib, self.ctx, self.lib.zigp_kron_predict(self.ctx, C.byref(s), ptr(Xnew), Xnew.shape[0], float(jitter),
+                                                               float(g_offset), ptr(out)))
+        return out
+
     # ---- measurement ----
     def profile_enable(self, on=True):
         _check(self.lib, self.ctx, self.lib.zigp_profile_enable(self.ctx, 1 if on else 0))
