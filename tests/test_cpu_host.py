@@ -163,3 +163,19 @@ def test_data_parallel_allreduce_gloo_world2_equals_single_process():
     for k in ot.PARAM_KEYS:
         a, b = np.asarray(g[k]).reshape(-1), np.asarray(g1[k]).reshape(-1)
         assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300), k
+
+
+def test_dataset_iterator_semantics():
+    from onofftf.main import DataSet
+    X, Y = np.arange(10)[:, None].astype(float), np.arange(10)[:, None].astype(float)
+    ds = DataSet(X, Y)
+    seen = []
+    for _ in range(5):
+        xb, yb = ds.next_batch(4)
+        assert xb.shape == (4, 1) and np.array_equal(xb, yb)
+        seen.append(xb.reshape(-1))
+    first_epoch = np.concatenate(seen)[:10]
+    assert sorted(first_epoch.tolist()) == list(range(10))       # one full permutation before the wrap-around
+    assert ds.epochs_completed == 1
+    ds2 = DataSet(X, Y)
+    assert np.array_equal(ds2.next_batch(4)[0].reshape(-1), seen[0])    # seed 121 -> reproducible

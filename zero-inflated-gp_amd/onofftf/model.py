@@ -1,0 +1,73 @@
+"""Parameter set of the Kronecker zero-inflated GP exactly as scripts/onoff.py:51-137 declares it
+(names follow the TF variable scopes f_kern/, g_kern/, likelihood/, f_ind/, g_ind/), + npz checkpoints in place of
+tf.train.Saver (onofftf/utils.py:61-73)."""
+from collections import OrderedDict
+
+import numpy as np
+
+from zigp.optim import ParamSet
+from zigp.transforms import Log1pe, positive
+from .main import Param
+
+
+def init_params(Xtrain, num_inducing_f, num_inducing_g, init_noisevar=0.01, kern_lr=1e-3, indp_lr=1e-3, rng=None, kmeans_seed=None):
+    """scripts/onoff.py:51-137 (fit, noise 0.01) / onofftf/onoffpred.py:21-105 (predict, noise 0.001)."""
+    from scipy.cluster.vq import kmeans
+    rng = rng or np.random
+    init_ell = [np.array([8., 8.]), np.array([5. / 1000])]                     # :57,60
+    Zs = kmeans(Xtrain[:, 0:2], int(num_inducing_f[0]), seed=kmeans_seed)[0]      # :67 (unseeded in the reference)
+    if Zs.shape[0] < int(num_inducing_f[0]):                                     # kmeans may return fewer centroids
+        extra = Xtrain[rng.choice(Xtrain.shape[0], int(num_inducing_f[0]) - Zs.shape[0], replace=False), 0:2]
+        Zs = np.vstack([Zs, extra + 1e-3])
+    Zt = np.linspace(Xtrain[:, 2].min(), Xtrain[:, 2].max(), int(num_inducing_f[1]))[:, None]   # :68
+    Zs_g = Zs if int(num_inducing_g[0]) == Zs.shape[0] else kmeans(Xtrain[:, 0:2], int(num_inducing_g[0]), seed=kmeans_seed)[0]
+    Zt_g = Zt if int(num_inducing_g[1]) == Zt.shape[0] else np.linspace(Xtrain[:, 2].min(), Xtrain[:, 2].max(), int(num_inducing_g[1]))[:, None]
+    Mf, Mg = int(np.prod(num_inducing_f)), int(np.prod(num_inducing_g))
+    p = OrderedDict()
+    for i in range(2):
+        p['f_kern/lengthscale_%d' % i] = Param(init_ell[i], Log1pe(), name='lengthscale', learning_rate=kern_lr)
+        p['f_kern/variance_%d' % i] = Param([20.], Log1pe(), name='variance', learning_rate=kern_lr)      # :58
+        p['g_kern/lengthscale_%d' % i] = Param(init_ell[i], Log1pe(), name='lengthscale', learning_rate=kern_lr)
+        p['g_kern/variance_%d' % i] = Param([10.], Log1pe(), name='variance', learning_rate=kern_lr)      # :61
+    p['likelihood/variance'] = Param(init_noisevar, Log1pe(), name='variance', learning_rate=kern_lr)     # :63,102-104
+    p['f_ind/z_0'], p['f_ind/z_1'] = Param(Zs.copy(), name='z', learning_rate=indp_lr), Param(Zt.copy(), name='z', learning_rate=indp_lr)
+    p['f_ind/value'] = Param(rng.randn(Mf, 1) * 0.1, name='value', learning_rate=indp_lr)                 # :71
+    p['f_ind/variance'] = Param(np.ones((Mf, 1)), positive, name='variance', learning_rate=indp_lr)       # :72,113-115
+    p['g_ind/z_0'], p['g_ind/z_1'] = Param(Zs_g.copy(), name='z', learning_rate=indp_lr), Param(Zt_g.copy(), name='z', learning_rate=indp_lr)
+    p['g_ind/value'] = Param(rng.randn(Mg, 1) * 0.1, name='value', learning_rate=indp_lr)                 # :75
+    p['g_ind/variance'] = Param(np.ones((Mg, 1)), positive, name='variance', learning_rate=indp_lr)
+    return ParamSet(p)
+
+
+def engine_params(pset):
+    v = {k: q.value for k, q in pset.params.items()}
+    return dict(Zf=[v['f_ind/z_0'], v['f_ind/z_1']], Zg=[v['g_ind/z_0'], v['g_ind/z_1']],
+                ell_f=[v['f_kern/lengthscale_0'], v['f_kern/lengthscale_1']], ell_g=[v['g_kern/lengthscale_0'], v['g_kern/lengthscale_1']],
+                var_f=[v['f_kern/variance_0'], v['f_kern/variance_1']], var_g=[v['g_kern/variance_0'], v['g_kern/variance_1']],
+                u_fm=v['f_ind/value'], u_gm=v['g_ind/value'], u_fs_sqrt=v['f_ind/variance'], u_gs_sqrt=v['g_ind/variance'],
+                noise=v['likelihood/variance'])
+
+
+def named_grads(g):
+    """engine gradient dict -> the Param names above."""
+    out = {'likelihood/variance': np.array([g['noise']])}
+    for tag in ('f', 'g'):
+        for i in range(2):
+            out['%s_kern/lengthscale_%d' % (tag, i)] = np.asarray(g['ell_' + tag][i])
+            out['%s_kern/variance_%d' % (tag, i)] = np.array([g['var_' + tag][i]])
+            out['%s_ind/z_%d' % (tag, i)] = np.asarray(g['Z' + tag][i])
+        out['%s_ind/value' % tag] = np.asarray(g['u_%sm' % tag])
+        out['%s_ind/variance' % tag] = np.asarray(g['u_%ss_sqrt' % tag])
+    return out
+
+
+def save_checkpoint(pset, path):
+    np.savez(path, **{k.replace('/', '__'): q.value for k, q in pset.params.items()})
+    return path if str(path).endswith('.npz') else str(path) + '.npz'
+
+
+def load_checkpoint(pset, path):
+    path = path if str(path).endswith('.npz') else str(path) + '.npz'
+    d = np.load(path)
+    for k, q in pset.params.items():
+        q.value = np.asarray(d[k.replace('/', '__')], dtype=np.float64).reshape(q.value.shape)

@@ -1,0 +1,65 @@
+"""`onoff(Xtrain, Ytrain, Xtest, Ytest, dir)` -- the Kronecker zero-inflated GP fit of scripts/onoff.py:22-500 on the
+MI355X engine.  Same defaults (50 000 Adam iterations, minibatch 1000, inducing grid [10,100], jitter 1e-5), same
+return dict; the TensorBoard summaries / plots of the reference are not reproduced (out of scope)."""
+import logging
+import os
+import time
+
+import numpy as np
+
+import zigp
+from zigp.optim import AdamGroups
+from .main import DataSet
+from .model import init_params, engine_params, named_grads, save_checkpoint
+
+jitter_level = 1e-5   # scripts/onoff.py:18
+
+
+def onoff(Xtrain, Ytrain, Xtest, Ytest, dir, num_iter=50000, num_inducing_f=(10, 100), num_inducing_g=(10, 100),
+          num_minibatch=1000, log_every=200, save_every=10000, device=0, engine=None, kmeans_seed=None, history=None):
+    os.makedirs(dir, exist_ok=True) if dir else None
+    logger = logging.getLogger('log')                                                # :35-40
+    logger.setLevel(logging.DEBUG)
+    handler = logging.FileHandler(os.path.join(dir, 'modelsumm.log')) if dir else logging.NullHandler()
+    logger.addHandler(handler)
+    logger.info('traning size   = ' + str(Xtrain.shape[0]))
+    logger.info('test size   = ' + str(Xtest.shape[0]))
+    train_data = DataSet(Xtrain, Ytrain)                                             # :43
+    num_data = Xtrain.shape[0]                                                       # :54
+    pset = init_params(Xtrain, num_inducing_f, num_inducing_g, init_noisevar=0.01, kmeans_seed=kmeans_seed)   # :51-137
+    eng = engine or zigp.DenseEngine(device)
+    opt = AdamGroups(pset)                                                           # :325-350 (one Adam per learning rate)
+    scale = float(num_data) / float(num_minibatch)                                   # :311
+    logger.info('*******  started optimization at ' + time.strftime('%Y%m%d-%H%M') + ' *******')
+    for i in range(num_iter):                                                        # :375-431
+        t0 = time.time()
+        xb, yb = train_data.next_batch(num_minibatch)
+        try:
+            ed, kl, g = eng.kron_elbo(engine_params(pset), xb, yb, jitter=jitter_level, scale=scale)
+            opt.step(named_grads(g))                                                 # minimises cost = -(var_exp*scale - kl), :318
+            if history is not None:
+                history.append(-(ed - kl))
+            if i % log_every == 0:
+                logger.info('{:>16d}'.format(i) + '{:>6.3f}'.format((time.time() - t0) / 60))
+            if save_every and i % save_every == 0 and dir:
+                save_checkpoint(pset, os.path.join(dir, 'model'))
+        except KeyboardInterrupt:
+            print('Stopping training')
+            break
+    if dir:
+        save_checkpoint(pset, os.path.join(dir, 'model'))
+    v = {k: q.value for k, q in pset.params.items()}
+    logger.info('Noise variance          = ' + str(v['likelihood/variance']))
+    for tag, nm in (('f', 'Kf'), ('g', 'Kg')):
+        logger.info('%s spatial lengthscale  = %s' % (nm, v['%s_kern/lengthscale_0' % tag]))
+        logger.info('%s spatial variance     = %s' % (nm, v['%s_kern/variance_0' % tag]))
+        logger.info('%s temporal lengthscale = %s' % (nm, v['%s_kern/lengthscale_1' % tag]))
+        logger.info('%s temporal variance    = %s' % (nm, v['%s_kern/variance_1' % tag]))
+    # test predictions with the TRAINING graph (jitter 1e-5, no gmean shift), clipped at 0  (:466-481)
+    pred_test = np.maximum(eng.kron_predict(engine_params(pset), Xtest, jitter=jitter_level, g_offset=0.0)[0].reshape(-1, 1), 0)
+    test_rmse = np.sqrt(np.mean((pred_test - Ytest) ** 2))
+    test_mae = np.mean(np.abs(pred_test - Ytest))
+    logger.info('test rmse:' + str(test_rmse))
+    logger.info('test mae:' + str(test_mae))
+    logger.removeHandler(handler)
+    return {'Xtrain': Xtrain, 'Ytrain': Ytrain, 'Xtest': Xtest, 'Ytest': Ytest, 'test_rmse': test_rmse, 'test_mae': test_mae}   # :487-500
