@@ -56,7 +56,7 @@ struct GemmTile {
 struct GemmSeg { const double* A; const double* B; int64_t lda, ldb; };
 
 struct GemmArgs {
-  GemmSeg seg[2];
+  GemmSeg seg[2];   // only seg[0] is used (one operand pair per launch)
   int nseg;
   const GemmTile* tiles;
   double* C; int64_t ldc; int64_t slice_stride;  // C plane stride for split-K partials
@@ -111,25 +111,31 @@ __device__ __forceinline__ int lds_idx(int mn, int k) {
   return k * LDMN + mn;
 }
 
-// Issue this wave's share (16 / GEMM_WAVES) of the 16 global_load_lds_dwordx4 of one operand tile.
+// Staging addresses.  A global_load_lds takes (scalar base) + (32-bit per-lane byte offset): the per-lane offsets of this
+// wave's 16 / GEMM_WAVES chunks are computed ONCE (they do not depend on the BK step), the scalar base advances by a
+// constant each step, and the LDS destination (M0) is scalar arithmetic on the wave id -- no per-step vector address math.
+constexpr int CHUNKS = 16 / GEMM_WAVES;
 template <int LAY>
-__device__ __forceinline__ void glds_tile(double* tile, const double* __restrict__ P, int64_t ld, int64_t mn0, int64_t k0,
-                                          int wave, int lane) {
+__device__ __forceinline__ void glds_lane_offsets(uint32_t (&off)[CHUNKS], int64_t ld, int wave, int lane) {
 #pragma unroll
-  for (int p = 0; p < 16 / GEMM_WAVES; ++p) {
+  for (int p = 0; p < CHUNKS; ++p) {
     const int c = GEMM_WAVES * p + wave;                // 1 KB chunk id (0..15)
-    const double* src;
-    double* dst;
     if (LAY == LAY_KCONTIG) {                           // chunk = rows 8c..8c+7, lane -> (row, granule position)
       const int row = 8 * c + (lane >> 3), gp = lane & 7;
       const int g = gp ^ ((row >> 1) & 7);
-      src = P + (mn0 + row) * ld + k0 + 2 * g;
-      dst = tile + c * 128;
+      off[p] = (uint32_t)((row * ld + 2 * g) * 8);
     } else {                                            // chunk = k-row c, lane -> granule
-      src = P + (k0 + c) * ld + mn0 + 2 * lane;
-      dst = tile + c * LDMN;
+      off[p] = (uint32_t)((c * ld + 2 * lane) * 8);
     }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+  }
+}
+template <int LAY>
+__device__ __forceinline__ void glds_tile(double* tile, const char* __restrict__ base, const uint32_t (&off)[CHUNKS], int wave) {
+#pragma unroll
+  for (int p = 0; p < CHUNKS; ++p) {
+    const int c = GEMM_WAVES * p + wave;
+    double* dst = tile + ((LAY == LAY_KCONTIG) ? c * 128 : c * LDMN);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (uint64_t)off[p]),
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
 }
@@ -148,7 +154,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, ((NSTAGE <= 2) ? 2 : 1) * GEMM_W
 gemm_f64_kernel(GemmArgs g, Epi epi) {
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
   const GemmTile tl = g.tiles[blockIdx.x];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS destinations and wave-level skips stay on the SALU
   const int wm = wave / WNW, wn = wave % WNW;
   const int64_t row0 = (int64_t)tl.bi * BM, col0 = (int64_t)tl.bj * BN;
 
@@ -160,24 +167,30 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.0;
 
-  const int nk = tl.kend - tl.kbeg;
-  const int total = nk * g.nseg;
+  const int total = tl.kend - tl.kbeg;       // BK steps of this tile
+  const GemmSeg& sg = g.seg[0];
+  uint32_t offA[CHUNKS], offB[CHUNKS];
+  glds_lane_offsets<ALAY>(offA, sg.lda, wave, lane);
+  glds_lane_offsets<BLAY>(offB, sg.ldb, wave, lane);
+  // scalar bases of BK step 0 and their per-step strides (bytes)
+  const int64_t kfirst = (int64_t)tl.kbeg * BK;
+  const char* baseA = (const char*)(sg.A + ((ALAY == LAY_KCONTIG) ? row0 * sg.lda + kfirst : kfirst * sg.lda + row0));
+  const char* baseB = (const char*)(sg.B + ((BLAY == LAY_KCONTIG) ? col0 * sg.ldb + kfirst : kfirst * sg.ldb + col0));
+  const int64_t strideA = (ALAY == LAY_KCONTIG) ? BK * 8 : BK * 8 * sg.lda;
+  const int64_t strideB = (BLAY == LAY_KCONTIG) ? BK * 8 : BK * 8 * sg.ldb;
+  const char* baseS = (const char*)(g.kscale + kfirst);
 
   auto issue = [&](int it) {
-    const int sg = (it >= nk) ? 1 : 0;
-    const int kb = tl.kbeg + (it - sg * nk);
-    const GemmSeg& s = g.seg[sg];
-    const int64_t k0 = (int64_t)kb * BK;
     double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
-    glds_tile<ALAY>(st, s.A, s.lda, row0, k0, wave, lane);
-    glds_tile<BLAY>(st + TILE_DOUBLES, s.B, s.ldb, col0, k0, wave, lane);
+    glds_tile<ALAY>(st, baseA + it * strideA, offA, wave);
+    glds_tile<BLAY>(st + TILE_DOUBLES, baseB + it * strideB, offB, wave);
     if (KSCALE) {   // 16 doubles of the scale vector; every wave issues the same 128 B (uniform vmcnt accounting)
       if (lane < 8)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.kscale + k0 + 2 * lane),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + (int64_t)it * (BK * 8) + (uint64_t)(16 * lane)),
                                          (__attribute__((address_space(3))) void*)(st + 2 * TILE_DOUBLES), 16, 0, 0);
     }
   };
-  constexpr int GLDS_PER_STAGE = 2 * (16 / GEMM_WAVES) + (KSCALE ? 1 : 0);
+  constexpr int GLDS_PER_STAGE = 2 * CHUNKS + (KSCALE ? 1 : 0);
 
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
@@ -202,8 +215,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
     // Triangular structure at wave (64-row) granularity: a wave whose rows cannot touch this BK step of a
     // triangular A, or whose whole 64x64 output lies above the diagonal of a lower-triangular C, issues no MFMAs
     // (it still takes part in staging and barriers; the co-resident workgroup gets the matrix pipe).
-    const int sgc = (it >= nk) ? 1 : 0;
-    const int krel = (tl.kbeg + (it - sgc * nk)) * BK - tl.bi * BM;   // k offset of this step relative to the row block
+    const int krel = (tl.kbeg + it) * BK - tl.bi * BM;   // k offset of this step relative to the row block
     bool skip = false;
     if (TRI == TRI_A_LOWER) skip = krel > wm * 64 + 63;
     if (TRI == TRI_A_UPPER) skip = krel + BK - 1 < wm * 64;
