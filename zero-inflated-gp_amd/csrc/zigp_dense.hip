@@ -147,8 +147,18 @@ int latent_chunk_backward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nro
   double* alpha = lt.vec.p + Mp;
   {
     ProfScope ps(c, PC_RED);
-    hipLaunchKernelGGL(k_kgrad, dim3(Mp), dim3(256), 0, c->stream, lt.Jp.p, lt.K.p, alpha, lt.gm.p, lt.gv.p, dX, Nrows, n0, lt.Z.p, lt.M, D,
-                       Nc, lt.krow.p);
+    const dim3 gk((unsigned)ceil_div(lt.M, KG_ROWS), KG_SPLIT), bk(256);
+    const int64_t slab = (int64_t)Mp * (2 + 2 * D);
+#define ZIGP_KGRAD(DD)                                                                                                            \
+  case DD:                                                                                                                        \
+    hipLaunchKernelGGL(k_kgrad<DD>, gk, bk, 0, c->stream, lt.Jp.p, lt.K.p, alpha, lt.gm.p, lt.gv.p, dX, Nrows, n0, lt.Z.p, lt.M, Nc, \
+                       slab, lt.krow.p);                                                                                                \
+    break;
+    switch (D) {
+      ZIGP_KGRAD(1) ZIGP_KGRAD(2) ZIGP_KGRAD(3) ZIGP_KGRAD(4) ZIGP_KGRAD(5) ZIGP_KGRAD(6) ZIGP_KGRAD(7) ZIGP_KGRAD(8)
+      default: return fail_arg(c, "D out of range");
+    }
+#undef ZIGP_KGRAD
     ZIGP_HIP(c, hipGetLastError());
   }
   {
@@ -173,7 +183,8 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
     // rank-1 seeds from K gm (accumulated by k_kgrad): A1 gm = W (K gm), A2 gm = du = W^T (A1 gm)
     {
       double* kgm = lt.vec.p + 3 * Mp + 8;
-      hipLaunchKernelGGL(k_gather, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.krow.p, 2 + 2 * D, 1 + 2 * D, Mp, kgm);
+      hipLaunchKernelGGL(k_gather, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.krow.p, 2 + 2 * D, 1 + 2 * D, Mp, KG_SPLIT,
+                         (int64_t)Mp * (2 + 2 * D), kgm);
       hipLaunchKernelGGL(k_gemv_rows, dim3(Mp), dim3(256), 0, c->stream, lt.W.p, kgm, (int64_t)Mp, lt.a1gm.p);
       hipLaunchKernelGGL(k_gemv_cols, dim3(ceil_div(Mp, 64)), dim3(64), 0, c->stream, lt.W.p, lt.a1gm.p, (int64_t)Mp, lt.du.p);
     }
@@ -287,14 +298,14 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     const int Mp = lt.Mp;
     ZIGP_ENSURE(c, lt.gm, Nc); ZIGP_ENSURE(c, lt.gv, Nc);
     if (need_grad) {
-      ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)Mp * (2 + 2 * D));
+      ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)KG_SPLIT * Mp * (2 + 2 * D));
       const int S = syr_slices(Mp / BM);
       ZIGP_ENSURE(c, lt.dLpart, (size_t)S * Mp * Mp);
       ZIGP_ENSURE(c, lt.a1gm, Mp);
       ZIGP_HIP(c, hipMemsetAsync(lt.a1gm.p, 0, sizeof(double) * Mp, c->stream));
       ZIGP_HIP(c, hipMemsetAsync(lt.du.p, 0, sizeof(double) * Mp, c->stream));
       ZIGP_HIP(c, hipMemsetAsync(lt.dsq.p, 0, sizeof(double) * Mp, c->stream));
-      ZIGP_HIP(c, hipMemsetAsync(lt.krow.p, 0, sizeof(double) * Mp * (2 + 2 * D), c->stream));
+      ZIGP_HIP(c, hipMemsetAsync(lt.krow.p, 0, sizeof(double) * KG_SPLIT * Mp * (2 + 2 * D), c->stream));
       if (has_rows) ZIGP_HIP(c, hipMemsetAsync(lt.dLpart.p, 0, sizeof(double) * S * Mp * Mp, c->stream));
     }
   }
@@ -333,7 +344,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
       ZIGP_HIP(c, hipMemcpyAsync(hvec[h].data(), lt.vec.p, sizeof(double) * hvec[h].size(), hipMemcpyDeviceToHost, c->stream));
     }
     if (need_grad) {
-      hdu[h].resize(lt.Mp); hdsq[h].resize(lt.Mp); hkrow[h].resize((size_t)lt.Mp * (2 + 2 * D));
+      hdu[h].resize(lt.Mp); hdsq[h].resize(lt.Mp); hkrow[h].resize((size_t)KG_SPLIT * lt.Mp * (2 + 2 * D));
       ZIGP_HIP(c, hipMemcpyAsync(hdu[h].data(), lt.du.p, sizeof(double) * lt.Mp, hipMemcpyDeviceToHost, c->stream));
       ZIGP_HIP(c, hipMemcpyAsync(hdsq[h].data(), lt.dsq.p, sizeof(double) * lt.Mp, hipMemcpyDeviceToHost, c->stream));
       ZIGP_HIP(c, hipMemcpyAsync(hkrow[h].data(), lt.krow.p, sizeof(double) * hkrow[h].size(), hipMemcpyDeviceToHost, c->stream));
@@ -361,7 +372,12 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
       double dv = 0.0;
       std::vector<double> dl(D, 0.0);
       for (int m = 0; m < M; ++m) {
-        const double* r = &hkrow[h][(size_t)m * W];
+        double r[2 + 2 * MAXD];
+        for (int q = 0; q < W; ++q) {   // column splits summed in fixed order
+          double a = 0.0;
+          for (int sp = 0; sp < KG_SPLIT; ++sp) a += hkrow[h][((size_t)sp * lt.Mp + m) * W + q];
+          r[q] = a;
+        }
         dv += r[0];
         for (int d = 0; d < D; ++d) {
           if (gZ[h]) gZ[h][m * D + d] = r[1 + d] / (ell[d] * ell[d]);

@@ -205,53 +205,72 @@ k_pointwise(PwArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kuf -> (Z, ell, var) cotangent reductions, block per row m of K, with the Kuf cotangent formed on the fly
-//   F[m,n] = dK = alpha[m] gm[n] + 2 gv[n] J'[m,n]:
+// Kuf -> (Z, ell, var) cotangent reductions.  A block owns KG_ROWS rows of K / J' and sweeps the chunk's columns, so
+// gm, gv and the D coordinates of x_n are loaded once per column and reused for every row.  The Kuf cotangent is formed
+// on the fly, F[m,n] = dK = alpha[m] gm[n] + 2 gv[n] J'[m,n]:
 //   krow[m][0]     += sum_n F K
 //   krow[m][1+d]   += sum_n F K (x_nd - z_md)
 //   krow[m][1+D+d] += sum_n F K (x_nd - z_md)^2
 //   krow[m][1+2D]  += sum_n K[m,n] gm[n]          (K gm: seeds A1 gm = W (K gm) and A2 gm = W^T W (K gm))
 // (reverse of KernSE.K, onofftf/main.py:41-57)
 // ---------------------------------------------------------------------------------------------
+constexpr int KG_ROWS = 4;
+constexpr int KG_SPLIT = 4;   // column splits (blockIdx.y); each split accumulates into its own krow slab [KG_SPLIT][Mp][W]
+template <int D>
 __global__ void __launch_bounds__(256)
 k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const double* __restrict__ alpha,
         const double* __restrict__ gm, const double* __restrict__ gv, const double* __restrict__ X, int64_t N, int64_t n0,
-        const double* __restrict__ Z, int M, int D, int64_t Nc, double* __restrict__ krow) {
-  __shared__ double sh[4];
-  const int m = blockIdx.x;
-  if (m >= M) return;
-  double zz[MAXD];
+        const double* __restrict__ Z, int M, int64_t Nc, int64_t slab, double* __restrict__ krow) {
+  constexpr int W = 2 + 2 * D;
+  __shared__ double sh[4][KG_ROWS * W];
+  krow += (int64_t)blockIdx.y * slab;
+  const int m0 = blockIdx.x * KG_ROWS;
+  if (m0 >= M) return;
+  double zz[KG_ROWS][D], am[KG_ROWS], acc[KG_ROWS][W];
 #pragma unroll
-  for (int d = 0; d < MAXD; ++d) zz[d] = (d < D) ? Z[m * D + d] : 0.0;
-  double s0 = 0.0, s1[MAXD], s2[MAXD], skg = 0.0;
+  for (int r = 0; r < KG_ROWS; ++r) {
+    const int m = min(m0 + r, M - 1);
+    am[r] = alpha[m];
 #pragma unroll
-  for (int d = 0; d < MAXD; ++d) { s1[d] = 0.0; s2[d] = 0.0; }
-  const double* fr = Jp + (int64_t)m * Nc;
-  const double* kr = K + (int64_t)m * Nc;
-  const double am = alpha[m];
-  for (int64_t n = threadIdx.x; n < Nc; n += 256) {
-    if (n0 + n >= N) break;
-    const double kk = kr[n], gmn = gm[n];
-    const double t = fma(2.0 * gv[n], fr[n], am * gmn) * kk;
-    skg = fma(kk, gmn, skg);
-    s0 += t;
+    for (int d = 0; d < D; ++d) zz[r][d] = Z[m * D + d];
 #pragma unroll
-    for (int d = 0; d < MAXD; ++d)
-      if (d < D) {
-        const double df = X[(n0 + n) * D + d] - zz[d];
-        const double td = t * df;
-        s1[d] += td;
-        s2[d] = fma(td, df, s2[d]);
-      }
+    for (int q = 0; q < W; ++q) acc[r][q] = 0.0;
   }
-  const int W = 2 + 2 * D;
-  s0 = block_sum<4>(s0, sh);
-  skg = block_sum<4>(skg, sh);
-  if (threadIdx.x == 0) { krow[(int64_t)m * W] += s0; krow[(int64_t)m * W + 1 + 2 * D] += skg; }
-  for (int d = 0; d < D; ++d) {
-    double a = block_sum<4>(s1[d], sh);
-    double b = block_sum<4>(s2[d], sh);
-    if (threadIdx.x == 0) { krow[(int64_t)m * W + 1 + d] += a; krow[(int64_t)m * W + 1 + D + d] += b; }
+  const int64_t nspan = Nc / KG_SPLIT, nbeg = (int64_t)blockIdx.y * nspan;
+  const int64_t nmax = min(nbeg + nspan, N - n0);
+  for (int64_t n = nbeg + threadIdx.x; n < nmax; n += 256) {
+    const double gmn = gm[n], gv2 = 2.0 * gv[n];
+    double x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = X[(n0 + n) * D + d];
+#pragma unroll
+    for (int r = 0; r < KG_ROWS; ++r) {
+      const int64_t o = (int64_t)(m0 + r) * Nc + n;     // rows beyond M are zero-padded panels (inside the allocation)
+      const double kk = K[o];
+      const double t = fma(gv2, Jp[o], am[r] * gmn) * kk;
+      acc[r][0] += t;
+      acc[r][1 + 2 * D] = fma(kk, gmn, acc[r][1 + 2 * D]);
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const double df = x[d] - zz[r][d];
+        const double td = t * df;
+        acc[r][1 + d] += td;
+        acc[r][1 + D + d] = fma(td, df, acc[r][1 + D + d]);
+      }
+    }
+  }
+  // fixed-order block reduction of the KG_ROWS*W partials: lanes by xor tree, then waves 0..3
+#pragma unroll
+  for (int r = 0; r < KG_ROWS; ++r)
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      const double v = wave_sum(acc[r][q]);
+      if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][r * W + q] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < KG_ROWS * W) {
+    const int r = threadIdx.x / W, q = threadIdx.x - r * W;
+    if (m0 + r < M) krow[(int64_t)(m0 + r) * W + q] += (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
   }
 }
 
@@ -343,10 +362,13 @@ k_gemv_rows(const double* __restrict__ W, const double* __restrict__ u, int64_t 
   a = block_sum<4>(a, sh);
   if (threadIdx.x == 0) v[i] = a;
 }
-// strided gather x[i] = src[i*stride + off]
-__global__ void k_gather(const double* __restrict__ src, int stride, int off, int n, double* __restrict__ x) {
+// strided gather over slabs: x[i] = sum_sp src[sp*slab + i*stride + off]   (fixed order)
+__global__ void k_gather(const double* __restrict__ src, int stride, int off, int n, int nslab, int64_t slab, double* __restrict__ x) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] = src[(int64_t)i * stride + off];
+  if (i >= n) return;
+  double a = 0.0;
+  for (int sp = 0; sp < nslab; ++sp) a += src[(int64_t)sp * slab + (int64_t)i * stride + off];
+  x[i] = a;
 }
 // y[i] = sum_{k>=i} W[k][i] x[k]   (W^T x, W lower triangular; thread per column)
 __global__ void k_gemv_cols(const double* __restrict__ W, const double* __restrict__ x, int64_t Mp, double* __restrict__ y) {
