@@ -56,7 +56,9 @@ struct KronState;   // Kronecker-path buffers (zigp_kron.hip)
 
 struct zigp_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;    // stream every launch helper enqueues on (swapped to stream2 inside a TwoStream section)
+  hipStream_t stream_main = nullptr, stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   int info = 0;
   int64_t chunk = 32768;
@@ -112,6 +114,28 @@ namespace zigp {
   } while (0)
 
 inline int fail_arg(zigp_ctx* c, const char* msg) { c->err = msg; return ZIGP_EARG; }
+
+// Two independent launch chains (the MxM stages of latents f and g) on two HIP streams: fork() after the work both
+// depend on, second() switches the helpers to stream2, join() makes the main stream wait for it.  The destructor
+// restores the main stream on every exit path.
+struct TwoStream {
+  zigp_ctx* c;
+  explicit TwoStream(zigp_ctx* c_) : c(c_) {}
+  ~TwoStream() { c->stream = c->stream_main; }
+  int fork() {
+    ZIGP_HIP(c, hipEventRecord(c->ev_fork, c->stream_main));
+    ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    return 0;
+  }
+  void second() { c->stream = c->stream2; }
+  void first() { c->stream = c->stream_main; }
+  int join() {
+    c->stream = c->stream_main;
+    ZIGP_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+    ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0));
+    return 0;
+  }
+};
 
 // RAII-less profiling bracket: call prof_begin before and prof_end after a group of launches.
 struct ProfScope {

@@ -279,13 +279,20 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
   const double* ell_h[2] = {p->ell_f, p->ell_g};
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
-  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], D, jitter, true));
+  {
+    // MxM forward of f on the main stream and of g on stream2 (dozens of small dependent launches each)
+    TwoStream ts(c);
+    ZIGP_TRY(ts.fork());
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1) ts.second();
+      ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], D, jitter, true));
+      // v = W u and alpha = W^T v are needed by the KL value AND by the rank-1 parts of the data-term gradient
+      if ((include_kl || need_grad) && !predict) ZIGP_TRY(latent_kl(c, c->lat[h]));
+      if (need_grad) ZIGP_TRY(latent_forward_grad(c, c->lat[h]));
+    }
+    ZIGP_TRY(ts.join());
+  }
   ZIGP_TRY(check_info(c, "Kuu"));
-  // v = W u and alpha = W^T v are needed by the KL value AND by the rank-1 parts of the data-term gradient
-  if ((include_kl || need_grad) && !predict)
-    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_kl(c, c->lat[h]));
-  if (need_grad)
-    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward_grad(c, c->lat[h]));
 
   int64_t Nc = c->chunk;
   const int64_t span = has_rows ? (row_end - row_begin) : 0;
@@ -331,7 +338,15 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   }
   if (predict) { ZIGP_HIP(c, hipStreamSynchronize(c->stream)); prof_collect(c); return 0; }
   if (need_grad)
-    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_mxm_backward(c, c->lat[h], D, jitter, has_rows, include_kl != 0));
+  {
+    TwoStream ts(c);
+    ZIGP_TRY(ts.fork());
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1) ts.second();
+      ZIGP_TRY(latent_mxm_backward(c, c->lat[h], D, jitter, has_rows, include_kl != 0));
+    }
+    ZIGP_TRY(ts.join());
+  }
 
   // ---- gather results on the host (fixed-order final sums) ----
   std::vector<double> hpw((size_t)pw_blocks * 4);
@@ -418,6 +433,10 @@ int zigp_create(zigp_ctx** out, int device_id) {
   if (!c) return ZIGP_EHIP;
   c->device = device_id;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZIGP_EHIP; }
+  c->stream_main = c->stream;
+  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return ZIGP_EHIP; }
+  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipMalloc((void**)&c->d_info, sizeof(int)) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(sizeof(double) * PB * PBLD)) != hipSuccess) { delete c; return ZIGP_EHIP; }
@@ -428,7 +447,8 @@ int zigp_create(zigp_ctx** out, int device_id) {
 int zigp_destroy(zigp_ctx* c) {
   if (!c) return ZIGP_EARG;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream_main);
+  (void)hipStreamSynchronize(c->stream2);
   for (int h = 0; h < 2; ++h) {
     Latent& l = c->lat[h];
     DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.H, &l.Jp, &l.Wp, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
@@ -441,7 +461,10 @@ int zigp_destroy(zigp_ctx* c) {
   for (auto& kv : c->tiles) if (kv.second.d) (void)hipFree(kv.second.d);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->d_info) (void)hipFree(c->d_info);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream_main) (void)hipStreamDestroy(c->stream_main);
   delete c;
   return ZIGP_OK;
 }
