@@ -9,10 +9,9 @@
 //     instructions whose A operand is a 4-row block read from LDS with the same address in all four
 //     16-lane groups (LDS broadcast is free).  The accumulator layout then equals the 16x16x4 one:
 //     acc[r] of lane l = C[4r + l/16][l%16].
-//   * workgroup = 256 threads = 4 waves (2x2), tile 128x128, BK = 16; wave tile 64x64 = 16 sub-tiles,
-//     64 independent accumulators per lane (128 VGPRs) -> MFMA issue is never dependency-bound; two
-//     workgroups share a CU (2 waves/SIMD).  (An 8-wave 2x4 variant with 64x32 wave tiles and 4 waves/SIMD
-//     is kept behind ZIGP_GEMM_WAVES=8; it measured 10 % slower.)
+//   * workgroup tile 128x128, BK = 16, as 4 waves (2x2, 64x64 wave tiles, 64 accumulators/lane) or 8 waves
+//     (2x4, 64x32 wave tiles, 32 accumulators/lane); two workgroups share a CU.  MFMA issue is never
+//     dependency-bound (>= 32 independent accumulators).
 //   * operand tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into an
 //     NSTAGE-deep ring.  One wave-instruction writes 1 KB linearly, so bank conflicts are removed
 //     (a) for k-contiguous tiles ([128 rows][16 k], 8 rows per instruction) by an XOR swizzle of the 16-byte
@@ -29,13 +28,17 @@
 namespace zigp {
 
 constexpr int BM = 128, BN = 128, BK = 16;
-#ifndef ZIGP_GEMM_WAVES
-#define ZIGP_GEMM_WAVES 4     // measured on MI355X: 4 waves (64x64 wave tiles, 2 waves/SIMD) 170 ms/step vs 8 waves (64x32, 4 waves/SIMD) 187 ms
-#endif
-constexpr int GEMM_WAVES = ZIGP_GEMM_WAVES, GEMM_THREADS = 64 * GEMM_WAVES;   // 2 (M) x GEMM_WAVES/2 (N) waves
-constexpr int WNW = GEMM_WAVES / 2;          // waves along N
-constexpr int WTN = BN / WNW;                // wave tile width: 64 (4 waves) or 32 (8 waves)
-constexpr int TNW = WTN / 16;                // 16-column sub-tiles per wave
+// Workgroup shapes (template parameter WAVES of the kernel): 2 (M) x WAVES/2 (N) waves.
+//   WAVES = 4: wave tile 64x64, 64 accumulators/lane, <= 256 VGPRs, 2 waves/SIMD with 2 workgroups/CU
+//   WAVES = 8: wave tile 64x32, 32 accumulators/lane, <= 128 VGPRs, 4 waves/SIMD with 2 workgroups/CU
+// Measured on MI355X (cfg3): the 8-wave shape is ~7 % faster where it fits 128 VGPRs without spilling.
+template <int WAVES> struct Shape {
+  static constexpr int THREADS = 64 * WAVES;
+  static constexpr int WNW = WAVES / 2;        // waves along N
+  static constexpr int WTN = BN / WNW;         // wave tile width
+  static constexpr int TNW = WTN / 16;         // 16-column sub-tiles per wave
+  static constexpr int CHUNKS = 16 / WAVES;    // 1 KB staging chunks per wave and operand tile
+};
 constexpr int LDMN = 128 + 16;                    // row stride (doubles) of an m/n-contiguous tile image: odd k rows shift 128 B
 constexpr int TILE_DOUBLES = BK * LDMN;           // 2304 doubles (18 KB) holds either image: [128][16] swizzled or [16][144]
 constexpr int STAGE_DOUBLES = 2 * TILE_DOUBLES + BK;   // A tile + B tile + one BK-slice of the k-scale vector
@@ -66,14 +69,14 @@ struct GemmArgs {
 
 // ---- epilogues --------------------------------------------------------------------------------
 // acc[tm][tn][r] of lane l is C[row0 + wm*64 + tm*16 + 4r + l/16][col0 + wn*WTN + tn*16 + l%16].
-// An epilogue is `void operator()(const double (&acc)[4][TNW][4], const EpiCtx&) const`.
+// An epilogue is `template <int TN> void operator()(const double (&acc)[4][TN][4], const EpiCtx&) const`.
 struct EpiCtx {
   double* C; int64_t ldc; double alpha;
   int64_t row0, col0;   // of this wave's 64 x WTN sub-tile
   int lane;
 };
-template <class F>
-__device__ __forceinline__ void epi_foreach(const double (&acc)[4][TNW][4], const EpiCtx& e, F f) {
+template <int TN, class F>
+__device__ __forceinline__ void epi_foreach(const double (&acc)[4][TN][4], const EpiCtx& e, F f) {
   const int c_i = e.lane >> 4, c_j = e.lane & 15;
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm)
@@ -81,24 +84,27 @@ __device__ __forceinline__ void epi_foreach(const double (&acc)[4][TNW][4], cons
     for (int r = 0; r < 4; ++r) {
       const int64_t gi = e.row0 + tm * 16 + 4 * r + c_i;
 #pragma unroll
-      for (int tn = 0; tn < TNW; ++tn) f(gi, e.col0 + tn * 16 + c_j, e.alpha * acc[tm][tn][r]);
+      for (int tn = 0; tn < TN; ++tn) f(gi, e.col0 + tn * 16 + c_j, e.alpha * acc[tm][tn][r]);
     }
 }
 struct EpiStore {   // C = alpha*acc
-  __device__ __forceinline__ void operator()(const double (&acc)[4][TNW][4], const EpiCtx& e) const {
+  template <int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[4][TN][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = v; });
   }
 };
 struct EpiAccum {   // C += alpha*acc
-  __device__ __forceinline__ void operator()(const double (&acc)[4][TNW][4], const EpiCtx& e) const {
+  template <int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[4][TN][4], const EpiCtx& e) const {
     double* C = e.C; const int64_t ld = e.ldc;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] += v; });
   }
 };
 struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
   const double* __restrict__ S;
-  __device__ __forceinline__ void operator()(const double (&acc)[4][TNW][4], const EpiCtx& e) const {
+  template <int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[4][TN][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc; const double* __restrict__ Sp = S;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = v - Sp[i * ld + j]; });
   }
@@ -114,12 +120,12 @@ __device__ __forceinline__ int lds_idx(int mn, int k) {
 // Staging addresses.  A global_load_lds takes (scalar base) + (32-bit per-lane byte offset): the per-lane offsets of this
 // wave's 16 / GEMM_WAVES chunks are computed ONCE (they do not depend on the BK step), the scalar base advances by a
 // constant each step, and the LDS destination (M0) is scalar arithmetic on the wave id -- no per-step vector address math.
-constexpr int CHUNKS = 16 / GEMM_WAVES;
-template <int LAY>
-__device__ __forceinline__ void glds_lane_offsets(uint32_t (&off)[CHUNKS], int64_t ld, int wave, int lane) {
+template <int LAY, int WAVES>
+__device__ __forceinline__ void glds_lane_offsets(uint32_t (&off)[16 / WAVES], int64_t ld, int wave, int lane) {
+  constexpr int CHUNKS = 16 / WAVES;
 #pragma unroll
   for (int p = 0; p < CHUNKS; ++p) {
-    const int c = GEMM_WAVES * p + wave;                // 1 KB chunk id (0..15)
+    const int c = WAVES * p + wave;                     // 1 KB chunk id (0..15)
     if (LAY == LAY_KCONTIG) {                           // chunk = rows 8c..8c+7, lane -> (row, granule position)
       const int row = 8 * c + (lane >> 3), gp = lane & 7;
       const int g = gp ^ ((row >> 1) & 7);
@@ -129,11 +135,11 @@ __device__ __forceinline__ void glds_lane_offsets(uint32_t (&off)[CHUNKS], int64
     }
   }
 }
-template <int LAY>
-__device__ __forceinline__ void glds_tile(double* tile, const char* __restrict__ base, const uint32_t (&off)[CHUNKS], int wave) {
+template <int LAY, int WAVES>
+__device__ __forceinline__ void glds_tile(double* tile, const char* __restrict__ base, const uint32_t (&off)[16 / WAVES], int wave) {
 #pragma unroll
-  for (int p = 0; p < CHUNKS; ++p) {
-    const int c = GEMM_WAVES * p + wave;
+  for (int p = 0; p < 16 / WAVES; ++p) {
+    const int c = WAVES * p + wave;
     double* dst = tile + ((LAY == LAY_KCONTIG) ? c * 128 : c * LDMN);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (uint64_t)off[p]),
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -149,9 +155,10 @@ enum { TRI_NONE = 0,
        TRI_C_LOWER = 3    // only C(i,j), j <= i, is used (rank-N update of a lower-triangular cotangent)
 };
 
-template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, class Epi>
-__global__ void __launch_bounds__(GEMM_THREADS, ((NSTAGE <= 2) ? 2 : 1) * GEMM_WAVES / 4)
+template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, int WAVES, class Epi>
+__global__ void __launch_bounds__(64 * WAVES, ((NSTAGE <= 2) ? 2 : 1) * WAVES / 4)
 gemm_f64_kernel(GemmArgs g, Epi epi) {
+  constexpr int WNW = Shape<WAVES>::WNW, WTN = Shape<WAVES>::WTN, TNW = Shape<WAVES>::TNW, CHUNKS = Shape<WAVES>::CHUNKS;
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
   const GemmTile tl = g.tiles[blockIdx.x];
   const int t = threadIdx.x, lane = t & 63;
@@ -170,8 +177,8 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   const int total = tl.kend - tl.kbeg;       // BK steps of this tile
   const GemmSeg& sg = g.seg[0];
   uint32_t offA[CHUNKS], offB[CHUNKS];
-  glds_lane_offsets<ALAY>(offA, sg.lda, wave, lane);
-  glds_lane_offsets<BLAY>(offB, sg.ldb, wave, lane);
+  glds_lane_offsets<ALAY, WAVES>(offA, sg.lda, wave, lane);
+  glds_lane_offsets<BLAY, WAVES>(offB, sg.ldb, wave, lane);
   // scalar bases of BK step 0 and their per-step strides (bytes)
   const int64_t kfirst = (int64_t)tl.kbeg * BK;
   const char* baseA = (const char*)(sg.A + ((ALAY == LAY_KCONTIG) ? row0 * sg.lda + kfirst : kfirst * sg.lda + row0));
@@ -182,8 +189,8 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
 
   auto issue = [&](int it) {
     double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
-    glds_tile<ALAY>(st, baseA + it * strideA, offA, wave);
-    glds_tile<BLAY>(st + TILE_DOUBLES, baseB + it * strideB, offB, wave);
+    glds_tile<ALAY, WAVES>(st, baseA + it * strideA, offA, wave);
+    glds_tile<BLAY, WAVES>(st + TILE_DOUBLES, baseB + it * strideB, offB, wave);
     if (KSCALE) {   // 16 doubles of the scale vector; every wave issues the same 128 B (uniform vmcnt accounting)
       if (lane < 8)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + (int64_t)it * (BK * 8) + (uint64_t)(16 * lane)),
@@ -232,22 +239,39 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
 #pragma unroll
           for (int tn = 0; tn < TNW; ++tn) bf[tn] *= sc;
         }
-        // all 16 A fragments of this k-step are requested before the first MFMA (the 64 MFMAs that follow
-        // cover the LDS latency of the next k-step's reads, which the compiler hoists above them)
-        double af[4][4];
+        if (WAVES == 4) {
+          // all 16 A fragments of this k-step are requested before the first MFMA (the 64 MFMAs that follow
+          // cover the LDS latency of the next k-step's reads, which the compiler hoists above them)
+          double af[4][4];
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            af[tm][r] = As[a_base + ((ALAY == LAY_KCONTIG) ? ((tm * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r)))
-                                                             : (ks * 4 * LDMN + tm * 16 + 4 * r))];
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TNW; ++tn)
+          for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
+              af[tm][r] = As[a_base + ((ALAY == LAY_KCONTIG) ? ((tm * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r)))
+                                                               : (ks * 4 * LDMN + tm * 16 + 4 * r))];
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TNW; ++tn)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
+        } else {
+          // 4 waves/SIMD hide LDS latency across waves: fragments are read 4 at a time to stay within 128 VGPRs
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm) {
+            double af[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              af[r] = As[a_base + ((ALAY == LAY_KCONTIG) ? ((tm * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r)))
+                                                           : (ks * 4 * LDMN + tm * 16 + 4 * r))];
+#pragma unroll
+            for (int tn = 0; tn < TNW; ++tn)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[r], bf[tn], acc[tm][tn][r], 0, 0, 0);
+          }
+        }
       }
     }
   }

@@ -9,7 +9,8 @@
 namespace zigp {
 
 struct EpiPhi {  // Phi: keep strictly-lower, halve the diagonal, zero above
-  __device__ __forceinline__ void operator()(const double (&acc)[4][TNW][4], const EpiCtx& e) const {
+  template <int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[4][TN][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = (j < i) ? v : ((j == i) ? 0.5 * v : 0.0); });
   }
@@ -39,20 +40,30 @@ static inline GemmTile mk_tile(int bi, int bj, int kbeg, int kend, int slice = 0
   GemmTile t; t.bi = bi; t.bj = bj; t.kbeg = kbeg; t.kend = kend; t.slice = slice; t.pad0 = t.pad1 = t.pad2 = 0; return t;
 }
 
+#ifndef ZIGP_WAVES_DEFAULT
+#define ZIGP_WAVES_DEFAULT 4
+#endif
 constexpr int NST = ZIGP_NSTAGE;   // LDS ring depth of the GEMM core (2 -> 64 KB, 2 workgroups/CU; 3-4 -> 1 workgroup/CU)
+
+// Workgroup shape per operand-layout pair (see Shape<> in zigp_gemm.h): 8 waves where the kernel fits 128 VGPRs
+template <int AL, int BL, bool KS> struct WavesFor { static constexpr int value = ZIGP_WAVES_DEFAULT; };
+#ifndef ZIGP_NO_8WAVE
+template <> struct WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false> { static constexpr int value = 8; };
+#endif
 
 template <int AL, int BL, bool KS, int TRI = TRI_NONE, class EP>
 static int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
+  constexpr int WV = WavesFor<AL, BL, KS>::value;
   if (tl.n == 0) return 0;
   g.tiles = tl.d;
   constexpr size_t shm = sizeof(double) * NST * STAGE_DOUBLES;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
-    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<AL, BL, NST, KS, TRI, EP>),
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<AL, BL, NST, KS, TRI, WV, EP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, KS, TRI, EP>), dim3(tl.n), dim3(GEMM_THREADS), shm, c->stream, g, ep);
+  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, KS, TRI, WV, EP>), dim3(tl.n), dim3(64 * WV), shm, c->stream, g, ep);
   ZIGP_HIP(c, hipGetLastError());
   return 0;
 }
