@@ -84,7 +84,8 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
   ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc);
   ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc);
   ZIGP_ENSURE(c, lt.A2, (size_t)Mp * Nc);
-  ZIGP_ENSURE(c, lt.part, (size_t)2 * MSPLIT * Nc);
+  const int np = Mp / 64;   // partial rows of the fused column sums
+  ZIGP_ENSURE(c, lt.part, (size_t)3 * np * Nc);
   KernHyp hyp = make_hyp(ell_host, lt.var, D);
   {
     ProfScope ps(c, PC_KUF);
@@ -97,12 +98,14 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
   ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu));
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {
-    ProfScope ps(c, PC_GEMM_LO, fl);   // A1 = W K
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), EpiStore())));
+    ProfScope ps(c, PC_GEMM_LO, fl);   // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
+    EpiStoreColsum ep{lt.vec.p, nullptr, lt.part.p, lt.part.p + (size_t)np * Nc};
+    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), ep)));
   }
   {
-    ProfScope ps(c, PC_GEMM_UP, fl);   // A2 = W^T A1
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), EpiStore())));
+    ProfScope ps(c, PC_GEMM_UP, fl);   // A2 = W^T A1 ; partial column sums  sum s^2 A2^2
+    EpiStoreColsum ep{nullptr, lt.s2.p, nullptr, lt.part.p + (size_t)2 * np * Nc};
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), ep)));
   }
   if (need_grad) {
     ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc);
@@ -115,12 +118,6 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
       ProfScope ps(c, PC_GEMM_UP, fl);   // J' = W^T H - A2
       ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.H.p, Nc, lt.Jp.p, Nc), EpiSubLoad{lt.A2.p})));
     }
-  }
-  {
-    ProfScope ps(c, PC_POINT);
-    hipLaunchKernelGGL(k_colred, dim3((unsigned)(Nc / 256), MSPLIT), dim3(256), 0, c->stream, lt.A1.p, lt.A2.p, lt.u.p, lt.s2.p, Mp, Nc,
-                       lt.part.p);
-    ZIGP_HIP(c, hipGetLastError());
   }
   return 0;
 }
@@ -287,7 +284,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
       if (h == 1) ts.second();
       ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], D, jitter, true));
       // v = W u and alpha = W^T v are needed by the KL value AND by the rank-1 parts of the data-term gradient
-      if ((include_kl || need_grad) && !predict) ZIGP_TRY(latent_kl(c, c->lat[h]));
+      ZIGP_TRY(latent_kl(c, c->lat[h]));   // v = W u feeds the fused mean (v^T A1) in every mode
       if (need_grad) ZIGP_TRY(latent_forward_grad(c, c->lat[h]));
     }
     ZIGP_TRY(ts.join());
@@ -324,7 +321,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     {
       ProfScope ps(c, PC_POINT);
       PwArgs a;
-      a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
+      a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 64; a.np_g = c->lat[1].Mp / 64; a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
       a.var_f = p->var_f; a.var_g = p->var_g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
       a.gm_f = need_grad ? c->lat[0].gm.p : nullptr; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
       a.acc = c->pw_part.p; a.out9 = d_out9 ? d_out9 - row_begin : nullptr; a.ld9 = row_end - row_begin;

@@ -110,6 +110,49 @@ struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
   }
 };
 
+// Store + fused column reductions over this wave's 64 rows (GPConditional's reduce_sum over the inducing index,
+// onofftf/main.py:278,287,291,302):   out1[n] = sum_m w1[m] C[m,n]   (skipped if w1 == nullptr)
+//                                      out2[n] = sum_m w2[m] C[m,n]^2 (w2 == nullptr -> weight 1)
+// written to partial row (global row / 64) of out1/out2 (each [Mp/64][ldc]); the point-wise kernel adds the partial
+// rows in index order, so the result does not depend on scheduling.
+struct EpiStoreColsum {
+  const double* __restrict__ w1; const double* __restrict__ w2; double* __restrict__ out1; double* __restrict__ out2;
+  template <int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[4][TN][4], const EpiCtx& e) const {
+    double* __restrict__ C = e.C; const int64_t ld = e.ldc;
+    const int c_i = e.lane >> 4, c_j = e.lane & 15;
+    double s1[TN], s2[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) { s1[tn] = 0.0; s2[tn] = 0.0; }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gi = e.row0 + tm * 16 + 4 * r + c_i;
+        const double a1 = w1 ? w1[gi] : 0.0, a2 = w2 ? w2[gi] : 1.0;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const double v = e.alpha * acc[tm][tn][r];
+          C[gi * ld + e.col0 + tn * 16 + c_j] = v;
+          s1[tn] = fma(a1, v, s1[tn]);
+          s2[tn] = fma(a2 * v, v, s2[tn]);
+        }
+      }
+    const int64_t prow = e.row0 >> 6;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {   // fixed-order combine of the four 16-lane row groups
+      double a = s1[tn], b = s2[tn];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      if (c_i == 0) {
+        const int64_t o = prow * ld + e.col0 + tn * 16 + c_j;
+        if (w1) out1[o] = a;
+        out2[o] = b;
+      }
+    }
+  }
+};
+
 // LDS index (in doubles) of tile element; `mn` = row of A / column of B within the tile, k in [0,16)
 template <int LAY>
 __device__ __forceinline__ int lds_idx(int mn, int k) {

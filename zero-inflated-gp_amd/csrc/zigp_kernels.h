@@ -85,34 +85,13 @@ k_kuf_build(const double* __restrict__ X, int64_t N, int64_t n0, const double* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// Column reductions of one chunk (GPConditional, onofftf/main.py:278,287,291,302):
-//   part[0][ms][n] = sum_{m in split ms} A2[m,n]*u[m]
-//   part[1][ms][n] = sum_{m in split ms} s2[m]*A2[m,n]^2 - A1[m,n]^2
-// grid (Nc/256, MSPLIT)
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_colred(const double* __restrict__ A1, const double* __restrict__ A2, const double* __restrict__ u,
-         const double* __restrict__ s2, int Mp, int64_t Nc, double* __restrict__ part) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int ms = blockIdx.y, mlen = Mp / MSPLIT, mb = ms * mlen;
-  double pm = 0.0, pv = 0.0;
-  for (int m = mb; m < mb + mlen; ++m) {
-    const double a1 = A1[(int64_t)m * Nc + n], a2 = A2[(int64_t)m * Nc + n];
-    pm = fma(a2, u[m], pm);
-    pv = fma(s2[m] * a2, a2, pv);
-    pv = fma(-a1, a1, pv);
-  }
-  part[(int64_t)(0 * MSPLIT + ms) * Nc + n] = pm;
-  part[(int64_t)(1 * MSPLIT + ms) * Nc + n] = pv;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Point-wise stage: probit moments (OnOffSVGP.ProbitExpectations onoffgpf/OnOffSVGP.py:168-204),
 // augmentation (:146-148), expected log-likelihood (OnOffLikelihood.py:30-32) and the hand-derived
 // reverse pass to the cotangents of (fmean, fvar, gmean, gvar) and the noise variance.
 // ---------------------------------------------------------------------------------------------
 struct PwArgs {
-  const double* part_f; const double* part_g;    // [2][MSPLIT][Nc]
+  const double* part_f; const double* part_g;    // per latent [3][NP][Nc]: sum v A1, sum A1^2, sum s2 A2^2 partial rows (EpiStoreColsum)
+  int np_f, np_g;                                 // partial rows per quantity (Mp/64)
   const double* Y; int64_t n0, row_end, Nc;
   double var_f, var_g, noise, g_offset, scale;
   double* gm_f; double* gv_f; double* gm_g; double* gv_g;
@@ -169,14 +148,18 @@ __global__ void __launch_bounds__(PW_THREADS)
 k_pointwise(PwArgs p) {
   __shared__ double sh[4];
   const int64_t n = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
-  double fm = 0.0, fv = p.var_f, gmn = 0.0, gvr = p.var_g;
-#pragma unroll
-  for (int ms = 0; ms < MSPLIT; ++ms) {
-    fm += p.part_f[(int64_t)(0 * MSPLIT + ms) * p.Nc + n];
-    fv += p.part_f[(int64_t)(1 * MSPLIT + ms) * p.Nc + n];
-    gmn += p.part_g[(int64_t)(0 * MSPLIT + ms) * p.Nc + n];
-    gvr += p.part_g[(int64_t)(1 * MSPLIT + ms) * p.Nc + n];
+  double fm = 0.0, fsq = 0.0, fs2 = 0.0, gmn = 0.0, gsq = 0.0, gs2 = 0.0;
+  for (int q = 0; q < p.np_f; ++q) {
+    fm += p.part_f[(int64_t)(0 * p.np_f + q) * p.Nc + n];
+    fsq += p.part_f[(int64_t)(1 * p.np_f + q) * p.Nc + n];
+    fs2 += p.part_f[(int64_t)(2 * p.np_f + q) * p.Nc + n];
   }
+  for (int q = 0; q < p.np_g; ++q) {
+    gmn += p.part_g[(int64_t)(0 * p.np_g + q) * p.Nc + n];
+    gsq += p.part_g[(int64_t)(1 * p.np_g + q) * p.Nc + n];
+    gs2 += p.part_g[(int64_t)(2 * p.np_g + q) * p.Nc + n];
+  }
+  const double fv = p.var_f - fsq + fs2, gvr = p.var_g - gsq + gs2;   // main.py:278,302
   gmn += p.g_offset;
   const bool valid = (p.n0 + n) < p.row_end;
   const double y = (valid && p.Y) ? p.Y[p.n0 + n] : 0.0;
