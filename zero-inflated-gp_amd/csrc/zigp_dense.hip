@@ -28,9 +28,9 @@ struct HostLatent {
   int M; const double *Z, *u, *s, *ell; double var;
 };
 
-// MxM forward for one latent: parameters to device, Kuu, L, W.
-int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double jitter, bool want_W) {
-  ProfScope ps(c, PC_MXM);
+// Parameters of one latent to the device (zero-padded to Mp).  Host->device copies from pageable memory block the
+// host, so they are all issued on the main stream BEFORE the two MxM launch chains fork.
+int latent_upload(zigp_ctx* c, Latent& lt, const HostLatent& h, int D) {
   lt.M = h.M;
   lt.Mp = (int)round_up(h.M, BM);
   lt.var = h.var;
@@ -40,11 +40,20 @@ int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double j
   ZIGP_TRY(upload_padded(c, lt.u, h.u, h.M, Mp));
   ZIGP_TRY(upload_padded(c, lt.s, h.s, h.M, Mp));
   ZIGP_ENSURE(c, lt.s2, Mp);
-  hipLaunchKernelGGL(k_square, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.s.p, lt.s2.p, Mp);
   ZIGP_ENSURE(c, lt.Kuu, (size_t)Mp * Mp);
   ZIGP_ENSURE(c, lt.L, (size_t)Mp * Mp);
   ZIGP_ENSURE(c, lt.W, (size_t)Mp * Mp);
   ZIGP_ENSURE(c, lt.T1, (size_t)Mp * Mp);
+  ZIGP_ENSURE(c, lt.vec, (size_t)4 * Mp + 8);
+  ZIGP_ENSURE(c, lt.Wp, (size_t)Mp * Mp);
+  return 0;
+}
+
+// MxM forward for one latent (kernels only): Kuu, L, W.
+int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double jitter, bool want_W) {
+  ProfScope ps(c, PC_MXM);
+  const int Mp = lt.Mp;
+  hipLaunchKernelGGL(k_square, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.s.p, lt.s2.p, Mp);
   KernHyp hyp = make_hyp(h.ell, h.var, D);
   hipLaunchKernelGGL(k_rbf_matrix, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.Z.p, (int64_t)h.M, lt.Z.p,
                      (int64_t)h.M, hyp, jitter, lt.Kuu.p, (int64_t)Mp, (int64_t)Mp, (int64_t)Mp);
@@ -276,6 +285,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
   const double* ell_h[2] = {p->ell_f, p->ell_g};
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_upload(c, c->lat[h], hl[h], D));
   {
     // MxM forward of f on the main stream and of g on stream2 (dozens of small dependent launches each)
     TwoStream ts(c);
@@ -531,6 +541,7 @@ int zigp_prior_kl(zigp_ctx* c, const zigp_params* p, double jitter, double* kl2)
   ZIGP_HIP(c, hipSetDevice(c->device));
   HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_upload(c, c->lat[h], hl[h], p->D));
   for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], p->D, jitter, true));
   ZIGP_TRY(check_info(c, "Kuu"));
   for (int h = 0; h < 2; ++h) {
