@@ -153,17 +153,20 @@ struct EpiStoreColsum {
   }
 };
 
-// LDS index (in doubles) of tile element; `mn` = row of A / column of B within the tile, k in [0,16)
-template <int LAY>
-__device__ __forceinline__ int lds_idx(int mn, int k) {
-  if (LAY == LAY_KCONTIG) return mn * 16 + 2 * ((k >> 1) ^ ((mn >> 1) & 7)) + (k & 1);
-  return k * LDMN + mn;
+// k-contiguous image swizzle: granule position = (k>>1) ^ kswz(row).  kswz takes 4 distinct values on any 4 consecutive
+// rows 4r..4r+3 (the A-operand broadcast read of one 16-lane group) and 8 distinct values on the even and on the odd
+// rows of any aligned group of 16 (the B-operand read of a 32-lane group): both reads are bank-conflict free.
+// (measured: this map for A tiles, the plain (row>>1)&7 map for B tiles -- the B read of 16 rows per 16-lane group
+// prefers the latter once the compiler pairs reads into ds_read2_b64)
+template <bool NEWMAP> __device__ __forceinline__ int kswz(int row) {
+  return NEWMAP ? ((row & 3) ^ (((row >> 2) & 1) << 2) ^ ((row >> 3) & 1)) : ((row >> 1) & 7);
 }
+
 
 // Staging addresses.  A global_load_lds takes (scalar base) + (32-bit per-lane byte offset): the per-lane offsets of this
 // wave's 16 / GEMM_WAVES chunks are computed ONCE (they do not depend on the BK step), the scalar base advances by a
 // constant each step, and the LDS destination (M0) is scalar arithmetic on the wave id -- no per-step vector address math.
-template <int LAY, int WAVES>
+template <int LAY, int WAVES, bool NEWMAP>
 __device__ __forceinline__ void glds_lane_offsets(uint32_t (&off)[16 / WAVES], int64_t ld, int wave, int lane) {
   constexpr int CHUNKS = 16 / WAVES;
 #pragma unroll
@@ -171,7 +174,7 @@ __device__ __forceinline__ void glds_lane_offsets(uint32_t (&off)[16 / WAVES], i
     const int c = WAVES * p + wave;                     // 1 KB chunk id (0..15)
     if (LAY == LAY_KCONTIG) {                           // chunk = rows 8c..8c+7, lane -> (row, granule position)
       const int row = 8 * c + (lane >> 3), gp = lane & 7;
-      const int g = gp ^ ((row >> 1) & 7);
+      const int g = gp ^ kswz<NEWMAP>(row);
       off[p] = (uint32_t)((row * ld + 2 * g) * 8);
     } else {                                            // chunk = k-row c, lane -> granule
       off[p] = (uint32_t)((c * ld + 2 * lane) * 8);
@@ -189,6 +192,17 @@ __device__ __forceinline__ void glds_tile(double* tile, const char* __restrict__
   }
 }
 
+// LDS offset of the A fragment (tm, r) of k-step ks for this lane (tm, r, ks are compile-time after unrolling)
+template <int ALAY, bool NEWMAP>
+__device__ __forceinline__ int a_read_off(const int (&a_base)[4], int tm, int r, int ks) {
+  if (ALAY == LAY_KCONTIG) {
+    if (!NEWMAP) return a_base[0] + (tm * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r));   // (row>>1)&7 map: fully separable
+    const int X = (2 * ks) ^ (4 * (r & 1) + (r >> 1));
+    return a_base[X & 3] + (tm * 16 + 4 * r) * 16 + 2 * (X & ~3);
+  }
+  return a_base[0] + ks * 4 * LDMN + tm * 16 + 4 * r;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // TRI: triangular structure exploited at wave (64-row) granularity inside diagonal blocks
@@ -202,6 +216,8 @@ template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, int WAVES, class
 __global__ void __launch_bounds__(64 * WAVES, ((NSTAGE <= 2) ? 2 : 1) * WAVES / 4)
 gemm_f64_kernel(GemmArgs g, Epi epi) {
   constexpr int WNW = Shape<WAVES>::WNW, WTN = Shape<WAVES>::WTN, TNW = Shape<WAVES>::TNW, CHUNKS = Shape<WAVES>::CHUNKS;
+  // the 4-base A map costs 3 VGPRs more: used where the B tile is m/n-contiguous (1 base register), not in the K/K kernels
+  constexpr bool A_NEWMAP = (BLAY == LAY_MNCONTIG);
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
   const GemmTile tl = g.tiles[blockIdx.x];
   const int t = threadIdx.x, lane = t & 63;
@@ -220,8 +236,8 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   const int total = tl.kend - tl.kbeg;       // BK steps of this tile
   const GemmSeg& sg = g.seg[0];
   uint32_t offA[CHUNKS], offB[CHUNKS];
-  glds_lane_offsets<ALAY, WAVES>(offA, sg.lda, wave, lane);
-  glds_lane_offsets<BLAY, WAVES>(offB, sg.ldb, wave, lane);
+  glds_lane_offsets<ALAY, WAVES, A_NEWMAP>(offA, sg.lda, wave, lane);
+  glds_lane_offsets<BLAY, WAVES, false>(offB, sg.ldb, wave, lane);
   // scalar bases of BK step 0 and their per-step strides (bytes)
   const int64_t kfirst = (int64_t)tl.kbeg * BK;
   const char* baseA = (const char*)(sg.A + ((ALAY == LAY_KCONTIG) ? row0 * sg.lda + kfirst : kfirst * sg.lda + row0));
@@ -248,12 +264,18 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
 
   const int a_i = lane & 3, kq = lane >> 4, b_j = lane & 15;
   // per-lane LDS read bases; the (tm, r, tn, ks) parts are compile-time offsets (see header comment)
-  const int a_base = (ALAY == LAY_KCONTIG) ? ((wm * 64 + a_i) * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1))
-                                           : (kq * LDMN + wm * 64 + a_i);
+  // k-contiguous A: granule = (2ks | kq>>1) ^ a_i ^ C(r), C(r) = 4(r&1) + (r>>1)  ->  [(2ks ^ C(r)) & ~3] is a compile-time
+  // offset and the low two bits select one of four per-lane bases a_base[x] = ... + 2*((a_i ^ (kq>>1)) ^ x)
+  int a_base[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+    a_base[x] = (ALAY == LAY_KCONTIG) ? (A_NEWMAP ? ((wm * 64 + a_i) * 16 + 2 * ((a_i ^ (kq >> 1)) ^ x) + (kq & 1))
+                                                    : ((wm * 64 + a_i) * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1)))
+                                      : (kq * LDMN + wm * 64 + a_i);
   int b_base[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
-    b_base[ks] = (BLAY == LAY_KCONTIG) ? ((wn * WTN + b_j) * 16 + 2 * (((2 * ks) | (kq >> 1)) ^ (b_j >> 1)) + (kq & 1))
+    b_base[ks] = (BLAY == LAY_KCONTIG) ? ((wn * WTN + b_j) * 16 + 2 * (((2 * ks) | (kq >> 1)) ^ kswz<false>(b_j)) + (kq & 1))
                                        : (kq * LDMN + wn * WTN + b_j + ks * 4 * LDMN);
   for (int it = 0; it < total; ++it) {
     // stage `it` must have landed: at most NSTAGE-2 younger stages (8 glds each) may stay in flight
@@ -290,8 +312,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
           for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              af[tm][r] = As[a_base + ((ALAY == LAY_KCONTIG) ? ((tm * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r)))
-                                                               : (ks * 4 * LDMN + tm * 16 + 4 * r))];
+              af[tm][r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
 #pragma unroll
           for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -306,8 +327,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
             double af[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              af[r] = As[a_base + ((ALAY == LAY_KCONTIG) ? ((tm * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r)))
-                                                           : (ks * 4 * LDMN + tm * 16 + 4 * r))];
+              af[r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
 #pragma unroll
             for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
