@@ -62,6 +62,7 @@ def main():
     ap.add_argument('--D', type=int, default=3)
     ap.add_argument('--chunk', type=int, default=32768)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL, the default) or 'gloo' to rehearse the multi-rank path on fewer GPUs than ranks")
     ap.add_argument('--cpu-sample-rows', type=int, default=60000)
     args = ap.parse_args()
 
@@ -70,10 +71,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = local_rank % ndev          # gloo rehearsal may put several ranks on one GPU
     if world > 1:
         import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        torch.cuda.set_device(dev)
+        if args.backend == 'nccl':
+            dist_mod.init_process_group(backend='nccl', device_id=torch.device('cuda', dev))
+        else:
+            dist_mod.init_process_group(backend=args.backend)
         dist = dist_mod
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
 
@@ -81,12 +87,13 @@ def main():
     from zigp.parallel import ShardedELBO
     N, M, D, jitter = args.rows, args.M, args.D, 1e-6
     X, Y, p = synth(N, M, D, rank)
-    eng = zigp.DenseEngine(local_rank)        # raises if libzigp.so is missing: no CPU fallback
+    eng = zigp.DenseEngine(dev)               # raises if libzigp.so is missing: no CPU fallback
     eng.set_chunk(args.chunk)
-    Xd = torch.from_numpy(X).to('cuda:%d' % local_rank)
-    Yd = torch.from_numpy(Y).to('cuda:%d' % local_rank)
+    Xd = torch.from_numpy(X).to('cuda:%d' % dev)
+    Yd = torch.from_numpy(Y).to('cuda:%d' % dev)
     eng.set_data_device(Xd, Yd)               # inputs resident in HBM before timing
-    sh = ShardedELBO(eng, dist, device='cuda:%d' % local_rank)
+    red_dev = ('cuda:%d' % dev) if args.backend == 'nccl' else 'cpu'
+    sh = ShardedELBO(eng, dist, device=red_dev)
     scale = 1.0
 
     def barrier():
@@ -108,7 +115,7 @@ def main():
     prof = eng.profile_get()
     eng.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda:%d' % local_rank)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     elbo_gpu = out[0] - out[1]
@@ -116,12 +123,15 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * args.steps / dt * (N / 1e6)
-        gk = prof['gemm_lower']     # dominant kernel: gemm_f64_kernel<KCONTIG,MNCONTIG,2,false,TRI_A_LOWER,EpiStore> (A1 and H products)
+        from zigp._lib import PROF_KERNELS
+        gemm_classes = ('gemm_A1', 'gemm_A2', 'gemm_H', 'gemm_J', 'syrk')
+        dom = max(gemm_classes, key=lambda k: prof[k]['ms'])          # dominant kernel = largest share of the timed region
+        gk = prof[dom]
         avg_launch_s = gk['ms'] * 1e-3 / max(gk['launches'], 1)
         flops_per_launch = gk['flops'] / max(gk['launches'], 1)     # algorithmic, triangle-aware: M^2 * chunk_rows
         achieved = flops_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
-        gemm_ms = sum(prof[k]['ms'] for k in ('gemm_lower', 'gemm_upper', 'syrk'))
-        gemm_fl = sum(prof[k]['flops'] for k in ('gemm_lower', 'gemm_upper', 'syrk'))
+        gemm_ms = sum(prof[k]['ms'] for k in gemm_classes)
+        gemm_fl = sum(prof[k]['flops'] for k in gemm_classes)
         res = {
             'metric': 'elbo_steps_per_sec', 'value': value, 'unit': 'ELBO steps/s (value+gradient, 1e6-row steps, fp64)',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -132,7 +142,8 @@ def main():
             'elbo': elbo_gpu,
             'roofline': {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': PEAK_FP64_MFMA / 1e12, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP64_MFMA, 'traffic': None,
-                         'kernel': 'gemm_f64_kernel<0,1,2,false,1,EpiStore> (A1 = W K and H = W diag(s^2) A2)',
+                         'kernel': PROF_KERNELS[dom],
+                         'per_kernel_tflops': {k: (prof[k]['flops'] / (prof[k]['ms'] * 1e-3) / 1e12 if prof[k]['ms'] > 0 else 0.0) for k in gemm_classes},
                          'flops_per_launch': flops_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
                          'all_gemm_tflops': gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
                          # whole step against the same peak: flops this engine's algorithm needs (10 M^2 N: four

@@ -128,12 +128,15 @@ int zigp_kron_predict(zigp_ctx* ctx, const zigp_kron_params* p, const double* Xn
 
 /* ---- measurement hooks (bench.py) ---- */
 /* Accumulated HIP-event time (ms), launch count and algorithmic flops per kernel class since the last reset,
- * measured with HIP events on the stream the kernels run on.  Classes:
- * 0 gemm_lower  (A1 = W K and H = W diag(s^2) A2: gemm_f64_kernel<KCONTIG,MNCONTIG,..,TRI_A_LOWER,EpiStore>)
- * 1 gemm_upper  (A2 = W^T A1 and J' = W^T H - A2: gemm_f64_kernel<MNCONTIG,MNCONTIG,..,TRI_A_UPPER,..>)
- * 2 syrk        (gv-weighted symmetric rank-N update C1 += A1 G A1^T)
- * 3 kuf_build   4 colred+pointwise   5 kgrad   6 MxM stage (all kernels)   7 everything else. */
-#define ZIGP_NCLASS 8
+ * measured with HIP events on the stream the kernels run on.  Classes (gemm_f64_kernel template arguments are
+ * <A layout, B layout, ring stages, k-scale, triangular mode, waves, epilogue>):
+ * 0 gemm_A1  A1 = W K            gemm_f64_kernel<0,1,2,false,1,4,EpiStoreColsum>
+ * 1 gemm_A2  A2 = W^T A1         gemm_f64_kernel<1,1,2,false,2,8,EpiStoreColsum>
+ * 2 gemm_H   H = W diag(s^2) A2  gemm_f64_kernel<0,1,2,false,1,4,EpiStore>
+ * 3 gemm_J   J' = W^T H - A2     gemm_f64_kernel<1,1,2,false,2,8,EpiSubLoad>
+ * 4 syrk     C1 += A1 G A1^T     gemm_f64_kernel<0,0,2,true,3,4,EpiAccum>
+ * 5 kuf_build   6 pointwise   7 kgrad   8 MxM stage (all kernels)   9 everything else. */
+#define ZIGP_NCLASS 10
 int zigp_profile_enable(zigp_ctx* ctx, int32_t on);
 int zigp_profile_get(zigp_ctx* ctx, double* ms /*[ZIGP_NCLASS]*/, int64_t* launches /*[ZIGP_NCLASS]*/,
                      double* flops /*[ZIGP_NCLASS] algorithmic*/);

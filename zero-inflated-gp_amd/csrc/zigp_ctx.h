@@ -27,7 +27,7 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-enum ProfClass { PC_GEMM_LO = 0, PC_GEMM_UP = 1, PC_SYR2K = 2, PC_KUF = 3, PC_POINT = 4, PC_RED = 5, PC_MXM = 6, PC_OTHER = 7 };
+enum ProfClass { PC_GEMM_A1 = 0, PC_GEMM_A2 = 1, PC_GEMM_H = 2, PC_GEMM_J = 3, PC_SYR2K = 4, PC_KUF = 5, PC_POINT = 6, PC_RED = 7, PC_MXM = 8, PC_OTHER = 9 };
 
 struct TileList {
   GemmTile* d = nullptr;

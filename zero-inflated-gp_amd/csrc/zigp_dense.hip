@@ -107,12 +107,12 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
   ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu));
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {
-    ProfScope ps(c, PC_GEMM_LO, fl);   // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
+    ProfScope ps(c, PC_GEMM_A1, fl);   // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
     EpiStoreColsum ep{lt.vec.p, nullptr, lt.part.p, lt.part.p + (size_t)np * Nc};
     ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), ep)));
   }
   {
-    ProfScope ps(c, PC_GEMM_UP, fl);   // A2 = W^T A1 ; partial column sums  sum s^2 A2^2
+    ProfScope ps(c, PC_GEMM_A2, fl);   // A2 = W^T A1 ; partial column sums  sum s^2 A2^2
     EpiStoreColsum ep{nullptr, lt.s2.p, nullptr, lt.part.p + (size_t)2 * np * Nc};
     ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), ep)));
   }
@@ -120,11 +120,11 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
     ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc);
     ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc);
     {
-      ProfScope ps(c, PC_GEMM_LO, fl);   // H = (W diag(s^2)) A2
+      ProfScope ps(c, PC_GEMM_H, fl);   // H = (W diag(s^2)) A2
       ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wp.p, Mp, lt.A2.p, Nc, lt.H.p, Nc), EpiStore())));
     }
     {
-      ProfScope ps(c, PC_GEMM_UP, fl);   // J' = W^T H - A2
+      ProfScope ps(c, PC_GEMM_J, fl);   // J' = W^T H - A2
       ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.H.p, Nc, lt.Jp.p, Nc), EpiSubLoad{lt.A2.p})));
     }
   }

@@ -8,8 +8,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(ROOT, 'lib', 'libzigp.so')
 
 ZIGP_OK, ZIGP_EARG, ZIGP_EHIP, ZIGP_ENOTPD = 0, -1, -2, -3
-NCLASS = 8
-PROF_CLASSES = ('gemm_lower', 'gemm_upper', 'syrk', 'kuf_build', 'colred_pointwise', 'kgrad', 'mxm_stage', 'other')
+NCLASS = 10
+PROF_CLASSES = ('gemm_A1', 'gemm_A2', 'gemm_H', 'gemm_J', 'syrk', 'kuf_build', 'pointwise', 'kgrad', 'mxm_stage', 'other')
+PROF_KERNELS = {'gemm_A1': 'gemm_f64_kernel<0,1,2,false,1,4,EpiStoreColsum> (A1 = W K)',
+                'gemm_A2': 'gemm_f64_kernel<1,1,2,false,2,8,EpiStoreColsum> (A2 = W^T A1)',
+                'gemm_H': 'gemm_f64_kernel<0,1,2,false,1,4,EpiStore> (H = W diag(s^2) A2)',
+                'gemm_J': 'gemm_f64_kernel<1,1,2,false,2,8,EpiSubLoad> (J\' = W^T H - A2)',
+                'syrk': 'gemm_f64_kernel<0,0,2,true,3,4,EpiAccum> (C1 += A1 G A1^T)'}
 
 dp = C.POINTER(C.c_double)
 
