@@ -132,6 +132,20 @@ def main():
         achieved = flops_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
         gemm_ms = sum(prof[k]['ms'] for k in gemm_classes)
         gemm_fl = sum(prof[k]['flops'] for k in gemm_classes)
+        # HBM traffic per launch of the dominant kernel: from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        # (tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950 correction).  Per-launch traffic depends on (M, chunk)
+        # only, so the summary collected at this chunk size applies; null when it is missing or the shape differs.
+        traffic = None
+        try:
+            if (M, args.chunk, D) == (1024, 32768, 3):
+                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01c_pmc_hbm_traffic.json')))
+                sym = PROF_KERNELS[dom].split('>')[0].replace('gemm_f64_kernel<', '').split(',')
+                for name, v in tr.items():
+                    args_ = name.split('gemm_f64_kernel<')[-1].split('>')[0].replace(' ', '').split(',') if 'gemm_f64_kernel<' in name else []
+                    if len(args_) >= 7 and args_[:6] == sym[:6] and args_[6].endswith(sym[6]) and v['launches'] >= 8:
+                        traffic = v['hbm_bytes_per_launch_corrected']
+        except Exception:
+            traffic = None
         res = {
             'metric': 'elbo_steps_per_sec', 'value': value, 'unit': 'ELBO steps/s (value+gradient, 1e6-row steps, fp64)',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -141,7 +155,7 @@ def main():
                        'parallelism': 'row-shard x%d, 1 all-reduce/step' % world},
             'elbo': elbo_gpu,
             'roofline': {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': PEAK_FP64_MFMA / 1e12, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP64_MFMA, 'traffic': None,
+                         'frac': achieved / PEAK_FP64_MFMA, 'traffic': traffic,
                          'kernel': PROF_KERNELS[dom],
                          'per_kernel_tflops': {k: (prof[k]['flops'] / (prof[k]['ms'] * 1e-3) / 1e12 if prof[k]['ms'] > 0 else 0.0) for k in gemm_classes},
                          'flops_per_launch': flops_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
