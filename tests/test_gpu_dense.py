@@ -172,3 +172,37 @@ def test_ill_conditioned_accuracy_vs_extended_precision(engine):
     e_gpu_v, e_orc_v = relerr(out[4], tv.astype(np.float64)), relerr(ref[4].reshape(-1), tv.astype(np.float64))
     print('fmean: gpu %.2e oracle %.2e ; fvar: gpu %.2e oracle %.2e' % (e_gpu_m, e_orc_m, e_gpu_v, e_orc_v))
     assert e_gpu_m < 10 * e_orc_m + 1e-9 and e_gpu_v < 10 * e_orc_v + 1e-9
+
+
+def test_wide_input_dimension_and_large_M(engine):
+    """D = 5 (ARD) and M = 1100 (nine 128-blocks, ragged) against the oracle."""
+    import zigp_oracle_torch as ot
+    for (N, M, D, ell) in ((1200, 70, 5, 0.8), (1300, 1100, 3, 0.12)):
+        X, Y, p = make_problem(N, M, D, seed=N + D, ell=ell, u_scale=0.1)
+        engine.set_chunk(32768)
+        engine.set_data(X, Y)
+        ed, kl, g = engine.elbo(p, jitter=1e-6)
+        e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X, Y, p, 1e-6, chunk=700)
+        c = _cond(p, 1e-6)
+        print('N=%d M=%d D=%d cond %.1e elbo rel %.1e' % (N, M, D, c, abs((ed - kl) - e_r) / abs(e_r)))
+        assert abs((ed - kl) - e_r) <= 1e-7 * abs(e_r)
+        for k in ot.PARAM_KEYS:
+            a, b = np.asarray(g[k]).reshape(-1), np.asarray(g_r[k]).reshape(-1)
+            assert np.max(np.abs(a - b)) <= max(1e-6, 1e-13 * c) * max(np.max(np.abs(b)), 1e-300), k
+
+
+def test_empty_row_range_gives_minus_kl_gradient(engine):
+    """rows = (k, k): no data term; ELBO = -KL and the gradient is -dKL (what a rank without rows contributes)."""
+    import zigp_oracle_torch as ot
+    X, Y, p = make_problem(600, 40, 3, seed=8)
+    engine.set_data(X, Y)
+    ed, kl, g = engine.elbo(p, rows=(100, 100))
+    assert ed == 0.0
+    P = ot.make_leaves(p)
+    k = ot.prior_kl(P, 1e-6)
+    (-k).backward()
+    assert abs(kl - float(k.detach())) <= 1e-9 * abs(kl)
+    for key in ('Zf', 'u_fm', 'u_gs_sqrt', 'ell_g', 'var_f'):
+        a, b = np.asarray(g[key]).reshape(-1), P[key].grad.numpy().reshape(-1)
+        assert np.max(np.abs(a - b)) <= 1e-7 * max(np.max(np.abs(b)), 1e-300), key
+    assert g['noise'] == 0.0

@@ -96,12 +96,21 @@ static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl) {
       for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * (BM / BK), nbm * (BM / BK)));
   }, tl);
 }
-// lower-triangular output tiles x S split-K slices over nk k-steps
+// lower-triangular output tiles x S split-K slices over nk k-steps.  Launch position p runs on XCD p % 8 (observed round-robin
+// dispatch; speed only): XCD x is handed a contiguous run of the slice-major tile order, so the tiles that re-read the same
+// column slice of the panels share one L2 instead of eight.
 static int tiles_syr2k(zigp_ctx* c, int nbm, int nk, int S, TileList& tl) {
   return get_tiles(c, "syr:" + std::to_string(nbm) + ":" + std::to_string(nk) + ":" + std::to_string(S), [&](std::vector<GemmTile>& v) {
+    std::vector<GemmTile> t;
     for (int s = 0; s < S; ++s)
       for (int bi = 0; bi < nbm; ++bi)
-        for (int bj = 0; bj <= bi; ++bj) v.push_back(mk_tile(bi, bj, (int)((int64_t)nk * s / S), (int)((int64_t)nk * (s + 1) / S), s));
+        for (int bj = 0; bj <= bi; ++bj) t.push_back(mk_tile(bi, bj, (int)((int64_t)nk * s / S), (int)((int64_t)nk * (s + 1) / S), s));
+    const int n = (int)t.size(), per = (n + 7) / 8;
+    v.reserve(n);
+    for (int p = 0; (int)v.size() < n; ++p) {
+      const int idx = per * (p % 8) + p / 8;
+      if (p / 8 < per && idx < n) v.push_back(t[idx]);
+    }
   }, tl);
 }
 static int tiles_full(zigp_ctx* c, int nbm, int nbn, int nk, TileList& tl) {
