@@ -89,6 +89,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ZigpError('libzigp.so not found at %s: build it first (python __graft_entry__.py / zigp.build.build()). '
                         'This engine has no CPU fallback.' % LIB_PATH)
+    # PyTorch wheels bundle their own libamdhip64; a process must not end up with two HIP runtimes (the second one sees
+    # no GPUs).  Loading torch's copy first lets libzigp.so bind to the same runtime, so engine buffers and torch tensors
+    # (zigp_set_data_device, the all-reduce buffer) live in one context.  Without torch the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
