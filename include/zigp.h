@@ -141,6 +141,9 @@ int zigp_profile_enable(zigp_ctx* ctx, int32_t on);
 int zigp_profile_get(zigp_ctx* ctx, double* ms /*[ZIGP_NCLASS]*/, int64_t* launches /*[ZIGP_NCLASS]*/,
                      double* flops /*[ZIGP_NCLASS] algorithmic*/);
 int zigp_profile_reset(zigp_ctx* ctx);
+/* Event pairs cost ~10 us each, so launches of the chunk loop are TIMED on every 4th full-size chunk only (ms / launches /
+ * flops above describe those sampled launches); zigp_profile_totals returns the number of launches per class, sampled or not. */
+int zigp_profile_totals(zigp_ctx* ctx, int64_t* total_launches /*[ZIGP_NCLASS]*/);
 
 /* ---- diagnostics used by the parity tests (building blocks through the same kernels) ---- */
 /* C (m,n) = op(A) * op(B) with the fp64 MFMA GEMM core; transA/transB as BLAS; all dims padded internally. */

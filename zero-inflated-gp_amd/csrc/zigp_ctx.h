@@ -78,6 +78,9 @@ struct zigp_ctx {
   std::map<std::string, zigp::TileList> tiles;
   // profiling
   bool prof_on = false;
+  int prof_every = 4;                    // chunk-loop launches are timed on every prof_every-th chunk (event pairs cost ~10 us)
+  bool prof_skip = false;                // set by the chunk loop for the chunks that are not sampled
+  int64_t prof_total[ZIGP_NCLASS] = {0}; // all launches per class, sampled or not
   double prof_ms[ZIGP_NCLASS] = {0};
   int64_t prof_n[ZIGP_NCLASS] = {0};
   double prof_flops[ZIGP_NCLASS] = {0};
@@ -146,6 +149,8 @@ struct ProfScope {
   }
   ProfScope(zigp_ctx* c_, int cls_, double flops = 0.0) : c(c_), cls(cls_), on(c_->prof_on) {
     if (!on) return;
+    c->prof_total[cls] += 1;
+    if (c->prof_skip) { on = false; return; }
     a = get_ev(c); b = get_ev(c);
     if (!a || !b) { on = false; return; }
     (void)hipEventRecord(a, c->stream);

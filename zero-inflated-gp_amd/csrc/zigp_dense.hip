@@ -327,6 +327,8 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc_full) {
     // the last (partial) chunk shrinks to the next multiple of 1024 rows
     Nc = std::min<int64_t>(Nc_full, round_up(row_end - n0, 1024));
+    // kernel timing (HIP events) samples every prof_every-th FULL chunk, so the averages describe full-size launches
+    c->prof_skip = c->prof_on && (Nc != Nc_full || (((n0 - row_begin) / Nc_full) % c->prof_every) != 0) && (row_end - row_begin > Nc_full);
     for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], dX, Nrows, n0, Nc, D, ell_h[h], need_grad));
     {
       ProfScope ps(c, PC_POINT);
@@ -343,6 +345,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     if (need_grad)
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_backward(c, c->lat[h], dX, Nrows, n0, Nc, D));
   }
+  c->prof_skip = false;
   if (predict) { ZIGP_HIP(c, hipStreamSynchronize(c->stream)); prof_collect(c); return 0; }
   if (need_grad)
   {
@@ -576,13 +579,18 @@ int zigp_profile_enable(zigp_ctx* c, int32_t on) { if (!c) return ZIGP_EARG; c->
 int zigp_profile_reset(zigp_ctx* c) {
   if (!c) return ZIGP_EARG;
   prof_collect(c);
-  for (int i = 0; i < ZIGP_NCLASS; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; c->prof_flops[i] = 0; }
+  for (int i = 0; i < ZIGP_NCLASS; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; c->prof_flops[i] = 0; c->prof_total[i] = 0; }
   return ZIGP_OK;
 }
 int zigp_profile_get(zigp_ctx* c, double* ms, int64_t* launches, double* flops) {
   if (!c) return ZIGP_EARG;
   prof_collect(c);
   for (int i = 0; i < ZIGP_NCLASS; ++i) { if (ms) ms[i] = c->prof_ms[i]; if (launches) launches[i] = c->prof_n[i]; if (flops) flops[i] = c->prof_flops[i]; }
+  return ZIGP_OK;
+}
+int zigp_profile_totals(zigp_ctx* c, int64_t* total_launches) {
+  if (!c || !total_launches) return ZIGP_EARG;
+  for (int i = 0; i < ZIGP_NCLASS; ++i) total_launches[i] = c->prof_total[i];
   return ZIGP_OK;
 }
 

@@ -248,8 +248,13 @@ class DenseEngine:
         ms = np.zeros(_lib.NCLASS)
         n = np.zeros(_lib.NCLASS, dtype=np.int64)
         fl = np.zeros(_lib.NCLASS)
+        tot = np.zeros(_lib.NCLASS, dtype=np.int64)
         _check(self.lib, self.ctx, self.lib.zigp_profile_get(self.ctx, ptr(ms), n.ctypes.data_as(C.POINTER(C.c_int64)), ptr(fl)))
-        return {name: dict(ms=float(ms[i]), launches=int(n[i]), flops=float(fl[i])) for i, name in enumerate(_lib.PROF_CLASSES)}
+        _check(self.lib, self.ctx, self.lib.zigp_profile_totals(self.ctx, tot.ctypes.data_as(C.POINTER(C.c_int64))))
+        # ms / launches / flops: the TIMED (sampled) launches; total_launches: all of them; est_total_ms = avg * total
+        return {name: dict(ms=float(ms[i]), launches=int(n[i]), flops=float(fl[i]), total_launches=int(tot[i]),
+                           est_total_ms=float(ms[i]) / max(int(n[i]), 1) * int(tot[i]))
+                for i, name in enumerate(_lib.PROF_CLASSES)}
 
     # ---- diagnostics ----
     def test_gemm(self, A, B, transA=False, transB=False):
