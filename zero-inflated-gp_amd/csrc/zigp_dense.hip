@@ -465,7 +465,7 @@ int zigp_destroy(zigp_ctx* c) {
                     &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec};
     for (DevBuf* b : bs) b->release();
   }
-  DevBuf* bs[] = {&c->ownX, &c->ownY, &c->E, &c->dA1, &c->F, &c->pw_part, &c->out9, &c->scratch, &c->scratch2};
+  DevBuf* bs[] = {&c->ownX, &c->ownY, &c->pw_part, &c->out9, &c->scratch, &c->scratch2};
   for (DevBuf* b : bs) b->release();
   if (c->kron && c->kron_free) c->kron_free(c->kron);
   for (auto& kv : c->tiles) if (kv.second.d) (void)hipFree(kv.second.d);

@@ -56,11 +56,10 @@ struct GemmTile {
   int pad0, pad1, pad2;
 };
 
-struct GemmSeg { const double* A; const double* B; int64_t lda, ldb; };
+struct GemmSeg { const double* A; const double* B; int64_t lda, ldb; };   // one operand pair
 
 struct GemmArgs {
-  GemmSeg seg[2];   // only seg[0] is used (one operand pair per launch)
-  int nseg;
+  GemmSeg seg[1];
   const GemmTile* tiles;
   double* C; int64_t ldc; int64_t slice_stride;  // C plane stride for split-K partials
   double alpha;

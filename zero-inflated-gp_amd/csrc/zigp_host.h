@@ -74,8 +74,7 @@ static int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
 static inline GemmArgs mk_args(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha = 1.0) {
   GemmArgs g;
   g.seg[0].A = A; g.seg[0].B = B; g.seg[0].lda = lda; g.seg[0].ldb = ldb;
-  g.seg[1] = g.seg[0];
-  g.nseg = 1; g.tiles = nullptr; g.C = C; g.ldc = ldc; g.slice_stride = 0; g.alpha = alpha; g.kscale = nullptr;
+  g.tiles = nullptr; g.C = C; g.ldc = ldc; g.slice_stride = 0; g.alpha = alpha; g.kscale = nullptr;
   return g;
 }
 

@@ -8,7 +8,6 @@
 namespace zigp {
 
 constexpr int MAXD = 8;       // max input dimension handled by the fused kernels
-constexpr int MSPLIT = 8;     // m-splits of the column reduction
 constexpr int PW_THREADS = 256;
 
 struct KernHyp { double inv_ell[MAXD]; double var; int D; };
@@ -399,10 +398,6 @@ k_kl_value(const double* __restrict__ v, const double* __restrict__ L, const dou
   if (threadIdx.x == 0) out[0] = 0.5 * (mah - (double)M - lq + tr + lp);
 }
 
-__global__ void k_fill(double* p, int64_t n, double v) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
 // s2 = s*s
 __global__ void k_square(const double* s, double* s2, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

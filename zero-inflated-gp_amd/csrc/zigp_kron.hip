@@ -37,6 +37,7 @@ struct KronLatent {
 struct KronState {
   KronLatent lat[2];
   DevBuf X, Y, acc, out9;
+  std::vector<std::vector<double>> stage;   // host images of the padded (M0q x M1q) grids; alive until the step's final sync
 };
 
 static void kron_free(KronState* k) {
@@ -343,12 +344,12 @@ int factor_forward(zigp_ctx* c, KronFactor& f, int M, int D, int col0, const dou
 }
 
 int upload_grid(zigp_ctx* c, DevBuf& b, const double* src, int M0, int M1, int Mq0, int Mq1, bool square) {
-  std::vector<double> h((size_t)Mq0 * Mq1, 0.0);
+  c->kron->stage.emplace_back((size_t)Mq0 * Mq1, 0.0);
+  std::vector<double>& h = c->kron->stage.back();
   for (int i = 0; i < M0; ++i)
     for (int j = 0; j < M1; ++j) { const double v = src[(size_t)i * M1 + j]; h[(size_t)i * Mq1 + j] = square ? v * v : v; }
   ZIGP_ENSURE(c, b, h.size());
   ZIGP_HIP(c, hipMemcpyAsync(b.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
-  ZIGP_HIP(c, hipStreamSynchronize(c->stream));   // h goes out of scope
   return 0;
 }
 
@@ -476,6 +477,7 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
              double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads) {
   if (!c->kron) { c->kron = new (std::nothrow) KronState(); c->kron_free = kron_free; if (!c->kron) { c->err = "out of memory"; return ZIGP_EHIP; } }
   KronState& ks = *c->kron;
+  ks.stage.clear();   // every call ends with a stream synchronisation, so the previous step's images are no longer in flight
   const bool need_grad = grads != nullptr && !predict;
   const int D0 = p->D0, D1 = p->D1, ldx = D0 + D1;
   const int64_t Nc = std::max<int64_t>(1024, round_up(N, 1024));
