@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, 'lib', 'libzigp.so')
+LIB_PATH = os.environ.get('ZIGP_LIB') or os.path.join(ROOT, 'lib', 'libzigp.so')   # ZIGP_LIB: A/B builds on one GPU box
 
 ZIGP_OK, ZIGP_EARG, ZIGP_EHIP, ZIGP_ENOTPD = 0, -1, -2, -3
 NCLASS = 10
