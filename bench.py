@@ -146,6 +146,20 @@ def main():
                         traffic = v['hbm_bytes_per_launch_corrected']
         except Exception:
             traffic = None
+        # HBM-bound side kernels: algorithmic bytes / measured average launch time
+        Mp = (M + 127) // 128 * 128
+        panel = 8.0 * Mp * args.chunk
+        hbm = {}
+        for k, nbytes in (('kgrad', 2 * panel), ('kuf_build', panel)):
+            if prof[k]['launches'] > 0 and prof[k]['ms'] > 0:
+                hbm[k] = {'GBps': nbytes / (prof[k]['ms'] * 1e-3 / prof[k]['launches']) / 1e9, 'bytes_per_launch': nbytes}
+        mfma_util = None
+        try:
+            mu = json.load(open(os.path.join(ROOT, 'profiles', 'r01c_pmc_mfma_util.json')))
+            mfma_util = {k.split('gemm_f64_kernel')[-1].split('(')[0]: round(v['mfma_busy_frac_of_simd_cycles'], 3)
+                         for k, v in mu.items() if v['launches'] >= 8 and v['avg_us_under_pmc'] > 300}
+        except Exception:
+            pass
         res = {
             'metric': 'elbo_steps_per_sec', 'value': value, 'unit': 'ELBO steps/s (value+gradient, 1e6-row steps, fp64)',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -165,6 +179,7 @@ def main():
                          # 12 M^2 N of the literal reverse pass it replaces
                          'step_frac_10M2N': (10.0 * M * M * N / (dt / args.steps)) / PEAK_FP64_MFMA,
                          'step_frac_12M2N_literal': (12.0 * M * M * N / (dt / args.steps)) / PEAK_FP64_MFMA},
+            'hbm_bound_kernels': hbm, 'mfma_busy_pmc': mfma_util,
             'kernel_ms_per_step': {k: v['est_total_ms'] / args.steps for k, v in prof.items()},   # avg of the timed launches x all launches
         }
         if not args.no_cpu_baseline and world == 1:
