@@ -485,6 +485,7 @@ int zigp_last_info(zigp_ctx* c) { return c ? c->info : 0; }
 int zigp_set_chunk(zigp_ctx* c, int64_t chunk_rows) {
   if (!c) return ZIGP_EARG;
   if (chunk_rows < 1024 || chunk_rows % 1024 != 0) return fail_arg(c, "chunk must be a positive multiple of 1024");
+  if (chunk_rows > (1 << 20)) return fail_arg(c, "chunk must be <= 1048576 rows (32-bit staging offsets; 5 panels of 8*M*chunk bytes per latent)");
   c->chunk = chunk_rows;
   return ZIGP_OK;
 }
