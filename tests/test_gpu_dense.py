@@ -129,6 +129,11 @@ def test_bad_arguments(engine):
         engine.elbo(q)
     with pytest.raises(ValueError):
         engine.elbo(p, rows=(0, 101))
+    q = dict(p)
+    q['u_fs_sqrt'] = p['u_fs_sqrt'].copy()
+    q['u_fs_sqrt'][3] = 0.0
+    with pytest.raises(ValueError):
+        engine.elbo(q)
     with pytest.raises(ValueError):
         engine.set_chunk(1000)
 

@@ -273,6 +273,10 @@ int validate_params(zigp_ctx* c, const zigp_params* p) {
   if (!(p->var_f > 0) || !(p->var_g > 0) || !(p->noise > 0)) return fail_arg(c, "variances must be positive");
   for (int d = 0; d < p->D; ++d)
     if (!(p->ell_f[d] > 0) || !(p->ell_g[d] > 0)) return fail_arg(c, "lengthscales must be positive");
+  for (int m = 0; m < p->Mf; ++m)
+    if (!(p->u_fs_sqrt[m] > 0)) return fail_arg(c, "u_fs_sqrt must be positive (diagonal q_sqrt, transforms.positive)");
+  for (int m = 0; m < p->Mg; ++m)
+    if (!(p->u_gs_sqrt[m] > 0)) return fail_arg(c, "u_gs_sqrt must be positive (diagonal q_sqrt, transforms.positive)");
   return 0;
 }
 
