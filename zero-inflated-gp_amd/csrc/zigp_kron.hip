@@ -487,7 +487,15 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
   HostKronLatent hl[2] = {{{p->M0f, p->M1f}, {p->Z0f, p->Z1f}, {p->ell0f, p->ell1f}, {p->var0f, p->var1f}, p->u_fm, p->u_fs_sqrt},
                           {{p->M0g, p->M1g}, {p->Z0g, p->Z1g}, {p->ell0g, p->ell1g}, {p->var0g, p->var1g}, p->u_gm, p->u_gs_sqrt}};
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
-  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_setup(c, ks.lat[h], hl[h], D0, D1, jitter));
+  {
+    TwoStream ts(c);   // the two latents are independent launch chains of small kernels: f on the main stream, g on stream2
+    ZIGP_TRY(ts.fork());
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1) ts.second();
+      ZIGP_TRY(latent_setup(c, ks.lat[h], hl[h], D0, D1, jitter));
+    }
+    ZIGP_TRY(ts.join());
+  }
   ZIGP_TRY(check_info(c, "a Kronecker factor of Kuu"));
   // KL scalars (value) -- before the backward pass overwrites nothing it needs
   std::vector<double> hkl[2];
@@ -501,10 +509,16 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
       ZIGP_HIP(c, hipMemcpyAsync(hkl[h].data(), lt.vec.p + Mq0 + Mq1, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
     }
   }
-  for (int h = 0; h < 2; ++h) {
-    KronLatent& lt = ks.lat[h];
-    ZIGP_TRY(latent_forward_panels(c, lt, ks.X.p, N, Nc, ldx));
-    ZIGP_ENSURE(c, lt.gm, Nc); ZIGP_ENSURE(c, lt.gv, Nc); ZIGP_ENSURE(c, lt.dq0, Nc); ZIGP_ENSURE(c, lt.dq1, Nc);
+  {
+    TwoStream ts(c);
+    ZIGP_TRY(ts.fork());
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1) ts.second();
+      KronLatent& lt = ks.lat[h];
+      ZIGP_TRY(latent_forward_panels(c, lt, ks.X.p, N, Nc, ldx));
+      ZIGP_ENSURE(c, lt.gm, Nc); ZIGP_ENSURE(c, lt.gv, Nc); ZIGP_ENSURE(c, lt.dq0, Nc); ZIGP_ENSURE(c, lt.dq1, Nc);
+    }
+    ZIGP_TRY(ts.join());
   }
   const int blocks = (int)(Nc / PW_THREADS);
   ZIGP_ENSURE(c, ks.acc, (size_t)blocks * 4);
@@ -530,7 +544,10 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
 
   std::vector<double> hkrow[2][2], hG[2][2], hgu[2], hgs[2];
   if (need_grad) {
+    TwoStream ts(c);
+    ZIGP_TRY(ts.fork());
     for (int h = 0; h < 2; ++h) {
+      if (h == 1) ts.second();
       KronLatent& lt = ks.lat[h];
       ZIGP_TRY(latent_backward(c, lt, ks.X.p, N, Nc, ldx, include_kl != 0));
       const int M0 = lt.f[0].M, M1 = lt.f[1].M, Mq0 = lt.f[0].Mq, Mq1 = lt.f[1].Mq;
@@ -553,6 +570,7 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
       ZIGP_HIP(c, hipMemcpyAsync(hgu[h].data(), lt.T0.p, sizeof(double) * M0 * M1, hipMemcpyDeviceToHost, c->stream));
       ZIGP_HIP(c, hipMemcpyAsync(hgs[h].data(), lt.T1.p, sizeof(double) * M0 * M1, hipMemcpyDeviceToHost, c->stream));
     }
+    ZIGP_TRY(ts.join());
   }
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   double s_ve = 0, s_dn = 0, s_gv[2] = {0, 0};
