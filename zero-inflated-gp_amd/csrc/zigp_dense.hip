@@ -93,7 +93,7 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
   ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc);
   ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc);
   ZIGP_ENSURE(c, lt.A2, (size_t)Mp * Nc);
-  const int np = Mp / 64;   // partial rows of the fused column sums
+  const int np = Mp / 32;   // partial rows of the fused column sums (one per 32 inducing rows)
   ZIGP_ENSURE(c, lt.part, (size_t)3 * np * Nc);
   KernHyp hyp = make_hyp(ell_host, lt.var, D);
   {
@@ -337,7 +337,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     {
       ProfScope ps(c, PC_POINT);
       PwArgs a;
-      a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 64; a.np_g = c->lat[1].Mp / 64; a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
+      a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32; a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
       a.var_f = p->var_f; a.var_g = p->var_g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
       a.gm_f = need_grad ? c->lat[0].gm.p : nullptr; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
       a.acc = c->pw_part.p; a.out9 = d_out9 ? d_out9 - row_begin : nullptr; a.ld9 = row_end - row_begin;

@@ -28,15 +28,19 @@
 namespace zigp {
 
 constexpr int BM = 128, BN = 128, BK = 16;
-// Workgroup shapes (template parameter WAVES of the kernel): 2 (M) x WAVES/2 (N) waves.
+// Workgroup shapes (template parameter WAVES of the kernel): WAVES/2 (M) x 2 (N) waves, wave tiles 64 columns wide.
 //   WAVES = 4: wave tile 64x64, 64 accumulators/lane, <= 256 VGPRs, 2 waves/SIMD with 2 workgroups/CU
-//   WAVES = 8: wave tile 64x32, 32 accumulators/lane, <= 128 VGPRs, 4 waves/SIMD with 2 workgroups/CU
+//   WAVES = 8: wave tile 32x64, 32 accumulators/lane, <= 128 VGPRs, 4 waves/SIMD with 2 workgroups/CU; triangular
+//              structure is skipped at 32-row granularity
 // Measured on MI355X (cfg3): the 8-wave shape is ~7 % faster where it fits 128 VGPRs without spilling.
 template <int WAVES> struct Shape {
   static constexpr int THREADS = 64 * WAVES;
-  static constexpr int WNW = WAVES / 2;        // waves along N
-  static constexpr int WTN = BN / WNW;         // wave tile width
-  static constexpr int TNW = WTN / 16;         // 16-column sub-tiles per wave
+  static constexpr int WMW = WAVES / 2;        // waves along M
+  static constexpr int WNW = 2;                // waves along N
+  static constexpr int RW = BM / WMW;          // rows per wave: 64 or 32
+  static constexpr int TMW = RW / 16;          // 16-row sub-tiles per wave: 4 or 2
+  static constexpr int WTN = BN / WNW;         // wave tile width: 64
+  static constexpr int TNW = WTN / 16;         // 16-column sub-tiles per wave: 4
   static constexpr int CHUNKS = 16 / WAVES;    // 1 KB staging chunks per wave and operand tile
 };
 constexpr int LDMN = 128 + 16;                    // row stride (doubles) of an m/n-contiguous tile image: odd k rows shift 128 B
@@ -67,18 +71,18 @@ struct GemmArgs {
 };
 
 // ---- epilogues --------------------------------------------------------------------------------
-// acc[tm][tn][r] of lane l is C[row0 + wm*64 + tm*16 + 4r + l/16][col0 + wn*WTN + tn*16 + l%16].
-// An epilogue is `template <int TN> void operator()(const double (&acc)[4][TN][4], const EpiCtx&) const`.
+// acc[tm][tn][r] of lane l is C[row0 + wm*RW + tm*16 + 4r + l/16][col0 + wn*64 + tn*16 + l%16]  (RW = 64 or 32 rows per wave).
+// An epilogue is `template <int TM, int TN> void operator()(const double (&acc)[TM][TN][4], const EpiCtx&) const`.
 struct EpiCtx {
   double* C; int64_t ldc; double alpha;
-  int64_t row0, col0;   // of this wave's 64 x WTN sub-tile
+  int64_t row0, col0;   // of this wave's RW x 64 sub-tile
   int lane;
 };
-template <int TN, class F>
-__device__ __forceinline__ void epi_foreach(const double (&acc)[4][TN][4], const EpiCtx& e, F f) {
+template <int TM, int TN, class F>
+__device__ __forceinline__ void epi_foreach(const double (&acc)[TM][TN][4], const EpiCtx& e, F f) {
   const int c_i = e.lane >> 4, c_j = e.lane & 15;
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t gi = e.row0 + tm * 16 + 4 * r + c_i;
@@ -87,23 +91,23 @@ __device__ __forceinline__ void epi_foreach(const double (&acc)[4][TN][4], const
     }
 }
 struct EpiStore {   // C = alpha*acc
-  template <int TN>
-  __device__ __forceinline__ void operator()(const double (&acc)[4][TN][4], const EpiCtx& e) const {
+  template <int TM, int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = v; });
   }
 };
 struct EpiAccum {   // C += alpha*acc
-  template <int TN>
-  __device__ __forceinline__ void operator()(const double (&acc)[4][TN][4], const EpiCtx& e) const {
+  template <int TM, int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const {
     double* C = e.C; const int64_t ld = e.ldc;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] += v; });
   }
 };
 struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
   const double* __restrict__ S;
-  template <int TN>
-  __device__ __forceinline__ void operator()(const double (&acc)[4][TN][4], const EpiCtx& e) const {
+  template <int TM, int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc; const double* __restrict__ Sp = S;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = v - Sp[i * ld + j]; });
   }
@@ -112,41 +116,45 @@ struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
 // Store + fused column reductions over this wave's 64 rows (GPConditional's reduce_sum over the inducing index,
 // onofftf/main.py:278,287,291,302):   out1[n] = sum_m w1[m] C[m,n]   (skipped if w1 == nullptr)
 //                                      out2[n] = sum_m w2[m] C[m,n]^2 (w2 == nullptr -> weight 1)
-// written to partial row (global row / 64) of out1/out2 (each [Mp/64][ldc]); the point-wise kernel adds the partial
+// written to partial row (global row / 32) of out1/out2 (each [Mp/32][ldc]); the point-wise kernel adds the partial
 // rows in index order, so the result does not depend on scheduling.
 struct EpiStoreColsum {
   const double* __restrict__ w1; const double* __restrict__ w2; double* __restrict__ out1; double* __restrict__ out2;
-  template <int TN>
-  __device__ __forceinline__ void operator()(const double (&acc)[4][TN][4], const EpiCtx& e) const {
+  template <int TM, int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc;
     const int c_i = e.lane >> 4, c_j = e.lane & 15;
-    double s1[TN], s2[TN];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) { s1[tn] = 0.0; s2[tn] = 0.0; }
+    for (int tp = 0; tp < TM / 2; ++tp) {   // one partial row per 32 rows (pair of 16-row sub-tiles)
+      double s1[TN], s2[TN];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+      for (int tn = 0; tn < TN; ++tn) { s1[tn] = 0.0; s2[tn] = 0.0; }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t gi = e.row0 + tm * 16 + 4 * r + c_i;
-        const double a1 = w1 ? w1[gi] : 0.0, a2 = w2 ? w2[gi] : 1.0;
+      for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const double v = e.alpha * acc[tm][tn][r];
-          C[gi * ld + e.col0 + tn * 16 + c_j] = v;
-          s1[tn] = fma(a1, v, s1[tn]);
-          s2[tn] = fma(a2 * v, v, s2[tn]);
+        for (int r = 0; r < 4; ++r) {
+          const int tm = 2 * tp + tq;
+          const int64_t gi = e.row0 + tm * 16 + 4 * r + c_i;
+          const double a1 = w1 ? w1[gi] : 0.0, a2 = w2 ? w2[gi] : 1.0;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const double v = e.alpha * acc[tm][tn][r];
+            C[gi * ld + e.col0 + tn * 16 + c_j] = v;
+            s1[tn] = fma(a1, v, s1[tn]);
+            s2[tn] = fma(a2 * v, v, s2[tn]);
+          }
         }
-      }
-    const int64_t prow = e.row0 >> 6;
+      const int64_t prow = (e.row0 >> 5) + tp;
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {   // fixed-order combine of the four 16-lane row groups
-      double a = s1[tn], b = s2[tn];
-      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-      if (c_i == 0) {
-        const int64_t o = prow * ld + e.col0 + tn * 16 + c_j;
-        if (w1) out1[o] = a;
-        out2[o] = b;
+      for (int tn = 0; tn < TN; ++tn) {   // fixed-order combine of the four 16-lane row groups
+        double a = s1[tn], b = s2[tn];
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        if (c_i == 0) {
+          const int64_t o = prow * ld + e.col0 + tn * 16 + c_j;
+          if (w1) out1[o] = a;
+          out2[o] = b;
+        }
       }
     }
   }
@@ -215,6 +223,7 @@ template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, int WAVES, class
 __global__ void __launch_bounds__(64 * WAVES, ((NSTAGE <= 2) ? 2 : 1) * WAVES / 4)
 gemm_f64_kernel(GemmArgs g, Epi epi) {
   constexpr int WNW = Shape<WAVES>::WNW, WTN = Shape<WAVES>::WTN, TNW = Shape<WAVES>::TNW, CHUNKS = Shape<WAVES>::CHUNKS;
+  constexpr int RW = Shape<WAVES>::RW, TMW = Shape<WAVES>::TMW;
   // the 4-base A map costs 3 VGPRs more: used where the B tile is m/n-contiguous (1 base register), not in the K/K kernels
   constexpr bool A_NEWMAP = (BLAY == LAY_MNCONTIG);
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
@@ -224,9 +233,9 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   const int wm = wave / WNW, wn = wave % WNW;
   const int64_t row0 = (int64_t)tl.bi * BM, col0 = (int64_t)tl.bj * BN;
 
-  double acc[4][TNW][4];
+  double acc[TMW][TNW][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < TMW; ++a)
 #pragma unroll
     for (int b = 0; b < TNW; ++b)
 #pragma unroll
@@ -268,9 +277,9 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   int a_base[4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
-    a_base[x] = (ALAY == LAY_KCONTIG) ? (A_NEWMAP ? ((wm * 64 + a_i) * 16 + 2 * ((a_i ^ (kq >> 1)) ^ x) + (kq & 1))
-                                                    : ((wm * 64 + a_i) * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1)))
-                                      : (kq * LDMN + wm * 64 + a_i);
+    a_base[x] = (ALAY == LAY_KCONTIG) ? (A_NEWMAP ? ((wm * RW + a_i) * 16 + 2 * ((a_i ^ (kq >> 1)) ^ x) + (kq & 1))
+                                                    : ((wm * RW + a_i) * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1)))
+                                      : (kq * LDMN + wm * RW + a_i);
   int b_base[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
@@ -288,9 +297,9 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
     // (it still takes part in staging and barriers; the co-resident workgroup gets the matrix pipe).
     const int krel = (tl.kbeg + it) * BK - tl.bi * BM;   // k offset of this step relative to the row block
     bool skip = false;
-    if (TRI == TRI_A_LOWER) skip = krel > wm * 64 + 63;
-    if (TRI == TRI_A_UPPER) skip = krel + BK - 1 < wm * 64;
-    if (TRI == TRI_C_LOWER) skip = (tl.bi == tl.bj) && (wn * WTN > wm * 64 + 63);
+    if (TRI == TRI_A_LOWER) skip = krel > wm * RW + RW - 1;
+    if (TRI == TRI_A_UPPER) skip = krel + BK - 1 < wm * RW;
+    if (TRI == TRI_C_LOWER) skip = (tl.bi == tl.bj) && (wn * WTN > wm * RW + RW - 1);
     if (!skip) {
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {
@@ -306,14 +315,14 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
         if (WAVES == 4) {
           // all 16 A fragments of this k-step are requested before the first MFMA (the 64 MFMAs that follow
           // cover the LDS latency of the next k-step's reads, which the compiler hoists above them)
-          double af[4][4];
+          double af[TMW][4];
 #pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
+          for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               af[tm][r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
 #pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
+          for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
@@ -322,7 +331,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
         } else {
           // 4 waves/SIMD hide LDS latency across waves: fragments are read 4 at a time to stay within 128 VGPRs
 #pragma unroll
-          for (int tm = 0; tm < 4; ++tm) {
+          for (int tm = 0; tm < TMW; ++tm) {
             double af[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -340,7 +349,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
 
   EpiCtx e;
   e.C = g.C + (int64_t)tl.slice * g.slice_stride; e.ldc = g.ldc; e.alpha = g.alpha;
-  e.row0 = row0 + wm * 64; e.col0 = col0 + wn * WTN; e.lane = lane;
+  e.row0 = row0 + wm * RW; e.col0 = col0 + wn * WTN; e.lane = lane;
   epi(acc, e);
 }
 

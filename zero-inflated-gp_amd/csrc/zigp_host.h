@@ -9,8 +9,8 @@
 namespace zigp {
 
 struct EpiPhi {  // Phi: keep strictly-lower, halve the diagonal, zero above
-  template <int TN>
-  __device__ __forceinline__ void operator()(const double (&acc)[4][TN][4], const EpiCtx& e) const {
+  template <int TM, int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc;
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = (j < i) ? v : ((j == i) ? 0.5 * v : 0.0); });
   }

@@ -90,7 +90,7 @@ k_kuf_build(const double* __restrict__ X, int64_t N, int64_t n0, const double* _
 // ---------------------------------------------------------------------------------------------
 struct PwArgs {
   const double* part_f; const double* part_g;    // per latent [3][NP][Nc]: sum v A1, sum A1^2, sum s2 A2^2 partial rows (EpiStoreColsum)
-  int np_f, np_g;                                 // partial rows per quantity (Mp/64)
+  int np_f, np_g;                                 // partial rows per quantity (Mp/32)
   const double* Y; int64_t n0, row_end, Nc;
   double var_f, var_g, noise, g_offset, scale;
   double* gm_f; double* gv_f; double* gm_g; double* gv_g;
