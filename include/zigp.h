@@ -126,6 +126,25 @@ int zigp_kron_elbo(zigp_ctx* ctx, const zigp_kron_params* p, const double* X, co
 int zigp_kron_predict(zigp_ctx* ctx, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter,
                       double g_offset, double* out9);
 
+/* Single-latent heads on the same Kronecker conditional -- the reference's baselines, which re-use kron_inf and
+ * GaussKLkron with one latent f:
+ *   ZIGP_LIK_GAUSSIAN   scripts/svgp.py:127-200,207-233 and scripts/hurdle.py:127-252 (regression; noise variance)
+ *   ZIGP_LIK_BERNOULLI  scripts/classifier.py:116-240 (log probit(fmean / sqrt(1 + fvar)) of the 0/1 label, y == 1 is "on")
+ * Only the f fields of zigp_kron_params / zigp_kron_grads are read / written (g pointers may be NULL; noise is ignored
+ * by the Bernoulli head).  f_mu is the constant mean offset of classifier.py:70-72,136-137 (0 when include_f_mu is False);
+ * d_f_mu (nullable) receives the gradient of the scaled data term with respect to it. */
+#define ZIGP_LIK_ONOFF 0
+#define ZIGP_LIK_GAUSSIAN 1
+#define ZIGP_LIK_BERNOULLI 2
+int zigp_kron_head_elbo(zigp_ctx* ctx, const zigp_kron_params* p, int32_t lik, const double* X, const double* Y,
+                        int64_t N, double jitter, double scale, double f_mu, int32_t include_kl,
+                        double* elbo_data, double* kl, zigp_kron_grads* grads, double* d_f_mu);
+/* Replaces predict_svgp / predict_scgp (onofftf/svgppred.py:15-203, onofftf/svcppred.py:15-224).  out4 = 4 x N rows:
+ * fmean, fvar, pfmean, pfvar.  Bernoulli: pfmean = probit(fmean / sqrt(1 + fvar)), pfvar = pfmean - pfmean^2
+ * (svcppred.py "pfmean"/"pfvar"); Gaussian: pfmean = fmean, pfvar = fvar + noise (svgppred.py returns rows 0-1). */
+int zigp_kron_head_predict(zigp_ctx* ctx, const zigp_kron_params* p, int32_t lik, const double* Xnew, int64_t N,
+                           double jitter, double f_mu, double* out4);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* Accumulated HIP-event time (ms), launch count and algorithmic flops per kernel class since the last reset,
  * measured with HIP events on the stream the kernels run on.  Classes (gemm_f64_kernel template arguments are

@@ -259,3 +259,37 @@ def kron_elbo(X, Y, p, jitter, scale=1.0, g_offset=0.0):
     gfmean, gfvar, gfmeanu = kron_build_predict(X, p, jitter, g_offset)[:3]
     data = np.sum(variational_expectations(gfmean, gfvar, gfmeanu, Y.reshape(-1, 1), p['noise']))
     return data * scale - (klf + klg), data, klf, klg
+
+
+# --------------------------------------------------------------------------
+# (f) rank 4: single-latent heads on the same kron_inf -- the reference's baselines
+#     Gaussian regression  scripts/svgp.py:116-233 (= scripts/hurdle.py:127-252 on the "on" subset)
+#     Bernoulli classifier scripts/classifier.py:116-240
+# --------------------------------------------------------------------------
+def head_probit(x):                                                    # classifier.py:216-217
+    return 0.5 * (1.0 + erf(x / np.sqrt(2.0))) * (1 - 2e-3) + 1e-3
+
+
+def kron_head_predict(Xnew, p, lik, jitter, f_mu=0.0):
+    """svgp.py:127-138 -> (fmean, fvar); classifier.py:128-142 -> (pfmean, pfvar, fmean, fvar)."""
+    fmean, fvar = kron_inf(Xnew, p['Zf'], p['ell_f'], p['var_f'], p['u_fm'], p['u_fs_sqrt'], jitter)
+    fmean = fmean + f_mu                                               # classifier.py:136-137
+    if lik == 'gaussian':
+        return fmean, fvar
+    pr = head_probit(fmean / np.sqrt(1 + fvar))                        # classifier.py:139
+    return pr, pr - np.square(pr), fmean, fvar                         # :140
+
+
+def kron_head_elbo(X, Y, p, lik, jitter, scale=1.0, f_mu=0.0):
+    """svgp.py:207-233 / classifier.py:219-240: cost = -(sum(var_exp)*scale - kl); returns (ELBO, data, KL)."""
+    Kf = [rbf_K(Z, None, l, v) + np.eye(Z.shape[0]) * jitter for Z, l, v in zip(p['Zf'], p['ell_f'], p['var_f'])]
+    kl = gauss_kl_kron(p['u_fm'], p['u_fs_sqrt'], Kf)                  # svgp.py:116-125
+    Y = Y.reshape(-1, 1)
+    if lik == 'gaussian':
+        fmean, fvar = kron_head_predict(X, p, lik, jitter, f_mu)
+        ve = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(p['noise']) - 0.5 * (np.square(Y - fmean) + fvar) / p['noise']   # svgp.py:198-200
+    else:
+        pr = kron_head_predict(X, p, lik, jitter, f_mu)[0]
+        ve = np.log(np.where(Y == 1, pr, 1 - pr))                      # classifier.py:213-214
+    data = np.sum(ve)
+    return data * scale - kl, data, kl

@@ -218,3 +218,39 @@ def kron_elbo_and_grad(X, Y, p_np, jitter, scale=1.0, g_offset=0.0, include_kl=T
         for k in KRON_VEC_KEYS:
             grads[k] = p[k].grad.numpy().copy()
     return float(elbo.detach()), float(data.detach()), float(kl.detach()), grads
+
+
+# ---------------------------------------------------------------- single-latent heads (baselines) -----
+HEAD_KEYS = ('Zf', 'ell_f', 'var_f')
+
+
+def kron_head_elbo_and_grad(X, Y, p_np, lik, jitter, scale=1.0, f_mu=0.0, include_kl=True, need_grad=True):
+    """scripts/svgp.py:116-233 ('gaussian') / scripts/classifier.py:116-240 ('bernoulli'), literal dense order + autograd.
+    Returns (elbo, data, kl, grads) with grads keys Zf, ell_f, var_f (lists), u_fm, u_fs_sqrt, noise, f_mu."""
+    Xt, Yt = _t(X), _t(Y).reshape(-1, 1)
+    p = {k: [_t(v).clone().requires_grad_(need_grad) for v in p_np[k]] for k in HEAD_KEYS}
+    for k in ('u_fm', 'u_fs_sqrt'):
+        p[k] = _t(p_np[k]).clone().requires_grad_(need_grad)
+    p['noise'] = _t(p_np.get('noise', 1.0)).clone().requires_grad_(need_grad)
+    p['f_mu'] = _t(f_mu).clone().requires_grad_(need_grad)
+    with torch.set_grad_enabled(need_grad):
+        fmean, fvar = kron_inf(Xt, p['Zf'], p['ell_f'], p['var_f'], p['u_fm'], p['u_fs_sqrt'], jitter)
+        fmean = fmean + p['f_mu']
+        if lik == 'gaussian':
+            ve = -0.5 * np.log(2 * np.pi) - 0.5 * torch.log(p['noise']) - 0.5 * (torch.square(Yt - fmean) + fvar) / p['noise']
+        else:
+            pr = 0.5 * (1.0 + torch.erf(fmean / torch.sqrt(1 + fvar) / np.sqrt(2.0))) * (1 - 2e-3) + 1e-3
+            ve = torch.log(torch.where(Yt == 1, pr, 1 - pr))
+        data = torch.sum(ve)
+        kl = torch.zeros((), dtype=DT)
+        if include_kl:
+            Kf = [rbf_K(Z, None, l, v) + torch.eye(Z.shape[0], dtype=DT) * jitter for Z, l, v in zip(p['Zf'], p['ell_f'], p['var_f'])]
+            kl = gauss_kl_kron(p['u_fm'], p['u_fs_sqrt'], Kf)
+        elbo = data * scale - kl
+    grads = None
+    if need_grad:
+        elbo.backward()
+        grads = {k: [v.grad.numpy().copy() for v in p[k]] for k in HEAD_KEYS}
+        for k in ('u_fm', 'u_fs_sqrt', 'noise', 'f_mu'):
+            grads[k] = p[k].grad.numpy().copy() if p[k].grad is not None else np.zeros(tuple(p[k].shape))
+    return float(elbo.detach()), float(data.detach()), float(kl.detach()), grads

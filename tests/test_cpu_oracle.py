@@ -117,3 +117,34 @@ def test_kronecker_literal_equals_factored_identities():
     al = np.linalg.solve(Ls, u.reshape(Ms, Mt)) @ np.linalg.inv(Lt).T
     kl_f = 0.5 * ((al ** 2).sum() - Ms * Mt - np.log(s ** 2).sum() + (dk * s ** 2).sum() + logdet)
     assert abs(kl - kl_f) < 1e-10 * abs(kl)
+
+
+def _head_problem(N, M0, M1, lik):
+    rs = np.random.RandomState(5)
+    X = np.hstack([rs.rand(N, 2) * 10.0, rs.rand(N, 1)])
+    Y = np.where(rs.rand(N) > 0.6, np.abs(np.sin(X[:, 0]) + 0.3 * rs.randn(N)), 0.0)[:, None]
+    if lik == 'bernoulli':
+        Y = (Y > 0) * 1.0
+    p = dict(Zf=[rs.rand(M0, 2) * 10.0, np.linspace(0, 1, M1)[:, None]], ell_f=[np.array([3.0, 3.5]), np.array([0.4])],
+             var_f=[np.array([2.0]), np.array([1.5])], u_fm=0.1 * rs.randn(M0 * M1, 1), u_fs_sqrt=0.5 + rs.rand(M0 * M1, 1), noise=0.05)
+    return X, Y, p
+
+
+def test_head_numpy_and_torch_oracles_agree():
+    """the numpy and torch restatements of the single-latent heads (svgp.py / classifier.py) agree, and autograd matches
+    central differences on f_mu and the noise variance."""
+    import zigp_oracle as o
+    import zigp_oracle_torch as ot
+    for lik in ('gaussian', 'bernoulli'):
+        X, Y, p = _head_problem(150, 4, 5, lik)
+        e_np, d_np, kl_np = o.kron_head_elbo(X, Y, p, lik, 1e-5, scale=3.0, f_mu=0.1)
+        e_t, d_t, kl_t, _ = ot.kron_head_elbo_and_grad(X, Y, p, lik, 1e-5, scale=3.0, f_mu=0.1, need_grad=False)
+        assert abs(e_np - e_t) < 1e-9 * abs(e_t) and abs(kl_np - kl_t) < 1e-9 * abs(kl_t)
+        _, _, _, g = ot.kron_head_elbo_and_grad(X, Y, p, lik, 1e-5, scale=3.0, f_mu=0.1)
+        h = 1e-5
+        fd = (o.kron_head_elbo(X, Y, p, lik, 1e-5, 3.0, 0.1 + h)[0] - o.kron_head_elbo(X, Y, p, lik, 1e-5, 3.0, 0.1 - h)[0]) / (2 * h)
+        assert abs(fd - float(g['f_mu'])) < 1e-6 * max(1.0, abs(fd))
+        if lik == 'gaussian':
+            fd = (o.kron_head_elbo(X, Y, dict(p, noise=0.05 + 1e-7), lik, 1e-5, 3.0, 0.1)[0]
+                  - o.kron_head_elbo(X, Y, dict(p, noise=0.05 - 1e-7), lik, 1e-5, 3.0, 0.1)[0]) / 2e-7
+            assert abs(fd - float(g['noise'])) < 1e-5 * abs(fd)

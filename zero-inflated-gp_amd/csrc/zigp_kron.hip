@@ -149,6 +149,54 @@ k_kron_pointwise(KronPwArgs p) {
   if (threadIdx.x == 0) { double* a = p.acc + (int64_t)blockIdx.x * 4; a[0] = s0; a[1] = s1; a[2] = s2; a[3] = s3; }
 }
 
+// Single-latent heads on the same kron_inf (the reference's baselines):
+//   lik 1, Gaussian  (scripts/svgp.py:198-200, hurdle.py:217-219):  ve = -1/2 log 2pi - 1/2 log s2 - 1/2 ((y - fm)^2 + fv) / s2
+//   lik 2, Bernoulli (scripts/classifier.py:139-140,210-217):       p = probit(fm / sqrt(1 + fv)),  ve = log(y == 1 ? p : 1 - p)
+// with fm = kron mean + f_mu (classifier.py:136-137).  acc[b] = {ve, d noise, sum gv, sum gm (= d f_mu)}.
+// Predict rows (ld = N): fmean, fvar, pfmean, pfvar -- Gaussian: pfmean = fm, pfvar = fv + s2 (density of y);
+// Bernoulli: pfmean = p, pfvar = p - p^2 (classifier.py:140).
+template <bool PREDICT>
+__global__ void __launch_bounds__(PW_THREADS)
+k_kron_head_pointwise(KronPwArgs p, int lik) {
+  __shared__ double sh[4];
+  const int64_t n = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  const double q0 = p.part_f[n], q1 = p.part_f[p.Nc + n];
+  const double fm = p.part_f[2 * p.Nc + n] + p.g_offset, fv = p.knn_f - q0 * q1 + p.part_f[3 * p.Nc + n];
+  const bool valid = n < p.N;
+  const double y = (valid && p.Y) ? p.Y[n] : 0.0;
+  double ve, dfm, dfv, dnoise = 0.0, pm, pv;
+  if (lik == ZIGP_LIK_GAUSSIAN) {
+    const double inv = 1.0 / p.noise, res = y - fm, q = res * res + fv;
+    ve = -0.5 * 1.8378770664093454836 - 0.5 * log(p.noise) - 0.5 * q * inv;
+    dfm = res * inv; dfv = -0.5 * inv; dnoise = -0.5 * inv + 0.5 * q * inv * inv;
+    pm = fm; pv = fv + p.noise;
+  } else {
+    const double c1 = 1.0 - 2.e-3, c0 = 1.e-3;
+    const double r = 1.0 / sqrt(1.0 + fv), z = fm * r;
+    const double pr = 0.5 * (1.0 + erf(z * 0.70710678118654752440)) * c1 + c0;   // classifier.py:216-217
+    const bool on = (y == 1.0);                                                  // tf.equal(y, 1) :214
+    ve = log(on ? pr : 1.0 - pr);
+    const double dp = on ? 1.0 / pr : -1.0 / (1.0 - pr);
+    const double dz = dp * c1 * 0.39894228040143267794 * exp(-0.5 * z * z);
+    dfm = dz * r; dfv = dz * (-0.5 * z / (1.0 + fv));
+    pm = pr; pv = pr - pr * pr;
+  }
+  if (PREDICT) {
+    if (valid) { double* q = p.out9 + n; q[0] = fm; q[p.ld9] = fv; q[2 * p.ld9] = pm; q[3 * p.ld9] = pv; }
+    return;
+  }
+  const double sc = valid ? p.scale : 0.0;
+  if (p.gm_f) {
+    const double gvf = sc * dfv;
+    p.gm_f[n] = sc * dfm; p.gv_f[n] = gvf; p.dq0_f[n] = -gvf * q1; p.dq1_f[n] = -gvf * q0;
+  }
+  double s0 = block_sum<4>(sc * ve, sh);
+  double s1 = block_sum<4>(sc * dnoise, sh);
+  double s2 = block_sum<4>(sc * dfv, sh);
+  double s3 = block_sum<4>(sc * dfm, sh);
+  if (threadIdx.x == 0) { double* a = p.acc + (int64_t)blockIdx.x * 4; a[0] = s0; a[1] = s1; a[2] = s2; a[3] = s3; }
+}
+
 // dA[i][n] = 2 A[i][n] gv[n] C[i][n] ; E[i][n] = dq[n] K[i][n] + dA[i][n]
 __global__ void k_kron_da(const double* __restrict__ A, const double* __restrict__ C, const double* __restrict__ K,
                           const double* __restrict__ gv, const double* __restrict__ dq, int64_t Nc, int64_t total,
@@ -309,14 +357,17 @@ struct HostKronLatent {
   int M[2]; const double* Z[2]; const double* ell[2]; double var[2]; const double* u; const double* s;
 };
 
-int validate_kron(zigp_ctx* c, const zigp_kron_params* p) {
+// lik != ZIGP_LIK_ONOFF: single latent, only the f fields (and, for the Gaussian head, noise) are read
+int validate_kron(zigp_ctx* c, const zigp_kron_params* p, int lik = ZIGP_LIK_ONOFF) {
   if (!p) return fail_arg(c, "kron params is NULL");
-  if (p->M0f <= 0 || p->M1f <= 0 || p->M0g <= 0 || p->M1g <= 0) return fail_arg(c, "inducing counts must be positive");
+  if (lik != ZIGP_LIK_ONOFF && lik != ZIGP_LIK_GAUSSIAN && lik != ZIGP_LIK_BERNOULLI) return fail_arg(c, "unknown likelihood head");
+  const bool two = lik == ZIGP_LIK_ONOFF;
+  if (p->M0f <= 0 || p->M1f <= 0 || (two && (p->M0g <= 0 || p->M1g <= 0))) return fail_arg(c, "inducing counts must be positive");
   if (p->D0 <= 0 || p->D1 <= 0 || p->D0 > MAXD || p->D1 > MAXD) return fail_arg(c, "factor dimensions must be in [1, 8]");
-  if (!p->Z0f || !p->Z1f || !p->Z0g || !p->Z1g || !p->ell0f || !p->ell1f || !p->ell0g || !p->ell1g || !p->u_fm || !p->u_gm ||
-      !p->u_fs_sqrt || !p->u_gs_sqrt)
-    return fail_arg(c, "NULL pointer in kron params");
-  if (!(p->var0f > 0) || !(p->var1f > 0) || !(p->var0g > 0) || !(p->var1g > 0) || !(p->noise > 0)) return fail_arg(c, "variances must be positive");
+  if (!p->Z0f || !p->Z1f || !p->ell0f || !p->ell1f || !p->u_fm || !p->u_fs_sqrt) return fail_arg(c, "NULL pointer in kron params");
+  if (two && (!p->Z0g || !p->Z1g || !p->ell0g || !p->ell1g || !p->u_gm || !p->u_gs_sqrt)) return fail_arg(c, "NULL pointer in kron params");
+  if (!(p->var0f > 0) || !(p->var1f > 0) || (two && (!(p->var0g > 0) || !(p->var1g > 0)))) return fail_arg(c, "variances must be positive");
+  if (lik != ZIGP_LIK_BERNOULLI && !(p->noise > 0)) return fail_arg(c, "variances must be positive");
   return 0;
 }
 
@@ -474,7 +525,9 @@ int latent_backward(zigp_ctx* c, KronLatent& lt, const double* dX, int64_t N, in
 namespace {
 
 int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
-             double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads) {
+             double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
+             int lik = ZIGP_LIK_ONOFF, double* d_offset = nullptr) {
+  const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;   // single-latent heads use the f latent only; g_offset is then f_mu
   if (!c->kron) { c->kron = new (std::nothrow) KronState(); c->kron_free = kron_free; if (!c->kron) { c->err = "out of memory"; return ZIGP_EHIP; } }
   KronState& ks = *c->kron;
   ks.stage.clear();   // every call ends with a stream synchronisation, so the previous step's images are no longer in flight
@@ -486,11 +539,12 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
   if (Y) { ZIGP_ENSURE(c, ks.Y, (size_t)N); ZIGP_HIP(c, hipMemcpyAsync(ks.Y.p, Y, sizeof(double) * N, hipMemcpyHostToDevice, c->stream)); }
   HostKronLatent hl[2] = {{{p->M0f, p->M1f}, {p->Z0f, p->Z1f}, {p->ell0f, p->ell1f}, {p->var0f, p->var1f}, p->u_fm, p->u_fs_sqrt},
                           {{p->M0g, p->M1g}, {p->Z0g, p->Z1g}, {p->ell0g, p->ell1g}, {p->var0g, p->var1g}, p->u_gm, p->u_gs_sqrt}};
+  if (nlat == 1) hl[1] = hl[0];
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
   {
     TwoStream ts(c);   // the two latents are independent launch chains of small kernels: f on the main stream, g on stream2
     ZIGP_TRY(ts.fork());
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < nlat; ++h) {
       if (h == 1) ts.second();
       ZIGP_TRY(latent_setup(c, ks.lat[h], hl[h], D0, D1, jitter));
     }
@@ -500,7 +554,7 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
   // KL scalars (value) -- before the backward pass overwrites nothing it needs
   std::vector<double> hkl[2];
   if (include_kl && !predict) {
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < nlat; ++h) {
       KronLatent& lt = ks.lat[h];
       const int Mq0 = lt.f[0].Mq, Mq1 = lt.f[1].Mq;
       hipLaunchKernelGGL(k_kron_kl, dim3(1), dim3(256), 0, c->stream, lt.U.p, lt.Al.p, lt.S.p, lt.vec.p, lt.vec.p + Mq0, lt.f[0].L.p, lt.f[1].L.p,
@@ -512,7 +566,7 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
   {
     TwoStream ts(c);
     ZIGP_TRY(ts.fork());
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < nlat; ++h) {
       if (h == 1) ts.second();
       KronLatent& lt = ks.lat[h];
       ZIGP_TRY(latent_forward_panels(c, lt, ks.X.p, N, Nc, ldx));
@@ -523,21 +577,25 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
   const int blocks = (int)(Nc / PW_THREADS);
   ZIGP_ENSURE(c, ks.acc, (size_t)blocks * 4);
   KronPwArgs a;
-  a.part_f = ks.lat[0].part.p; a.part_g = ks.lat[1].part.p; a.Y = Y ? ks.Y.p : nullptr; a.N = N; a.Nc = Nc;
+  const int gl_ = nlat - 1;   // latent whose buffers stand in for g (unused by the single-latent kernels)
+  a.part_f = ks.lat[0].part.p; a.part_g = ks.lat[gl_].part.p; a.Y = Y ? ks.Y.p : nullptr; a.N = N; a.Nc = Nc;
   a.knn_f = p->var0f * p->var1f; a.knn_g = p->var0g * p->var1g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
-  a.gm_f = need_grad ? ks.lat[0].gm.p : nullptr; a.gv_f = ks.lat[0].gv.p; a.gm_g = ks.lat[1].gm.p; a.gv_g = ks.lat[1].gv.p;
-  a.dq0_f = ks.lat[0].dq0.p; a.dq1_f = ks.lat[0].dq1.p; a.dq0_g = ks.lat[1].dq0.p; a.dq1_g = ks.lat[1].dq1.p;
+  a.gm_f = need_grad ? ks.lat[0].gm.p : nullptr; a.gv_f = ks.lat[0].gv.p; a.gm_g = ks.lat[gl_].gm.p; a.gv_g = ks.lat[gl_].gv.p;
+  a.dq0_f = ks.lat[0].dq0.p; a.dq1_f = ks.lat[0].dq1.p; a.dq0_g = ks.lat[gl_].dq0.p; a.dq1_g = ks.lat[gl_].dq1.p;
   a.acc = ks.acc.p; a.out9 = nullptr; a.ld9 = N;
   if (predict) {
-    ZIGP_ENSURE(c, ks.out9, (size_t)9 * N);
+    const int rows = nlat == 2 ? 9 : 4;
+    ZIGP_ENSURE(c, ks.out9, (size_t)rows * N);
     a.out9 = ks.out9.p;
-    hipLaunchKernelGGL(k_kron_pointwise<true>, dim3(blocks), dim3(PW_THREADS), 0, c->stream, a);
+    if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<true>, dim3(blocks), dim3(PW_THREADS), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_kron_head_pointwise<true>, dim3(blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
     ZIGP_HIP(c, hipGetLastError());
-    ZIGP_HIP(c, hipMemcpyAsync(out9, ks.out9.p, sizeof(double) * 9 * N, hipMemcpyDeviceToHost, c->stream));
+    ZIGP_HIP(c, hipMemcpyAsync(out9, ks.out9.p, sizeof(double) * rows * N, hipMemcpyDeviceToHost, c->stream));
     ZIGP_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
   }
-  hipLaunchKernelGGL(k_kron_pointwise<false>, dim3(blocks), dim3(PW_THREADS), 0, c->stream, a);
+  if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<false>, dim3(blocks), dim3(PW_THREADS), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_kron_head_pointwise<false>, dim3(blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
   ZIGP_HIP(c, hipGetLastError());
   std::vector<double> hacc((size_t)blocks * 4);
   ZIGP_HIP(c, hipMemcpyAsync(hacc.data(), ks.acc.p, sizeof(double) * hacc.size(), hipMemcpyDeviceToHost, c->stream));
@@ -546,7 +604,7 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
   if (need_grad) {
     TwoStream ts(c);
     ZIGP_TRY(ts.fork());
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < nlat; ++h) {
       if (h == 1) ts.second();
       KronLatent& lt = ks.lat[h];
       ZIGP_TRY(latent_backward(c, lt, ks.X.p, N, Nc, ldx, include_kl != 0));
@@ -576,9 +634,10 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
   double s_ve = 0, s_dn = 0, s_gv[2] = {0, 0};
   for (int b = 0; b < blocks; ++b) { s_ve += hacc[4 * b]; s_dn += hacc[4 * b + 1]; s_gv[0] += hacc[4 * b + 2]; s_gv[1] += hacc[4 * b + 3]; }
   if (elbo_data) *elbo_data = s_ve;
+  if (nlat == 1) { if (d_offset) *d_offset = s_gv[1]; s_gv[1] = 0.0; }   // acc[3] of the head kernel is sum gm = d ve / d f_mu
   double klsum = 0.0;
   if (include_kl) {
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < nlat; ++h) {
       const int M0 = ks.lat[h].f[0].M, M1 = ks.lat[h].f[1].M;
       klsum += 0.5 * (hkl[h][0] - (double)M0 * M1 - hkl[h][1] + hkl[h][2] + (double)M1 * hkl[h][3] + (double)M0 * hkl[h][4]);
     }
@@ -590,7 +649,7 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
     double gvar[2][2];
     double* gu[2] = {grads->u_fm, grads->u_gm};
     double* gs[2] = {grads->u_fs_sqrt, grads->u_gs_sqrt};
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < nlat; ++h) {
       for (int q = 0; q < 2; ++q) {
         const KronFactor& f = ks.lat[h].f[q];
         const int D = f.D, W = 2 + 2 * D;
@@ -612,7 +671,8 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
       if (gu[h]) memcpy(gu[h], hgu[h].data(), sizeof(double) * hgu[h].size());
       if (gs[h]) memcpy(gs[h], hgs[h].data(), sizeof(double) * hgs[h].size());
     }
-    grads->var0f = gvar[0][0]; grads->var1f = gvar[0][1]; grads->var0g = gvar[1][0]; grads->var1g = gvar[1][1];
+    grads->var0f = gvar[0][0]; grads->var1f = gvar[0][1];
+    grads->var0g = nlat == 2 ? gvar[1][0] : 0.0; grads->var1g = nlat == 2 ? gvar[1][1] : 0.0;
     grads->noise = s_dn;
   }
   return 0;
@@ -639,6 +699,28 @@ int zigp_kron_predict(zigp_ctx* c, const zigp_kron_params* p, const double* Xnew
   if (N == 0) return ZIGP_OK;
   ZIGP_HIP(c, hipSetDevice(c->device));
   return kron_run(c, p, Xnew, nullptr, N, jitter, 1.0, g_offset, 0, true, out9, nullptr, nullptr, nullptr);
+}
+
+int zigp_kron_head_elbo(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, const double* X, const double* Y, int64_t N, double jitter,
+                        double scale, double f_mu, int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads, double* d_f_mu) {
+  if (!c) return ZIGP_EARG;
+  if (lik == ZIGP_LIK_ONOFF) return fail_arg(c, "zigp_kron_head_elbo: use zigp_kron_elbo for the OnOff likelihood");
+  ZIGP_TRY(validate_kron(c, p, lik));
+  if (!X || !Y || N <= 0) return fail_arg(c, "zigp_kron_head_elbo: need X, Y and N > 0");
+  if (!(jitter >= 0)) return fail_arg(c, "zigp_kron_head_elbo: jitter must be >= 0");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  return kron_run(c, p, X, Y, N, jitter, scale, f_mu, include_kl, false, nullptr, elbo_data, kl, grads, lik, d_f_mu);
+}
+
+int zigp_kron_head_predict(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, const double* Xnew, int64_t N, double jitter, double f_mu,
+                           double* out4) {
+  if (!c) return ZIGP_EARG;
+  if (lik == ZIGP_LIK_ONOFF) return fail_arg(c, "zigp_kron_head_predict: use zigp_kron_predict for the OnOff likelihood");
+  ZIGP_TRY(validate_kron(c, p, lik));
+  if (N < 0 || (N > 0 && (!Xnew || !out4))) return fail_arg(c, "zigp_kron_head_predict: bad arguments");
+  if (N == 0) return ZIGP_OK;
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  return kron_run(c, p, Xnew, nullptr, N, jitter, 1.0, f_mu, 0, true, out4, nullptr, nullptr, nullptr, lik, nullptr);
 }
 
 }  // extern "C"

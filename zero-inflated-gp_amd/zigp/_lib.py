@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get('ZIGP_LIB') or os.path.join(ROOT, 'lib', 'libzigp.so')
 
 ZIGP_OK, ZIGP_EARG, ZIGP_EHIP, ZIGP_ENOTPD = 0, -1, -2, -3
 NCLASS = 10
+LIK_ONOFF, LIK_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2   # include/zigp.h ZIGP_LIK_*
 PROF_CLASSES = ('gemm_A1', 'gemm_A2', 'gemm_H', 'gemm_J', 'syrk', 'kuf_build', 'pointwise', 'kgrad', 'mxm_stage', 'other')
 PROF_KERNELS = {'gemm_A1': 'gemm_f64_kernel<0,1,2,false,1,4,EpiStoreColsum> (A1 = W K)',
                 'gemm_A2': 'gemm_f64_kernel<1,1,2,false,2,8,EpiStoreColsum> (A2 = W^T A1)',
@@ -71,6 +72,9 @@ SIGNATURES = {
     'zigp_kron_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, dp, C.c_int64, C.c_double, C.c_double, C.c_double,
                                  C.c_int32, dp, dp, C.POINTER(zigp_kron_grads)]),
     'zigp_kron_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, C.c_int64, C.c_double, C.c_double, dp]),
+    'zigp_kron_head_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), C.c_int32, dp, dp, C.c_int64, C.c_double, C.c_double,
+                                      C.c_double, C.c_int32, dp, dp, C.POINTER(zigp_kron_grads), dp]),
+    'zigp_kron_head_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), C.c_int32, dp, C.c_int64, C.c_double, C.c_double, dp]),
     'zigp_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),
     'zigp_profile_get': (C.c_int, [C.c_void_p, dp, C.POINTER(C.c_int64), dp]),
     'zigp_profile_reset': (C.c_int, [C.c_void_p]),

@@ -151,7 +151,7 @@ class DenseEngine:
 
     # ---- Kronecker (space x time) variant -------------------------------------------------------
     @staticmethod
-    def _pack_kron(p):
+    def _pack_kron(p, tags=('f', 'g')):
         """p: Zf/Zg = [Z0 (M0,D0), Z1 (M1,D1)], ell_f/ell_g = [l0, l1], var_f/var_g = [v0, v1], u_* (M0*M1), noise."""
         keep = {}
         s = _lib.zigp_kron_params()
@@ -165,7 +165,7 @@ class DenseEngine:
             return np.ascontiguousarray(v)
 
         dims = None
-        for tag in ('f', 'g'):
+        for tag in tags:
             Z0, Z1 = as_f64(p['Z' + tag][0]), as_f64(p['Z' + tag][1])
             if Z0.ndim != 2 or Z1.ndim != 2:
                 raise ValueError('factor inducing inputs must be 2-D')
@@ -186,7 +186,7 @@ class DenseEngine:
             setattr(s, 'var0' + tag, float(np.squeeze(p['var_' + tag][0]))); setattr(s, 'var1' + tag, float(np.squeeze(p['var_' + tag][1])))
             setattr(s, 'u_%sm' % tag, ptr(um)); setattr(s, 'u_%ss_sqrt' % tag, ptr(us))
         s.D0, s.D1 = dims
-        s.noise = float(np.squeeze(p['noise']))
+        s.noise = float(np.squeeze(p.get('noise', 1.0)))
         return s, keep, dims
 
     def kron_elbo(self, p, X, Y, jitter=1e-5, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True):
@@ -235,6 +235,49 @@ class DenseEngine:
         out = np.zeros((9, Xnew.shape[0]))
         _check(self.lib, self.ctx, self.lib.zigp_kron_predict(self.ctx, C.byref(s), ptr(Xnew), Xnew.shape[0], float(jitter),
                                                                float(g_offset), ptr(out)))
+        return out
+
+    LIK = {'gaussian': _lib.LIK_GAUSSIAN, 'bernoulli': _lib.LIK_BERNOULLI}
+
+    def kron_head_elbo(self, p, X, Y, lik, jitter=1e-5, scale=1.0, f_mu=0.0, include_kl=True, need_grad=True):
+        """Single-latent Kronecker SVGP bound with a 'gaussian' (scripts/svgp.py, hurdle.py) or 'bernoulli'
+        (scripts/classifier.py) head.  p holds the f fields only (Zf, ell_f, var_f, u_fm, u_fs_sqrt[, noise]).
+        Returns (elbo_data, kl, grads or None); grads has the f keys, 'noise' and 'f_mu'."""
+        s, keep, dims = self._pack_kron(p, tags=('f',))
+        X = as_f64(X)
+        if X.ndim != 2 or X.shape[1] != dims[0] + dims[1]:
+            raise ValueError('X must be (N,%d)' % (dims[0] + dims[1]))
+        Y = as_f64(Y).reshape(-1)
+        if Y.size != X.shape[0]:
+            raise ValueError('Y must have N entries')
+        ed, kl, dmu = C.c_double(0), C.c_double(0), C.c_double(0)
+        gs, a = None, None
+        if need_grad:
+            gs = _lib.zigp_kron_grads()
+            Z0, Z1, l0, l1, um, us = keep['f']
+            a = dict(Z0=np.zeros_like(Z0), Z1=np.zeros_like(Z1), ell0=np.zeros_like(l0), ell1=np.zeros_like(l1),
+                     um=np.zeros_like(um), us=np.zeros_like(us))
+            gs.Z0f, gs.Z1f, gs.ell0f, gs.ell1f = ptr(a['Z0']), ptr(a['Z1']), ptr(a['ell0']), ptr(a['ell1'])
+            gs.u_fm, gs.u_fs_sqrt = ptr(a['um']), ptr(a['us'])
+        rc = self.lib.zigp_kron_head_elbo(self.ctx, C.byref(s), self.LIK[lik], ptr(X), ptr(Y), X.shape[0], float(jitter), float(scale),
+                                          float(f_mu), 1 if include_kl else 0, C.byref(ed), C.byref(kl),
+                                          C.byref(gs) if gs is not None else None, C.byref(dmu))
+        _check(self.lib, self.ctx, rc)
+        out = None
+        if need_grad:
+            out = dict(noise=gs.noise, f_mu=dmu.value, Zf=[a['Z0'], a['Z1']], ell_f=[a['ell0'], a['ell1']], var_f=[gs.var0f, gs.var1f],
+                       u_fm=a['um'], u_fs_sqrt=a['us'])
+        return ed.value, kl.value, out
+
+    def kron_head_predict(self, p, Xnew, lik, jitter=1e-6, f_mu=0.0):
+        """(4,N): fmean, fvar, pfmean, pfvar (onofftf/svgppred.py:180-186, onofftf/svcppred.py 'pfmean'/'pfvar')."""
+        s, keep, dims = self._pack_kron(p, tags=('f',))
+        Xnew = as_f64(Xnew)
+        if Xnew.ndim != 2 or Xnew.shape[1] != dims[0] + dims[1]:
+            raise ValueError('Xnew must be (N,%d)' % (dims[0] + dims[1]))
+        out = np.zeros((4, Xnew.shape[0]))
+        _check(self.lib, self.ctx, self.lib.zigp_kron_head_predict(self.ctx, C.byref(s), self.LIK[lik], ptr(Xnew), Xnew.shape[0],
+                                                                    float(jitter), float(f_mu), ptr(out)))
         return out
 
     # ---- measurement ----
