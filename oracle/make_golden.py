@@ -6,6 +6,8 @@ G2  g2_dense_oracle.npz : outputs of this repo's CPU restatement (oracle/zigp_or
     inputs: the 9-tuple, KL_f, KL_g, ELBO and the full gradient.  NOT produced by the reference
     (TensorFlow/GPflow are not installable): these fixtures freeze the oracle so that a later edit
     cannot silently change it; they do not pin it to the reference ("parity unpinned").
+G3  g3_utils_pptr.npz : outputs of the REFERENCE's own `preprocessing` class (onofftf/utils_pptr.py, NumPy/pandas only,
+    imported in place) on a seeded synthetic station table: time filter, location/time scaling, kernel_params.
 """
 import os
 import sys
@@ -51,8 +53,44 @@ def g2():
     np.savez_compressed(os.path.join(OUT, 'g2_dense_oracle.npz'), **out)
 
 
+def pptr_like_table(seed=7, ntr=300, nte=90):
+    """seeded stand-in for the precipitation table: lat, lon, ndatehour columns + X arrays in that column order"""
+    import pandas as pd
+    rs = np.random.RandomState(seed)
+
+    def mk(n):
+        df = pd.DataFrame({'lat': 60 + 8 * rs.rand(n), 'lon': 20 + 10 * rs.rand(n), 'ndatehour': rs.randint(0, 400, n).astype(float)})
+        X = df[['lat', 'lon', 'ndatehour']].values.copy()
+        Y = np.where(rs.rand(n) > 0.6, 3 * rs.rand(n), 0.0)[:, None]
+        return df, X, Y
+    tr, te = mk(ntr), mk(nte)
+    return {'traindf': tr[0], 'testdf': te[0], 'Xtrain': tr[1], 'Ytrain': tr[2], 'Xtest': te[1], 'Ytest': te[2]}
+
+
+def g3():
+    sys.path.insert(0, '/root/reference')
+    from onofftf.utils_pptr import preprocessing   # the reference's own code, imported in place
+    out = {}
+    for tag, filt, loc, tim in (('raw', False, False, False), ('filt', True, False, False), ('loc', False, True, False), ('all', True, True, True)):
+        pp = preprocessing(pptr_like_table())
+        if filt:
+            pp.filter_time(50, 320)
+        if loc or tim:
+            pp.scale(scale_loc=loc, scale_time=tim)
+        md = pp.model_data
+        var, ell = pp.kernel_params
+        out.update({tag + '_Xtrain': md['Xtrain'], tag + '_Xtest': md['Xtest'], tag + '_Ytrain': md['Ytrain'], tag + '_Ytest': md['Ytest'],
+                    tag + '_traindf': md['traindf'][['lat', 'lon', 'ndatehour']].values, tag + '_shape': np.array(pp.shape),
+                    tag + '_kvar': np.array(var), tag + '_kell': np.array(ell)})
+        if loc or tim:
+            for c, v in pp.scale_param.items():
+                out['%s_sp_%s' % (tag, c)] = np.array([v['min'], v['range']])
+    np.savez_compressed(os.path.join(OUT, 'g3_utils_pptr.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     g1()
     g2()
+    g3()
     print(os.listdir(OUT))

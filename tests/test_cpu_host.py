@@ -9,6 +9,8 @@ import pytest
 
 from conftest import make_problem, ROOT
 
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
 
 def test_library_loads_and_exports_every_declared_symbol():
     """Every function declared in include/zigp.h resolves in libzigp.so and is bound in zigp._lib."""
@@ -179,3 +181,82 @@ def test_dataset_iterator_semantics():
     assert ds.epochs_completed == 1
     ds2 = DataSet(X, Y)
     assert np.array_equal(ds2.next_batch(4)[0].reshape(-1), seen[0])    # seed 121 -> reproducible
+
+
+# ---- data preparation of the precipitation experiments ------------------------------------
+def test_preprocessing_matches_reference_golden():
+    """onofftf.utils_pptr.preprocessing against outputs of the reference's own class (tests/golden/g3_utils_pptr.npz, made by
+    oracle/make_golden.py::g3 importing /root/reference/onofftf/utils_pptr.py in place)."""
+    import warnings
+    from make_golden import pptr_like_table
+    from onofftf.utils_pptr import preprocessing
+    g = np.load(os.path.join(GOLD, 'g3_utils_pptr.npz'))
+    for tag, filt, loc, tim in (('raw', False, False, False), ('filt', True, False, False), ('loc', False, True, False), ('all', True, True, True)):
+        pp = preprocessing(pptr_like_table())
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            if filt:
+                pp.filter_time(50, 320)
+            if loc or tim:
+                pp.scale(scale_loc=loc, scale_time=tim)
+        md = pp.model_data
+        for k in ('Xtrain', 'Xtest', 'Ytrain', 'Ytest'):
+            assert np.array_equal(md[k], g['%s_%s' % (tag, k)]), (tag, k)
+        assert np.array_equal(md['traindf'][['lat', 'lon', 'ndatehour']].values, g[tag + '_traindf'])
+        assert np.array_equal(np.array(pp.shape), g[tag + '_shape'])
+        var, ell = pp.kernel_params
+        assert var == float(g[tag + '_kvar']) and np.array_equal(np.array(ell), g[tag + '_kell'])
+        if loc or tim:
+            for c, v in pp.scale_param.items():
+                assert np.array_equal(np.array([v['min'], v['range']]), g['%s_sp_%s' % (tag, c)])
+
+
+def test_create_cvsplits_protocol(tmp_path):
+    """scripts/create_cvsplits.py: 5 folds of the pooled data, time / 1000, KFold(shuffle, random_state=1234), data.pickle per fold."""
+    import pickle
+    from scripts.create_cvsplits import create_cvsplits
+    d = np.load(os.path.join(GOLD, 'pptr.npz'))
+    small = {'Xtrain': d['Xtrain'][:400].copy(), 'Ytrain': d['Ytrain'][:400], 'Xtest': d['Xtest'][:100].copy(), 'Ytest': d['Ytest'][:100]}
+    src = tmp_path / 'pptr.pickle'
+    pickle.dump(small, open(src, 'wb'))
+    dirs = create_cvsplits(str(src), str(tmp_path / 'cv'))
+    assert [os.path.basename(x) for x in dirs] == ['1', '2', '3', '4', '5']
+    pooledX = np.concatenate([small['Xtrain'], small['Xtest']])
+    pooledX[:, 2] /= 1000
+    seen = []
+    for x in dirs:
+        f = pickle.load(open(os.path.join(x, 'data.pickle'), 'rb'))
+        assert f['Xtrain'].shape == (400, 3) and f['Xtest'].shape == (100, 3) and f['Ytest'].shape == (100, 1)
+        seen.append(f['Xtest'])
+    allx = np.concatenate(seen)
+    assert sorted(map(tuple, allx)) == sorted(map(tuple, pooledX))      # every pooled row is a test row exactly once
+    from sklearn.model_selection import KFold
+    tr, te = next(iter(KFold(n_splits=5, random_state=1234, shuffle=True).split(pooledX)))
+    assert np.array_equal(pickle.load(open(os.path.join(dirs[0], 'data.pickle'), 'rb'))['Xtest'], pooledX[te])
+
+
+def test_zero_inflated_combination_host_only(tmp_path):
+    """scripts/zero_inflated.py is pure post-processing: probability- and indicator-weighted regression mean, clipped metrics."""
+    from scripts.zero_inflated import zero_inflated, rmse, mad
+    rs = np.random.RandomState(0)
+    Ytr, Yte = np.abs(rs.randn(50, 1)), np.abs(rs.randn(20, 1))
+    clf = {'pred_train': {'pfmean': rs.rand(50, 1)}, 'pred_test': {'pfmean': rs.rand(20, 1)}}
+    reg = {'pred_train': {'fmean': rs.randn(50, 1)}, 'pred_test': {'fmean': rs.randn(20, 1)}}
+    r = zero_inflated(Ytr, Yte, clf, reg, str(tmp_path))
+    assert np.array_equal(r['pred_test_zi_prob'], clf['pred_test']['pfmean'] * reg['pred_test']['fmean'])
+    assert r['test_zi_indc_reg_rmse'] == rmse((clf['pred_test']['pfmean'] > 0.5) * reg['pred_test']['fmean'], Yte)
+    assert r['train_zi_prob_reg_mae'] == mad(r['pred_train_zi_prob'], Ytr)
+    assert rmse(np.array([-1.0]), np.array([0.0])) == 0.0                # predictions are clipped at 0 before scoring
+    assert os.path.exists(os.path.join(str(tmp_path), 'results_zi.pickle'))
+
+
+def test_classifier_scores_match_sklearn():
+    from scripts.classifier import _scores
+    from sklearn.metrics import accuracy_score, precision_score, recall_score, roc_auc_score
+    rs = np.random.RandomState(1)
+    y = rs.rand(500) > 0.7
+    p = np.clip(0.3 * y + 0.5 * rs.rand(500), 0, 1)
+    p[:20] = 0.5                                                           # ties
+    acc, prec, rec, auc = _scores(p.reshape(-1, 1), y.reshape(-1, 1))
+    assert abs(acc - accuracy_score(y, p > 0.5)) < 1e-15 and abs(prec - precision_score(y, p > 0.5)) < 1e-15
+    assert abs(rec - recall_score(y, p > 0.5)) < 1e-15 and abs(auc - roc_auc_score(y, p)) < 1e-12
