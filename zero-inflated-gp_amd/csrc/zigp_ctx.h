@@ -31,7 +31,8 @@ enum ProfClass { PC_GEMM_A1 = 0, PC_GEMM_A2 = 1, PC_GEMM_H = 2, PC_GEMM_J = 3, P
 
 struct TileList {
   GemmTile* d = nullptr;
-  int n = 0;
+  int n = 0;     // list entries
+  int per = 1;   // entries per workgroup (n is a multiple of it)
 };
 
 // Per-latent (f or g) device state of the dense path

@@ -52,12 +52,14 @@ enum { LAY_KCONTIG = 0,   // A[i*ld + k]   /  B[j*ld + k]
        LAY_MNCONTIG = 1   // A[k*ld + i]   /  B[k*ld + j]
 };
 
-// One entry of the host-built work list (sorted by descending k-extent = LPT order).
+// One entry of the host-built work list.  A workgroup runs GemmArgs::per consecutive entries one after the other (a "unit");
+// entries with kend <= kbeg are padding and are skipped.
 struct GemmTile {
   int bi, bj;        // output tile coordinates (units of 128)
   int kbeg, kend;    // k range in units of BK, applied to every segment
   int slice;         // split-K slice id (selects the partial-output plane), 0 if unused
-  int pad0, pad1, pad2;
+  int kdir;          // +1: BK steps run kbeg -> kend-1, -1: kend-1 -> kbeg (lets the tiles of one column panel walk k in lockstep)
+  int pad1, pad2;
 };
 
 struct GemmSeg { const double* A; const double* B; int64_t lda, ldb; };   // one operand pair
@@ -65,6 +67,7 @@ struct GemmSeg { const double* A; const double* B; int64_t lda, ldb; };   // one
 struct GemmArgs {
   GemmSeg seg[1];
   const GemmTile* tiles;
+  int per;                // list entries per workgroup
   double* C; int64_t ldc; int64_t slice_stride;  // C plane stride for split-K partials
   double alpha;
   const double* kscale;   // KSCALE kernels: B[k][j] is multiplied by kscale[k] (k = global reduction index)
@@ -227,50 +230,22 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   // the 4-base A map costs 3 VGPRs more: used where the B tile is m/n-contiguous (1 base register), not in the K/K kernels
   constexpr bool A_NEWMAP = (BLAY == LAY_MNCONTIG);
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
-  const GemmTile tl = g.tiles[blockIdx.x];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS destinations and wave-level skips stay on the SALU
   const int wm = wave / WNW, wn = wave % WNW;
-  const int64_t row0 = (int64_t)tl.bi * BM, col0 = (int64_t)tl.bj * BN;
-
-  double acc[TMW][TNW][4];
-#pragma unroll
-  for (int a = 0; a < TMW; ++a)
-#pragma unroll
-    for (int b = 0; b < TNW; ++b)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.0;
-
-  const int total = tl.kend - tl.kbeg;       // BK steps of this tile
   const GemmSeg& sg = g.seg[0];
-  uint32_t offA[CHUNKS], offB[CHUNKS];
-  glds_lane_offsets<ALAY, WAVES, A_NEWMAP>(offA, sg.lda, wave, lane);
-  glds_lane_offsets<BLAY, WAVES, false>(offB, sg.ldb, wave, lane);
-  // scalar bases of BK step 0 and their per-step strides (bytes)
-  const int64_t kfirst = (int64_t)tl.kbeg * BK;
-  const char* baseA = (const char*)(sg.A + ((ALAY == LAY_KCONTIG) ? row0 * sg.lda + kfirst : kfirst * sg.lda + row0));
-  const char* baseB = (const char*)(sg.B + ((BLAY == LAY_KCONTIG) ? col0 * sg.ldb + kfirst : kfirst * sg.ldb + col0));
-  const int64_t strideA = (ALAY == LAY_KCONTIG) ? BK * 8 : BK * 8 * sg.lda;
-  const int64_t strideB = (BLAY == LAY_KCONTIG) ? BK * 8 : BK * 8 * sg.ldb;
-  const char* baseS = (const char*)(g.kscale + kfirst);
-
-  auto issue = [&](int it) {
-    double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
-    glds_tile<ALAY, WAVES>(st, baseA + it * strideA, offA, wave);
-    glds_tile<BLAY, WAVES>(st + TILE_DOUBLES, baseB + it * strideB, offB, wave);
-    if (KSCALE) {   // 16 doubles of the scale vector; every wave issues the same 128 B (uniform vmcnt accounting)
-      if (lane < 8)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + (int64_t)it * (BK * 8) + (uint64_t)(16 * lane)),
-                                         (__attribute__((address_space(3))) void*)(st + 2 * TILE_DOUBLES), 16, 0, 0);
-    }
-  };
-  constexpr int GLDS_PER_STAGE = 2 * CHUNKS + (KSCALE ? 1 : 0);
-
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < total) issue(s);
-
-  const int a_i = lane & 3, kq = lane >> 4, b_j = lane & 15;
+  bool ring_used = false;
+  for (int u = 0; u < g.per; ++u) {
+  const GemmTile tl = g.tiles[(int64_t)blockIdx.x * g.per + u];
+  if (tl.kend <= tl.kbeg) continue;                 // padding entry (uniform over the workgroup)
+  if (ring_used) __builtin_amdgcn_s_barrier();      // slower waves may still read the previous tile's last stage
+  ring_used = true;
+  const int64_t row0 = (int64_t)tl.bi * BM, col0 = (int64_t)tl.bj * BN;
+  // Everything derived from the lane id is recomputed per tile from an opaque copy: otherwise the compiler keeps the ~16
+  // address registers alive across the epilogue of the previous tile and spills there.
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  const int a_i = ln & 3, kq = ln >> 4, b_j = ln & 15;
   // per-lane LDS read bases; the (tm, r, tn, ks) parts are compile-time offsets (see header comment)
   // k-contiguous A: granule = (2ks | kq>>1) ^ a_i ^ C(r), C(r) = 4(r&1) + (r>>1)  ->  [(2ks ^ C(r)) & ~3] is a compile-time
   // offset and the low two bits select one of four per-lane bases a_base[x] = ... + 2*((a_i ^ (kq>>1)) ^ x)
@@ -285,6 +260,45 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   for (int ks = 0; ks < 4; ++ks)
     b_base[ks] = (BLAY == LAY_KCONTIG) ? ((wn * WTN + b_j) * 16 + 2 * (((2 * ks) | (kq >> 1)) ^ kswz<false>(b_j)) + (kq & 1))
                                        : (kq * LDMN + wn * WTN + b_j + ks * 4 * LDMN);
+
+  double acc[TMW][TNW][4];
+#pragma unroll
+  for (int a = 0; a < TMW; ++a)
+#pragma unroll
+    for (int b = 0; b < TNW; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.0;
+
+  const int total = tl.kend - tl.kbeg;       // BK steps of this tile
+  uint32_t offA[CHUNKS], offB[CHUNKS];
+  glds_lane_offsets<ALAY, WAVES, A_NEWMAP>(offA, sg.lda, wave, ln);
+  glds_lane_offsets<BLAY, WAVES, false>(offB, sg.ldb, wave, ln);
+  // scalar bases of BK step 0 and their per-step strides (bytes)
+  const int kb0 = (tl.kdir >= 0) ? tl.kbeg : tl.kend - 1;   // k block (units of BK) of BK step 0; step `it` is kb0 + kdir * it
+  const int64_t kfirst = (int64_t)kb0 * BK;
+  const char* baseA = (const char*)(sg.A + ((ALAY == LAY_KCONTIG) ? row0 * sg.lda + kfirst : kfirst * sg.lda + row0));
+  const char* baseB = (const char*)(sg.B + ((BLAY == LAY_KCONTIG) ? col0 * sg.ldb + kfirst : kfirst * sg.ldb + col0));
+  const int64_t kd = (tl.kdir >= 0) ? 1 : -1;
+  const int64_t strideA = kd * ((ALAY == LAY_KCONTIG) ? BK * 8 : BK * 8 * sg.lda);
+  const int64_t strideB = kd * ((BLAY == LAY_KCONTIG) ? BK * 8 : BK * 8 * sg.ldb);
+  const char* baseS = (const char*)(g.kscale + kfirst);
+
+  auto issue = [&](int it) {
+    double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
+    glds_tile<ALAY, WAVES>(st, baseA + it * strideA, offA, wave);
+    glds_tile<BLAY, WAVES>(st + TILE_DOUBLES, baseB + it * strideB, offB, wave);
+    if (KSCALE) {   // 16 doubles of the scale vector; every wave issues the same 128 B (uniform vmcnt accounting)
+      if (ln < 8)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + kd * it * (BK * 8) + (int64_t)(16 * ln)),
+                                         (__attribute__((address_space(3))) void*)(st + 2 * TILE_DOUBLES), 16, 0, 0);
+    }
+  };
+  constexpr int GLDS_PER_STAGE = 2 * CHUNKS + (KSCALE ? 1 : 0);
+
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < total) issue(s);
+
   for (int it = 0; it < total; ++it) {
     // stage `it` must have landed: at most NSTAGE-2 younger stages (8 glds each) may stay in flight
     if (it + NSTAGE - 2 < total) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>();
@@ -295,7 +309,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
     // Triangular structure at wave (64-row) granularity: a wave whose rows cannot touch this BK step of a
     // triangular A, or whose whole 64x64 output lies above the diagonal of a lower-triangular C, issues no MFMAs
     // (it still takes part in staging and barriers; the co-resident workgroup gets the matrix pipe).
-    const int krel = (tl.kbeg + it) * BK - tl.bi * BM;   // k offset of this step relative to the row block
+    const int krel = (kb0 + (int)kd * it) * BK - tl.bi * BM;   // k offset of this step relative to the row block
     bool skip = false;
     if (TRI == TRI_A_LOWER) skip = krel > wm * RW + RW - 1;
     if (TRI == TRI_A_UPPER) skip = krel + BK - 1 < wm * RW;
@@ -351,6 +365,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   e.C = g.C + (int64_t)tl.slice * g.slice_stride; e.ldc = g.ldc; e.alpha = g.alpha;
   e.row0 = row0 + wm * RW; e.col0 = col0 + wn * WTN; e.lane = lane;
   epi(acc, e);
+  }
 }
 
 }  // namespace zigp

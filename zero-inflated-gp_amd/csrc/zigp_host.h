@@ -20,13 +20,13 @@ static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b)
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 template <class F>
-static int get_tiles(zigp_ctx* c, const std::string& key, F build, TileList& out) {
+static int get_tiles(zigp_ctx* c, const std::string& key, F build, TileList& out, int per = 1) {
   auto it = c->tiles.find(key);
   if (it != c->tiles.end()) { out = it->second; return 0; }
   std::vector<GemmTile> v;
   build(v);
   TileList tl;
-  tl.n = (int)v.size();
+  tl.n = (int)v.size(); tl.per = per;
   if (tl.n > 0) {
     ZIGP_HIP(c, hipMalloc((void**)&tl.d, sizeof(GemmTile) * v.size()));
     ZIGP_HIP(c, hipMemcpy(tl.d, v.data(), sizeof(GemmTile) * v.size(), hipMemcpyHostToDevice));
@@ -37,7 +37,7 @@ static int get_tiles(zigp_ctx* c, const std::string& key, F build, TileList& out
 }
 
 static inline GemmTile mk_tile(int bi, int bj, int kbeg, int kend, int slice = 0) {
-  GemmTile t; t.bi = bi; t.bj = bj; t.kbeg = kbeg; t.kend = kend; t.slice = slice; t.pad0 = t.pad1 = t.pad2 = 0; return t;
+  GemmTile t; t.bi = bi; t.bj = bj; t.kbeg = kbeg; t.kend = kend; t.slice = slice; t.kdir = 1; t.pad1 = t.pad2 = 0; return t;
 }
 
 #ifndef ZIGP_WAVES_DEFAULT
@@ -58,7 +58,7 @@ template <int AL, int BL, bool KS, int TRI = TRI_NONE, class EP>
 static int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
   constexpr int WV = WavesFor<AL, BL, KS>::value;
   if (tl.n == 0) return 0;
-  g.tiles = tl.d;
+  g.tiles = tl.d; g.per = tl.per;
   constexpr size_t shm = sizeof(double) * NST * STAGE_DOUBLES;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
@@ -66,7 +66,7 @@ static int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, KS, TRI, WV, EP>), dim3(tl.n), dim3(64 * WV), shm, c->stream, g, ep);
+  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, KS, TRI, WV, EP>), dim3(tl.n / tl.per), dim3(64 * WV), shm, c->stream, g, ep);
   ZIGP_HIP(c, hipGetLastError());
   return 0;
 }
@@ -74,27 +74,59 @@ static int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
 static inline GemmArgs mk_args(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha = 1.0) {
   GemmArgs g;
   g.seg[0].A = A; g.seg[0].B = B; g.seg[0].lda = lda; g.seg[0].ldb = ldb;
-  g.tiles = nullptr; g.C = C; g.ldc = ldc; g.slice_stride = 0; g.alpha = alpha; g.kscale = nullptr;
+  g.tiles = nullptr; g.per = 1; g.C = C; g.ldc = ldc; g.slice_stride = 0; g.alpha = alpha; g.kscale = nullptr;
   return g;
 }
 
 // ------------------------------------------------------------------------------------------------
 // tile lists
 // ------------------------------------------------------------------------------------------------
-// C(Mp x Nc) = W * B, W lower triangular: row block bi needs k blocks [0, bi]; heavy tiles first.
-static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl) {
-  return get_tiles(c, "trl:" + std::to_string(nbm) + ":" + std::to_string(nbn), [&](std::vector<GemmTile>& v) {
-    for (int bi = nbm - 1; bi >= 0; --bi)
-      for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, (bi + 1) * (BM / BK)));
-  }, tl);
+// Triangular products C(Mp x Nc) = T * B.  Row block bi of a lower-triangular T needs the k blocks [0, bi], of an upper-triangular
+// one (W^T) the k blocks [bi, nbm).
+// Default: one tile per workgroup, longest tiles first (LPT), tiles of one column panel on one XCD (launch position p runs on
+// XCD p % 8).  PMC: the B panel is fetched from HBM once per row block (1.18 GB per launch at M = 1024, Nc = 32768 for 0.27 GB
+// of operand) -- the tiles of a panel start at different times, so that XCD's L2 never sees them together.
+// -DZIGP_TRMM_PAIRED: work unit = one workgroup = two tiles of the same column panel, a short one (u+1 k blocks) and its
+// complement (nbm-u), so every unit runs nbm+1 k blocks; the units of a panel are consecutive entries of one XCD's queue and
+// walk k in lockstep (lower: short tiles ascend from k block 0, long tiles descend so that block-step t reads k block nbm - t
+// in every unit; upper: the mirror image).  PMC: 0.55 GB fetched per launch (2.2x less); measured 1 % SLOWER per step (same-box
+// A/B, five orderings tried, profiles/r01f_*): HBM traffic is not what limits these kernels, and equal-length units lose
+// the staggering of the LPT order.  Kept as a build option for a part with less HBM headroom.
+static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, TileList& tl) {
+  const int kb = BM / BK;
+  const std::string key = std::string(lower ? "trl:" : "tru:") + std::to_string(nbm) + ":" + std::to_string(nbn);
+#ifndef ZIGP_TRMM_PAIRED
+  return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
+    if (lower) { for (int bi = nbm - 1; bi >= 0; --bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, (bi + 1) * kb)); }
+    else { for (int bi = 0; bi < nbm; ++bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * kb, nbm * kb)); }
+  }, tl, 1);
+#else
+  return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
+    const int U = (nbm + 1) / 2;
+    auto tile = [&](int bi, int bj, int dir) {
+      GemmTile t = lower ? mk_tile(bi, bj, 0, (bi + 1) * kb) : mk_tile(bi, bj, bi * kb, nbm * kb);
+      t.kdir = dir;
+      return t;
+    };
+    std::vector<GemmTile> q[8];   // per-XCD queues of units (2 entries each)
+    for (int bj = 0; bj < nbn; ++bj)
+      for (int u = 0; u < U; ++u) {
+        const int lo = u, hi = nbm - 1 - u;                 // lo has the short k range for lower, hi for upper
+        std::vector<GemmTile>& dst = q[bj % 8];
+        if (lo == hi) { dst.push_back(tile(lo, bj, lower ? -1 : 1)); dst.push_back(mk_tile(0, 0, 0, 0)); continue; }
+        if (lower) { dst.push_back(tile(lo, bj, 1)); dst.push_back(tile(hi, bj, -1)); }
+        else { dst.push_back(tile(hi, bj, -1)); dst.push_back(tile(lo, bj, 1)); }
+      }
+    size_t longest = 0;
+    for (int x = 0; x < 8; ++x) longest = std::max(longest, q[x].size());
+    for (size_t e0 = 0; e0 < longest; e0 += 2)               // launch position p = 8 * (e0 / 2) + x  ->  XCD x
+      for (int x = 0; x < 8; ++x)
+        for (int e = 0; e < 2; ++e) v.push_back(e0 + e < q[x].size() ? q[x][e0 + e] : mk_tile(0, 0, 0, 0));
+  }, tl, 2);
+#endif
 }
-// C = W^T * B: row block bi needs k blocks [bi, nbm)
-static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl) {
-  return get_tiles(c, "tru:" + std::to_string(nbm) + ":" + std::to_string(nbn), [&](std::vector<GemmTile>& v) {
-    for (int bi = 0; bi < nbm; ++bi)
-      for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * (BM / BK), nbm * (BM / BK)));
-  }, tl);
-}
+static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl) { return tiles_trmm(c, true, nbm, nbn, tl); }
+static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl) { return tiles_trmm(c, false, nbm, nbn, tl); }
 // lower-triangular output tiles x S split-K slices over nk k-steps.  Launch position p runs on XCD p % 8 (observed round-robin
 // dispatch; speed only): XCD x is handed a contiguous run of the slice-major tile order, so the tiles that re-read the same
 // column slice of the panels share one L2 instead of eight.
