@@ -126,6 +126,15 @@ int zigp_kron_elbo(zigp_ctx* ctx, const zigp_kron_params* p, const double* X, co
 int zigp_kron_predict(zigp_ctx* ctx, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter,
                       double g_offset, double* out9);
 
+/* Mean function of the latent f: m(x) = b + a . x, added to fmean before the likelihood and in zigp_predict
+ * (`fmean = fmean + self.mean_function(Xnew)`, onoffgpf/OnOffSVGP.py:29,134).  Covers GPflow's Zero (the reference default:
+ * D = 0, b = 0 -- the state after zigp_create), Constant (D = 0, b = c) and Linear with one output (a[D], b).  The setting
+ * persists in the context.  zigp_get_mean_function_grad returns d(scale * sum var_exp)/d(a, b) of the LAST zigp_elbo
+ * called with grads != NULL (zeros when the mean function is off); like the other gradients it is a per-shard partial
+ * sum under data-parallel use. */
+int zigp_set_mean_function(zigp_ctx* ctx, const double* a, int32_t D, double b);
+int zigp_get_mean_function_grad(zigp_ctx* ctx, double* da, int32_t D, double* db);
+
 /* Single-latent heads on the same Kronecker conditional -- the reference's baselines, which re-use kron_inf and
  * GaussKLkron with one latent f:
  *   ZIGP_LIK_GAUSSIAN   scripts/svgp.py:127-200,207-233 and scripts/hurdle.py:127-252 (regression; noise variance)

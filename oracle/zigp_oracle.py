@@ -128,8 +128,20 @@ def variational_expectations(Fmu, Fvar, Fmuvar, Y, noise_variance):
 # a5  build_predict -- onoffgpf/OnOffSVGP.py:124-152 (zero mean function :134);
 #     g_offset reproduces the `gmean - 1` prediction quirk of onofftf/onoffpred.py:141
 # --------------------------------------------------------------------------
+def mean_function(Xnew, p):
+    """self.mean_function(Xnew), OnOffSVGP.py:29,134.  GPflow 0.4 mean functions with one output: Zero (default) -> 0,
+    Constant(c) -> c, Linear(A, b) -> X A + b; here p['mean_a'] (D,) and p['mean_b'] (scalar), both optional."""
+    m = np.zeros((Xnew.shape[0], 1))
+    if p.get('mean_a') is not None:
+        m = m + np.matmul(Xnew, np.asarray(p['mean_a'], dtype=np.float64).reshape(-1, 1))
+    if p.get('mean_b') is not None:
+        m = m + float(np.squeeze(p['mean_b']))
+    return m
+
+
 def build_predict(Xnew, p, jitter, g_offset=0.0):
     fmean, fvar = conditional(Xnew, p['Zf'], p['ell_f'], p['var_f'], p['u_fm'], p['u_fs_sqrt'], jitter)
+    fmean = fmean + mean_function(Xnew, p)                              # :134
     gmean, gvar = conditional(Xnew, p['Zg'], p['ell_g'], p['var_g'], p['u_gm'], p['u_gs_sqrt'], jitter)
     gmean = gmean + g_offset
     ephi_g, ephi2_g, evar_phi_g = probit_expectations(gmean, gvar)

@@ -82,6 +82,10 @@ def variational_expectations(Fmu, Fvar, Fmuvar, Y, noise):
 def data_term(X, Y, p, jitter, g_offset=0.0):
     """sum_n var_exp_n over the rows of X (onoffgpf/OnOffSVGP.py:113-116,124-152)."""
     fmean, fvar = conditional(X, p['Zf'], p['ell_f'], p['var_f'], p['u_fm'], p['u_fs_sqrt'], jitter)
+    if 'mean_a' in p:                                                   # fmean + self.mean_function(Xnew), OnOffSVGP.py:134
+        fmean = fmean + torch.matmul(X, p['mean_a'].reshape(-1, 1))
+    if 'mean_b' in p:
+        fmean = fmean + p['mean_b']
     gmean, gvar = conditional(X, p['Zg'], p['ell_g'], p['var_g'], p['u_gm'], p['u_gs_sqrt'], jitter)
     gmean = gmean + g_offset
     e1, e2, ev = probit_expectations(gmean, gvar)
@@ -95,8 +99,12 @@ def prior_kl(p, jitter):
     return gauss_kl_diag(p['u_fm'], p['u_fs_sqrt'], Kf) + gauss_kl_diag(p['u_gm'], p['u_gs_sqrt'], Kg)
 
 
+MEAN_KEYS = ('mean_a', 'mean_b')   # optional mean function of f: m(x) = mean_b + mean_a . x
+
+
 def make_leaves(p_np):
-    return {k: _t(p_np[k]).clone().requires_grad_(True) for k in PARAM_KEYS}
+    keys = PARAM_KEYS + tuple(k for k in MEAN_KEYS if p_np.get(k) is not None)
+    return {k: _t(p_np[k]).clone().requires_grad_(True) for k in keys}
 
 
 def elbo_and_grad(X, Y, p_np, jitter, scale=1.0, g_offset=0.0, chunk=20000, include_kl=True, need_grad=True):
@@ -125,7 +133,7 @@ def elbo_and_grad(X, Y, p_np, jitter, scale=1.0, g_offset=0.0, chunk=20000, incl
             with torch.no_grad():
                 k = prior_kl(p, jitter)
         kl = float(k.detach())
-    grads = {k: (p[k].grad.numpy().copy() if p[k].grad is not None else np.zeros(tuple(p[k].shape))) for k in PARAM_KEYS} \
+    grads = {k: (p[k].grad.numpy().copy() if p[k].grad is not None else np.zeros(tuple(p[k].shape))) for k in p} \
         if need_grad else None
     return data * scale - kl, data, kl, grads
 

@@ -211,3 +211,46 @@ def test_empty_row_range_gives_minus_kl_gradient(engine):
         a, b = np.asarray(g[key]).reshape(-1), P[key].grad.numpy().reshape(-1)
         assert np.max(np.abs(a - b)) <= 1e-7 * max(np.max(np.abs(b)), 1e-300), key
     assert g['noise'] == 0.0
+
+
+# ---- mean function of f (onoffgpf/OnOffSVGP.py:29,134): Zero / Constant / Linear as m(x) = b + a . x ------------------
+@pytest.mark.parametrize('kind', ['constant', 'linear'])
+def test_mean_function_matches_oracle(engine, kind):
+    import zigp_oracle as o
+    import zigp_oracle_torch as ot
+    N, M, D = 3000, 96, 3
+    X, Y, p = make_problem(N, M, D, seed=21, ell=0.35)
+    p = dict(p, mean_b=0.37)
+    if kind == 'linear':
+        p['mean_a'] = np.array([0.5, -0.25, 0.125])
+    engine.set_chunk(1024)            # several chunks: the per-block partial sums accumulate across them
+    engine.set_data(X, Y)
+    ed, kl, g = engine.elbo(p, jitter=1e-6, scale=1.7)
+    e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X, Y, p, 1e-6, scale=1.7)
+    assert abs(ed - 1.7 * d_r) <= 1e-8 * abs(1.7 * d_r) and abs(kl - kl_r) <= 1e-8 * abs(kl_r)
+    keys = ['Zf', 'u_fm', 'u_gm', 'u_fs_sqrt', 'ell_f', 'var_f', 'noise', 'mean_b'] + (['mean_a'] if kind == 'linear' else [])
+    for k in keys:
+        a, b = np.asarray(g[k], dtype=float).reshape(-1), np.asarray(g_r[k], dtype=float).reshape(-1)
+        e = np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+        print('mean function %s: grad %s relerr %.2e' % (kind, k, e))
+        assert e < 1e-6, (k, e)       # tolerance 1e-6 relative, fp64
+    out = engine.predict(p, X[:500], jitter=1e-6)
+    ref = o.build_predict(X[:500], p, 1e-6)
+    for i in range(9):
+        assert relerr(out[i], ref[i].reshape(-1)) < 1e-7, i
+    # the offset really is in: without the mean function the value differs, and the setting does not leak into the next call
+    p0 = {k: v for k, v in p.items() if not k.startswith('mean_')}
+    ed0, _, g0 = engine.elbo(p0, jitter=1e-6, scale=1.7)
+    assert abs(ed0 - ed) > 1e-3 * abs(ed) and 'mean_b' not in g0
+    _, d0_r, _, _ = ot.elbo_and_grad(X, Y, p0, 1e-6, scale=1.7, need_grad=False)
+    assert abs(ed0 - 1.7 * d0_r) <= 1e-8 * abs(1.7 * d0_r)
+    engine.set_chunk(32768)
+
+
+def test_mean_function_bad_arguments(engine):
+    X, Y, p = make_problem(200, 16, 2, seed=3)
+    engine.set_data(X, Y)
+    with pytest.raises(ValueError):
+        engine.elbo(dict(p, mean_a=np.ones(3)))
+    with pytest.raises(ValueError):
+        engine.elbo(dict(p, mean_b=float('nan')))

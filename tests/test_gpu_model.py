@@ -79,3 +79,32 @@ def test_minibatch_scale_and_adam():
     assert len(set(e)) == 3                      # different minibatches
     m.optimize(method='adam', maxiter=50, learning_rate=0.01)
     assert np.isfinite(m.compute_log_likelihood())
+
+
+def test_mean_function_model_surface(engine):
+    """OnOffSVGP(mean_function=Constant/Linear): trainable through optimize(), shifts fmean in predict_onoffgp (OnOffSVGP.py:134)."""
+    import onoffgpf
+    from onoffgpf import OnOffSVGP, OnOffLikelihood
+    from onoffgpf.mean_functions import Constant, Linear, Zero
+    rs = np.random.RandomState(0)
+    X = rs.rand(400, 1) * 10
+    Y = np.where(np.sin(X) > 0, 3.0 + 0.5 * X + 0.1 * rs.randn(400, 1), 0.0)
+    Z = np.linspace(0.5, 9.5, 12)[:, None]
+
+    def mk(mf):
+        np.random.seed(1)
+        return OnOffSVGP(X, Y, kernf=onoffgpf.kernels.RBF(1, lengthscales=2.0), kerng=onoffgpf.kernels.RBF(1, lengthscales=2.0, variance=5.0),
+                         likelihood=OnOffLikelihood(), Zf=Z, Zg=Z.copy(), mean_function=mf)
+    m0, mc, ml = mk(None), mk(Constant(2.0)), mk(Linear(np.array([[0.5]]), 3.0))
+    assert isinstance(m0.mean_function, Zero)
+    f0, fc, fl = m0.predict_onoffgp(X)[3], mc.predict_onoffgp(X)[3], ml.predict_onoffgp(X)[3]
+    assert np.allclose(fc - f0, 2.0, atol=1e-10) and np.allclose(fl - f0, 3.0 + 0.5 * X, atol=1e-10)
+    assert np.allclose(ml.mean_function(X), 3.0 + 0.5 * X)
+    e_before = mc.compute_log_likelihood()
+    c_before = float(mc.mean_function.c.value[0])
+    mc.optimize(maxiter=25)
+    assert mc.compute_log_likelihood() > e_before and float(mc.mean_function.c.value[0]) != c_before
+    ml.optimize(maxiter=25)
+    assert ml.mean_function.A.value.shape == (1, 1) and np.isfinite(ml.compute_log_likelihood())
+    with pytest.raises(TypeError):
+        mk(lambda x: 0 * x)

@@ -70,6 +70,9 @@ struct zigp_ctx {
   // dense path state
   zigp::Latent lat[2];
   zigp::DevBuf pw_part;                 // pointwise block partials
+  // mean function of f, m(x) = mean_b + mean_a . x (zigp_set_mean_function), and its gradient from the last zigp_elbo
+  bool mean_on = false;
+  double mean_a[8] = {0}, mean_b = 0.0, mean_da[8] = {0}, mean_db = 0.0;   // 8 = zigp::MAXD (zigp_kernels.h)
   zigp::DevBuf out9;                    // predict outputs (9,Nc)
   zigp::DevBuf scratch, scratch2;       // misc
   int* d_info = nullptr;

@@ -309,8 +309,8 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   const int64_t span = has_rows ? (row_end - row_begin) : 0;
   if (span < Nc) Nc = std::max<int64_t>(1024, round_up(span, 1024));
   const int pw_blocks = (int)(Nc / PW_THREADS);
-  ZIGP_ENSURE(c, c->pw_part, (size_t)pw_blocks * 4);
-  ZIGP_HIP(c, hipMemsetAsync(c->pw_part.p, 0, sizeof(double) * pw_blocks * 4, c->stream));
+  ZIGP_ENSURE(c, c->pw_part, (size_t)pw_blocks * PW_ACC);
+  ZIGP_HIP(c, hipMemsetAsync(c->pw_part.p, 0, sizeof(double) * pw_blocks * PW_ACC, c->stream));
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
     const int Mp = lt.Mp;
@@ -340,6 +340,8 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
       a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32; a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
       a.var_f = p->var_f; a.var_g = p->var_g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
       a.gm_f = need_grad ? c->lat[0].gm.p : nullptr; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
+      a.X = dX; a.D = D; a.mean_on = c->mean_on ? 1 : 0; a.mean_b = c->mean_b;
+      for (int d = 0; d < MAXD; ++d) a.mean_a[d] = (d < D) ? c->mean_a[d] : 0.0;
       a.acc = c->pw_part.p; a.out9 = d_out9 ? d_out9 - row_begin : nullptr; a.ld9 = row_end - row_begin;
       const int nblk = (int)(Nc / PW_THREADS);
       if (predict) hipLaunchKernelGGL(k_pointwise<true>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
@@ -363,7 +365,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   }
 
   // ---- gather results on the host (fixed-order final sums) ----
-  std::vector<double> hpw((size_t)pw_blocks * 4);
+  std::vector<double> hpw((size_t)pw_blocks * PW_ACC);
   ZIGP_HIP(c, hipMemcpyAsync(hpw.data(), c->pw_part.p, sizeof(double) * hpw.size(), hipMemcpyDeviceToHost, c->stream));
   std::vector<double> hvec[2], hdu[2], hdsq[2], hkrow[2];
   for (int h = 0; h < 2; ++h) {
@@ -382,7 +384,14 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
   double s_ve = 0, s_dn = 0, s_gvf = 0, s_gvg = 0;
-  for (int b = 0; b < pw_blocks; ++b) { s_ve += hpw[4 * b]; s_dn += hpw[4 * b + 1]; s_gvf += hpw[4 * b + 2]; s_gvg += hpw[4 * b + 3]; }
+  for (int b = 0; b < pw_blocks; ++b) { s_ve += hpw[PW_ACC * b]; s_dn += hpw[PW_ACC * b + 1]; s_gvf += hpw[PW_ACC * b + 2]; s_gvg += hpw[PW_ACC * b + 3]; }
+  c->mean_db = 0.0;
+  for (int d = 0; d < MAXD; ++d) c->mean_da[d] = 0.0;
+  if (c->mean_on)
+    for (int b = 0; b < pw_blocks; ++b) {
+      c->mean_db += hpw[PW_ACC * b + 4];
+      for (int d = 0; d < D; ++d) c->mean_da[d] += hpw[PW_ACC * b + 5 + d];
+    }
   if (elbo_data) *elbo_data = s_ve;
   double klsum = 0.0;
   if (include_kl) klsum = hvec[0][3 * c->lat[0].Mp] + hvec[1][3 * c->lat[1].Mp];
@@ -491,6 +500,28 @@ int zigp_set_chunk(zigp_ctx* c, int64_t chunk_rows) {
   if (chunk_rows < 1024 || chunk_rows % 1024 != 0) return fail_arg(c, "chunk must be a positive multiple of 1024");
   if (chunk_rows > (1 << 20)) return fail_arg(c, "chunk must be <= 1048576 rows (32-bit staging offsets; 5 panels of 8*M*chunk bytes per latent)");
   c->chunk = chunk_rows;
+  return ZIGP_OK;
+}
+
+static_assert(MAXD == 8, "zigp_ctx::mean_a / mean_da hold MAXD entries");
+
+int zigp_set_mean_function(zigp_ctx* c, const double* a, int32_t D, double b) {
+  if (!c) return ZIGP_EARG;
+  if (D < 0 || D > MAXD || (D > 0 && !a)) return fail_arg(c, "zigp_set_mean_function: need 0 <= D <= 8 and a[D]");
+  if (!std::isfinite(b)) return fail_arg(c, "zigp_set_mean_function: b must be finite");
+  for (int d = 0; d < D; ++d)
+    if (!std::isfinite(a[d])) return fail_arg(c, "zigp_set_mean_function: a must be finite");
+  for (int d = 0; d < MAXD; ++d) c->mean_a[d] = (d < D) ? a[d] : 0.0;
+  c->mean_b = b;
+  c->mean_on = (D > 0) || (b != 0.0);   // D = 0, b = 0 is GPflow's Zero: the point-wise kernel skips the term
+  return ZIGP_OK;
+}
+
+int zigp_get_mean_function_grad(zigp_ctx* c, double* da, int32_t D, double* db) {
+  if (!c) return ZIGP_EARG;
+  if (D < 0 || D > MAXD || (D > 0 && !da)) return fail_arg(c, "zigp_get_mean_function_grad: need 0 <= D <= 8 and da[D]");
+  for (int d = 0; d < D; ++d) da[d] = c->mean_da[d];
+  if (db) *db = c->mean_db;
   return ZIGP_OK;
 }
 

@@ -94,10 +94,14 @@ struct PwArgs {
   const double* Y; int64_t n0, row_end, Nc;
   double var_f, var_g, noise, g_offset, scale;
   double* gm_f; double* gv_f; double* gm_g; double* gv_g;
-  double* acc;      // [gridDim.x][4] running sums: var_exp, dnoise, sum gv_f, sum gv_g
+  double* acc;      // [gridDim.x][PW_ACC] running sums: var_exp, dnoise, sum gv_f, sum gv_g, then (mean function on) sum gm_f, sum gm_f x_d
+  // mean function of f, m(x) = mean_b + mean_a . x  (self.mean_function(Xnew), OnOffSVGP.py:134; Zero / Constant / Linear)
+  const double* X; int D; int mean_on; double mean_a[MAXD]; double mean_b;
   double* out9;     // predict: (9, ld9)
   int64_t ld9;
 };
+
+constexpr int PW_ACC = 5 + MAXD;
 
 struct PwOut { double gfmean, gfvar, gfmeanu, e1, e2, ev; double dfm, dfv, dgm, dgv, ve, dnoise; };
 
@@ -161,6 +165,16 @@ k_pointwise(PwArgs p) {
   const double fv = p.var_f - fsq + fs2, gvr = p.var_g - gsq + gs2;   // main.py:278,302
   gmn += p.g_offset;
   const bool valid = (p.n0 + n) < p.row_end;
+  double xs[MAXD];
+  if (p.mean_on) {
+    double m = p.mean_b;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) {
+      xs[d] = (d < p.D && valid) ? p.X[(p.n0 + n) * p.D + d] : 0.0;
+      m = fma(p.mean_a[d], xs[d], m);
+    }
+    fm += m;
+  }
   const double y = (valid && p.Y) ? p.Y[p.n0 + n] : 0.0;
   PwOut o = pointwise_eval(fm, fv, gmn, gvr, y, p.noise);
   if (PREDICT) {
@@ -181,8 +195,17 @@ k_pointwise(PwArgs p) {
   double s2 = block_sum<4>(sc * o.dfv, sh);
   double s3 = block_sum<4>(sc * o.dgv, sh);
   if (threadIdx.x == 0) {
-    double* a = p.acc + (int64_t)blockIdx.x * 4;
+    double* a = p.acc + (int64_t)blockIdx.x * PW_ACC;
     a[0] += s0; a[1] += s1; a[2] += s2; a[3] += s3;
+  }
+  if (p.mean_on) {   // d/d mean_b = sum gm_f, d/d mean_a[d] = sum gm_f x_d
+    const double gmf = sc * o.dfm;
+    double sb = block_sum<4>(gmf, sh);
+    if (threadIdx.x == 0) p.acc[(int64_t)blockIdx.x * PW_ACC + 4] += sb;
+    for (int d = 0; d < p.D; ++d) {
+      double sa = block_sum<4>(gmf * xs[d], sh);
+      if (threadIdx.x == 0) p.acc[(int64_t)blockIdx.x * PW_ACC + 5 + d] += sa;
+    }
   }
 }
 

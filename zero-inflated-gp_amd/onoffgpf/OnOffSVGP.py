@@ -4,7 +4,8 @@ Same constructor signature, attributes and methods the reference exposes / its n
   OnOffSVGP(X, Y, kernf, kerng, likelihood, Zf, Zg, mean_function=None, minibatch_size=None, name='model')
   .optimize(maxiter=...)  .compute_log_likelihood()  .predict_onoffgp(Xnew)  .compute_prior_KL()  .savemodel(fname)
   .Xtrain .Ytrain .Zf .Zg .u_fm .u_gm .u_fs_sqrt .u_gs_sqrt .kernf .kerng .likelihood.variance
-whiten=False and q_diag=True are hard-coded in the reference (:33-34); only the Zero mean function (:29) is supported.
+whiten=False and q_diag=True are hard-coded in the reference (:33-34).  mean_function (:29,134): onoffgpf.mean_functions.Zero
+(default), Constant or Linear -- evaluated, and differentiated, inside the engine's point-wise kernel.
 """
 import pickle
 import time
@@ -16,6 +17,7 @@ import zigp
 from zigp.optim import ParamSet, lbfgsb, AdamGroups
 from zigp.transforms import positive
 from .param import Param, DataHolder, Parameterized
+from .mean_functions import MeanFunction, Zero
 
 JITTER = 1e-6   # gpflow settings.numerics.jitter_level default (OnOffSVGP.py:96-97) [GPflow-recall]
 
@@ -23,8 +25,9 @@ JITTER = 1e-6   # gpflow settings.numerics.jitter_level default (OnOffSVGP.py:96
 class OnOffSVGP(Parameterized):
     def __init__(self, X, Y, kernf, kerng, likelihood, Zf, Zg, mean_function=None, minibatch_size=None, name='model',
                  device=0):
-        if mean_function is not None:
-            raise NotImplementedError('only the Zero mean function of the reference default is supported')
+        self.mean_function = mean_function or Zero()                 # :29
+        if not isinstance(self.mean_function, MeanFunction):
+            raise TypeError('mean_function must be an onoffgpf.mean_functions.{Zero, Constant, Linear}')
         X, Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
         if Y.ndim != 2 or Y.shape[1] != 1:
             raise ValueError('Y must be (N,1): num_latent is 1 (OnOffSVGP.py:45)')
@@ -51,10 +54,13 @@ class OnOffSVGP(Parameterized):
             ('Zf', self.Zf), ('Zg', self.Zg), ('u_fm', self.u_fm), ('u_gm', self.u_gm),
             ('u_fs_sqrt', self.u_fs_sqrt), ('u_gs_sqrt', self.u_gs_sqrt),
             ('ell_f', self.kernf.lengthscales), ('ell_g', self.kerng.lengthscales),
-            ('var_f', self.kernf.variance), ('var_g', self.kerng.variance), ('noise', self.likelihood.variance)]))
+            ('var_f', self.kernf.variance), ('var_g', self.kerng.variance), ('noise', self.likelihood.variance)]
+            + list(self.mean_function.trainables().items())))
 
     def _values(self):
-        return dict(Zf=self.Zf.value, Zg=self.Zg.value, u_fm=self.u_fm.value, u_gm=self.u_gm.value,
+        a, b = self.mean_function.linear_form(self.Xtrain.value.shape[1])
+        mf = {k: v for k, v in (('mean_a', a), ('mean_b', b)) if v is not None}
+        return dict(mf, Zf=self.Zf.value, Zg=self.Zg.value, u_fm=self.u_fm.value, u_gm=self.u_gm.value,
                     u_fs_sqrt=self.u_fs_sqrt.value, u_gs_sqrt=self.u_gs_sqrt.value,
                     ell_f=self.kernf.ell_vector(), ell_g=self.kerng.ell_vector(),
                     var_f=float(self.kernf.variance.value.reshape(-1)[0]), var_g=float(self.kerng.variance.value.reshape(-1)[0]),
@@ -68,6 +74,8 @@ class OnOffSVGP(Parameterized):
                 out[k] = np.array([np.sum(g[k])])
         for k in ('var_f', 'var_g', 'noise'):
             out[k] = np.array([g[k]])
+        if 'mean_b' in g:
+            out['mean_b'] = np.array([g['mean_b']])
         return out
 
     def _load_batch(self):
@@ -138,6 +146,7 @@ class OnOffSVGP(Parameterized):
 
     def __setstate__(self, d):
         self.__dict__.update(d)
+        self.__dict__.setdefault('mean_function', Zero())
         self.__dict__['_engine'] = zigp.DenseEngine(0)
 
     @staticmethod

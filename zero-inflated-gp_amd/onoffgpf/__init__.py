@@ -3,5 +3,6 @@ No GPflow, no TensorFlow: the graph is replaced by libzigp.so (include/zigp.h)."
 from .OnOffSVGP import OnOffSVGP
 from .OnOffLikelihood import OnOffLikelihood
 from . import kernels
+from . import mean_functions
 
-__all__ = ['OnOffSVGP', 'OnOffLikelihood', 'kernels']
+__all__ = ['OnOffSVGP', 'OnOffLikelihood', 'kernels', 'mean_functions']

@@ -104,6 +104,7 @@ class DenseEngine:
     def elbo(self, p, jitter=1e-6, scale=1.0, g_offset=0.0, rows=None, include_kl=True, need_grad=True):
         """Returns (elbo_data, kl, grads or None); ELBO = elbo_data - kl."""
         pk = _Packed(p)
+        mean_D = self._set_mean_function(p, pk.D)
         r0, r1 = (0, self.N) if rows is None else rows
         ed, kl = C.c_double(0), C.c_double(0)
         gs, g = None, None
@@ -118,11 +119,30 @@ class DenseEngine:
         _check(self.lib, self.ctx, rc)
         if need_grad:
             g['var_f'], g['var_g'], g['noise'] = gs.var_f, gs.var_g, gs.noise
+            if mean_D is not None:
+                da, db = np.zeros(max(mean_D, 1)), C.c_double(0)
+                _check(self.lib, self.ctx, self.lib.zigp_get_mean_function_grad(self.ctx, ptr(da), mean_D, C.byref(db)))
+                g['mean_a'], g['mean_b'] = da[:mean_D], db.value
         return ed.value, kl.value, g
+
+    def _set_mean_function(self, p, D):
+        """p may carry the mean function of f, m(x) = mean_b + mean_a . x (OnOffSVGP.py:29,134): 'mean_b' alone is GPflow's
+        Constant, 'mean_a' (+ 'mean_b') its Linear; neither is Zero.  Returns len(mean_a) when one is set, else None."""
+        a, b = p.get('mean_a'), p.get('mean_b')
+        if a is None and b is None:
+            _check(self.lib, self.ctx, self.lib.zigp_set_mean_function(self.ctx, None, 0, 0.0))
+            return None
+        a = np.zeros(0) if a is None else as_f64(a).reshape(-1)
+        if a.size not in (0, D):
+            raise ValueError('mean_a must have D entries')
+        _check(self.lib, self.ctx, self.lib.zigp_set_mean_function(self.ctx, ptr(a) if a.size else None, a.size,
+                                                                    float(np.squeeze(0.0 if b is None else b))))
+        return a.size
 
     def predict(self, p, Xnew, jitter=1e-6, g_offset=0.0):
         """(9,N) array in the order of OnOffSVGP.build_predict (onoffgpf/OnOffSVGP.py:152)."""
         pk = _Packed(p)
+        self._set_mean_function(p, pk.D)
         Xnew = as_f64(Xnew)
         if Xnew.ndim != 2 or Xnew.shape[1] != pk.D:
             raise ValueError('Xnew must be (N,%d)' % pk.D)

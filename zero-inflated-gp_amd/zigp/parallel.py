@@ -18,12 +18,15 @@ def shard_bounds(n_rows, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+OPTIONAL_KEYS = ('mean_a', 'mean_b')   # present when a mean function is set (zigp_set_mean_function)
+
+
 def pack(elbo_data, kl, grads):
     parts = [np.array([elbo_data, kl], dtype=np.float64)]
     shapes = []
-    for k in GRAD_KEYS:
+    for k in GRAD_KEYS + tuple(k for k in OPTIONAL_KEYS if k in grads):
         a = np.asarray(grads[k], dtype=np.float64)
-        shapes.append(a.shape)
+        shapes.append((k, a.shape))
         parts.append(a.reshape(-1))
     return np.concatenate(parts), shapes
 
@@ -31,7 +34,7 @@ def pack(elbo_data, kl, grads):
 def unpack(vec, shapes):
     elbo_data, kl = float(vec[0]), float(vec[1])
     g, o = {}, 2
-    for k, sh in zip(GRAD_KEYS, shapes):
+    for k, sh in shapes:
         n = int(np.prod(sh)) if len(sh) else 1
         g[k] = vec[o:o + n].reshape(sh) if len(sh) else float(vec[o])
         o += n
