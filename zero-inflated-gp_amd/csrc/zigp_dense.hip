@@ -80,7 +80,7 @@ int latent_kl(zigp_ctx* c, Latent& lt) {
   ZIGP_ENSURE(c, lt.vec, (size_t)4 * Mp + 8);
   double* v = lt.vec.p; double* alpha = v + Mp; double* dkinv = v + 2 * Mp; double* klv = v + 3 * Mp;
   hipLaunchKernelGGL(k_gemv_rows, dim3(Mp), dim3(256), 0, c->stream, lt.W.p, lt.u.p, (int64_t)Mp, v);
-  hipLaunchKernelGGL(k_kl_cols, dim3(ceil_div(Mp, 64)), dim3(64), 0, c->stream, lt.W.p, v, (int64_t)Mp, alpha, dkinv);
+  hipLaunchKernelGGL(k_kl_cols, dim3(Mp / 64), dim3(64, COL_LANES), 0, c->stream, lt.W.p, v, (int64_t)Mp, alpha, dkinv);
   hipLaunchKernelGGL(k_kl_value, dim3(1), dim3(256), 0, c->stream, v, lt.L.p, lt.s.p, dkinv, lt.M, (int64_t)Mp, klv);
   ZIGP_HIP(c, hipGetLastError());
   return 0;
@@ -192,7 +192,7 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
       hipLaunchKernelGGL(k_gather, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.krow.p, 2 + 2 * D, 1 + 2 * D, Mp, KG_SPLIT,
                          (int64_t)Mp * (2 + 2 * D), kgm);
       hipLaunchKernelGGL(k_gemv_rows, dim3(Mp), dim3(256), 0, c->stream, lt.W.p, kgm, (int64_t)Mp, lt.a1gm.p);
-      hipLaunchKernelGGL(k_gemv_cols, dim3(ceil_div(Mp, 64)), dim3(64), 0, c->stream, lt.W.p, lt.a1gm.p, (int64_t)Mp, lt.du.p);
+      hipLaunchKernelGGL(k_gemv_cols, dim3(Mp / 64), dim3(64, COL_LANES), 0, c->stream, lt.W.p, lt.a1gm.p, (int64_t)Mp, lt.du.p);
     }
     // C1 = sym(sum_s planes) -> T1
     hipLaunchKernelGGL(k_sym_from_planes, dim3(gridmm), dim3(256), 0, c->stream, lt.dLpart.p, syr_slices(nb), (int64_t)Mp, lt.T1.p);
@@ -202,7 +202,7 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
         for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, nb * kb));
     }, td));
     ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, td, mk_args(lt.T1.p, Mp, lt.W.p, Mp, lt.T3.p, Mp), EpiStore())));
-    hipLaunchKernelGGL(k_coldot, dim3(ceil_div(Mp, 64)), dim3(64), 0, c->stream, lt.W.p, lt.T3.p, (int64_t)Mp, lt.dsq.p);
+    hipLaunchKernelGGL(k_coldot, dim3(Mp / 64), dim3(64, COL_LANES), 0, c->stream, lt.W.p, lt.T3.p, (int64_t)Mp, lt.dsq.p);
     // T = (W diag(s^2)) W^T -> T2   (both factors lower triangular: k <= min(i,j))
     ZIGP_TRY(get_tiles(c, "bw_tt:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
       for (int bi = 0; bi < nb; ++bi)

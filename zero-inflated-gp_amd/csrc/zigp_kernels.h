@@ -375,34 +375,61 @@ __global__ void k_gather(const double* __restrict__ src, int stride, int off, in
   for (int sp = 0; sp < nslab; ++sp) a += src[(int64_t)sp * slab + (int64_t)i * stride + off];
   x[i] = a;
 }
-// y[i] = sum_{k>=i} W[k][i] x[k]   (W^T x, W lower triangular; thread per column)
-__global__ void k_gemv_cols(const double* __restrict__ W, const double* __restrict__ x, int64_t Mp, double* __restrict__ y) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Mp) return;
-  double a = 0.0;
-  for (int k = i; k < Mp; ++k) a = fma(W[(int64_t)k * Mp + i], x[k], a);
-  y[i] = a;
-}
-// d[i] = sum_{k>=i} W[k][i] Y[k][i]   (diag(W^T Y); thread per column)
-__global__ void k_coldot(const double* __restrict__ W, const double* __restrict__ Y, int64_t Mp, double* __restrict__ d) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Mp) return;
-  double a = 0.0;
-  for (int k = i; k < Mp; ++k) a = fma(W[(int64_t)k * Mp + i], Y[(int64_t)k * Mp + i], a);
-  d[i] = a;
-}
-// alpha[i] = sum_k W[k][i] v[k] ; dkinv[i] = sum_k W[k][i]^2   (thread per column)
-__global__ void k_kl_cols(const double* __restrict__ W, const double* __restrict__ v, int64_t Mp,
-                          double* __restrict__ alpha, double* __restrict__ dkinv) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Mp) return;
-  double a = 0.0, b = 0.0;
-  for (int k = i; k < Mp; ++k) {
-    const double w = W[(int64_t)k * Mp + i];
-    a = fma(w, v[k], a);
-    b = fma(w, w, b);
+// Column reductions over the lower triangle of W (row-major, Mp x Mp).  A block owns 64 columns; its 16 row lanes (threadIdx.y)
+// stride over the rows k >= first column of the strip, then the 16 partial sums are added in lane order (fixed order:
+// bit-stable).  Launch with dim3(Mp / 64), dim3(64, COL_LANES).
+constexpr int COL_LANES = 16;
+template <int NV>
+__device__ __forceinline__ void col_lanes_reduce(double (&a)[NV], double (*sh)[COL_LANES][64]) {
+#pragma unroll
+  for (int q = 0; q < NV; ++q) sh[q][threadIdx.y][threadIdx.x] = a[q];
+  __syncthreads();
+  if (threadIdx.y == 0) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      double t = 0.0;
+      for (int l = 0; l < COL_LANES; ++l) t += sh[q][l][threadIdx.x];
+      a[q] = t;
+    }
   }
-  alpha[i] = a; dkinv[i] = b;
+}
+// y[i] = sum_{k>=i} W[k][i] x[k]   (W^T x, W lower triangular)
+__global__ void __launch_bounds__(64 * COL_LANES)
+k_gemv_cols(const double* __restrict__ W, const double* __restrict__ x, int64_t Mp, double* __restrict__ y) {
+  __shared__ double sh[1][COL_LANES][64];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  double a[1] = {0.0};
+  for (int k = blockIdx.x * 64 + threadIdx.y; k < Mp; k += COL_LANES)
+    if (k >= i) a[0] = fma(W[(int64_t)k * Mp + i], x[k], a[0]);
+  col_lanes_reduce<1>(a, sh);
+  if (threadIdx.y == 0) y[i] = a[0];
+}
+// d[i] = sum_{k>=i} W[k][i] Y[k][i]   (diag(W^T Y))
+__global__ void __launch_bounds__(64 * COL_LANES)
+k_coldot(const double* __restrict__ W, const double* __restrict__ Y, int64_t Mp, double* __restrict__ d) {
+  __shared__ double sh[1][COL_LANES][64];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  double a[1] = {0.0};
+  for (int k = blockIdx.x * 64 + threadIdx.y; k < Mp; k += COL_LANES)
+    if (k >= i) a[0] = fma(W[(int64_t)k * Mp + i], Y[(int64_t)k * Mp + i], a[0]);
+  col_lanes_reduce<1>(a, sh);
+  if (threadIdx.y == 0) d[i] = a[0];
+}
+// alpha[i] = sum_k W[k][i] v[k] ; dkinv[i] = sum_k W[k][i]^2
+__global__ void __launch_bounds__(64 * COL_LANES)
+k_kl_cols(const double* __restrict__ W, const double* __restrict__ v, int64_t Mp,
+          double* __restrict__ alpha, double* __restrict__ dkinv) {
+  __shared__ double sh[2][COL_LANES][64];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  double a[2] = {0.0, 0.0};
+  for (int k = blockIdx.x * 64 + threadIdx.y; k < Mp; k += COL_LANES)
+    if (k >= i) {
+      const double w = W[(int64_t)k * Mp + i];
+      a[0] = fma(w, v[k], a[0]);
+      a[1] = fma(w, w, a[1]);
+    }
+  col_lanes_reduce<2>(a, sh);
+  if (threadIdx.y == 0) { alpha[i] = a[0]; dkinv[i] = a[1]; }
 }
 // KL value (gauss_kl_diag, onofftf/main.py:218-250): one block.
 __global__ void __launch_bounds__(256)
@@ -445,34 +472,132 @@ __global__ void k_rowscale(const double* __restrict__ P, const double* __restric
 // tf.matrix_triangular_solve calls :271,284 by GEMMs -- "W-form")
 // A/L/W point at the (j0,j0) block; ld = leading dimension.  info: first failing 1-based pivot index.
 // ---------------------------------------------------------------------------------------------
-constexpr int PB = 128, PBLD = 129;
+constexpr int PB = 128, PBLD = 129, PNB = 32;   // block size, LDS row stride, panel width
+// broadcast of one lane's double through the scalar unit (lane index is a compile-time constant after unrolling)
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// Blocked in 32-column panels so that the serial part runs in the registers of ONE wave:
+//   (1) wave 0 holds the 32x32 diagonal block row-per-lane, factors it (rank-1 updates fed by v_readlane broadcasts) and
+//       inverts it in place (dtrti2 order); L11 goes to the lower, inv(L11) transposed to the upper triangle of its LDS block
+//   (2) all threads: L21 = A21 inv(L11)^T, (3) all threads: A22 -= L21 L21^T
+// then the off-diagonal 32x32 blocks of W = L^-1 by block forward substitution, all blocks of one block-diagonal at a time:
+//   T = sum_k L_ik W_kj,  W_ij = -W_ii T.
+// LDS image: S[i][j], j <= i: L;  W[i][c], i > c, lives at S[c][i];  diag(W) in dinv.  ~25 workgroup barriers in total.
 __global__ void __launch_bounds__(1024)
 k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __restrict__ W, int64_t ld, int j0, int* info) {
   extern __shared__ double S[];   // [128][129]
   __shared__ double dinv[PB];
+  __shared__ double T[3][PNB][PNB + 1];
+  __shared__ int fail;
   const int t = threadIdx.x;
   for (int idx = t; idx < PB * PB; idx += 1024) {
     const int i = idx >> 7, j = idx & 127;
     S[i * PBLD + j] = (j <= i) ? A[(int64_t)i * ld + j] : 0.0;
   }
+  if (t == 0) fail = 0;
   __syncthreads();
-  const int ti = t >> 5, tk = t & 31;   // 32 x 32 thread grid over (row, col) pairs
-  for (int j = 0; j < PB; ++j) {
-    const double d = S[j * PBLD + j];
-    if (!(d > 0.0)) {  // non-positive or NaN pivot: uniform across the block
-      if (t == 0) atomicCAS(info, 0, j0 + j + 1);
-      return;
+  for (int jb = 0; jb < PB; jb += PNB) {
+    if (t < 64) {   // (1)
+      const int r = t & 31;                      // lanes 32..63 shadow lanes 0..31 (they never store)
+      double a[PNB];
+#pragma unroll
+      for (int k = 0; k < PNB; ++k) a[k] = S[(jb + r) * PBLD + jb + k];
+      int bad = 0;
+#pragma unroll
+      for (int j = 0; j < PNB; ++j) {
+        int rr = r;
+        asm volatile("" : "+v"(rr));   // lane masks of (rr == j) are recomputed per column instead of living in 2 SGPRs each
+        const double d = readlane_f64(a[j], j);
+        if (!(d > 0.0)) { if (!bad) bad = j + 1; }   // non-positive or NaN pivot (uniform); keep going on garbage, report below
+        const double rd = 1.0 / sqrt(d);
+        const double l = (rr == j) ? sqrt(d) : a[j] * rd;
+        a[j] = l;
+#pragma unroll
+        for (int k = j + 1; k < PNB; ++k) {   // row r, column k (k > r: unused)
+          a[k] = fma(-l, readlane_f64(l, k), a[k]);
+          asm volatile("" : "+v"(a[k]));     // materialise now: otherwise the update is sunk to column k and every broadcast stays live
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the broadcasts (SGPR pairs) of one column from piling up across columns
+      }
+      if (bad) {
+        if (t == 0) { atomicCAS(info, 0, j0 + jb + bad); fail = 1; }
+      } else {
+        // rows go through the staging tiles T[0] (L11) / T[1] (its inverse) with unconditional stores: predicated stores
+        // would keep one 64-bit lane mask per column alive in SGPRs
+        if (t < 32) {
+#pragma unroll
+          for (int k = 0; k < PNB; ++k) T[0][r][k] = a[k];
+        }
+        {
+          int rr = r;
+          asm volatile("" : "+v"(rr));
+#pragma unroll
+          for (int k = 1; k < PNB; ++k) a[k] = (k <= rr) ? a[k] : 0.0;   // columns right of the diagonal hold Schur-complement leftovers
+        }
+        // in-place inverse of the lower-triangular block, columns right to left:
+        //   w_jj = 1 / l_jj ;  w_rj = -w_jj * sum_{k=j+1..r} w_rk l_kj   (w_rk: already inverted, lane-local; l_kj: lane k, old)
+#pragma unroll
+        for (int j = PNB - 1; j >= 0; --j) {
+          int rr = r;
+          asm volatile("" : "+v"(rr));
+          const double wjj = 1.0 / readlane_f64(a[j], j);
+          double sum = 0.0;
+#pragma unroll
+          for (int k = j + 1; k < PNB; ++k) sum = fma(a[k], readlane_f64(a[j], k), sum);   // a[k] = 0 for k > r
+          a[j] = (rr == j) ? wjj : ((rr > j) ? -wjj * sum : 0.0);
+          asm volatile("" : "+v"(a[j]));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t < 32) {
+#pragma unroll
+          for (int k = 0; k < PNB; ++k) T[1][r][k] = a[k];
+        }
+      }
     }
-    const double rd = 1.0 / sqrt(d);
     __syncthreads();
-    if (t > j && t < PB) S[t * PBLD + j] *= rd;
-    if (t == j) { S[j * PBLD + j] = sqrt(d); dinv[j] = rd; }
-    __syncthreads();
-    for (int i = j + 1 + ti; i < PB; i += 32) {
-      const double lij = S[i * PBLD + j];
-      for (int k = j + 1 + tk; k <= i; k += 32) S[i * PBLD + k] = fma(-lij, S[k * PBLD + j], S[i * PBLD + k]);
+    if (fail) return;
+    {   // scatter the diagonal block: L11 -> lower triangle, inv(L11)^T -> upper triangle, its diagonal -> dinv
+      const int r = t >> 5, k = t & 31;
+      if (k <= r) S[(jb + r) * PBLD + jb + k] = T[0][r][k];
+      if (k < r) S[(jb + k) * PBLD + jb + r] = T[1][r][k];
+      if (k == r) dinv[jb + r] = T[1][r][r];
     }
-    // next iteration's first __syncthreads orders these updates before the scaling writes
+    __syncthreads();
+    __syncthreads();
+    if (fail) return;
+    const int nbelow = PB - jb - PNB;   // rows under the diagonal block
+    // (2) L21[i][c] = sum_{k<=c} A21[i][k] W11[c][k]   (in place: all sums first, then the stores)
+    double v[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = t + 1024 * q;
+      v[q] = 0.0;
+      if (idx < nbelow * PNB) {
+        const int i = jb + PNB + idx / PNB, c = idx % PNB;
+        double s = S[i * PBLD + jb + c] * dinv[jb + c];
+        for (int k = 0; k < c; ++k) s = fma(S[i * PBLD + jb + k], S[(jb + k) * PBLD + jb + c], s);
+        v[q] = s;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = t + 1024 * q;
+      if (idx < nbelow * PNB) S[(jb + PNB + idx / PNB) * PBLD + jb + idx % PNB] = v[q];
+    }
+    __syncthreads();
+    // (3) trailing update S[i][k] -= sum_c L[i][jb+c] L[k][jb+c] for jb+32 <= k <= i
+    for (int idx = t; idx < nbelow * nbelow; idx += 1024) {
+      const int i = jb + PNB + idx / nbelow, k = jb + PNB + idx % nbelow;
+      if (k > i) continue;
+      double acc = S[i * PBLD + k];
+#pragma unroll 8
+      for (int c = 0; c < PNB; ++c) acc = fma(-S[i * PBLD + jb + c], S[k * PBLD + jb + c], acc);
+      S[i * PBLD + k] = acc;
+    }
     __syncthreads();
   }
   if (L) {
@@ -481,34 +606,32 @@ k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __res
       L[(int64_t)i * ld + j] = (j <= i) ? S[i * PBLD + j] : 0.0;
     }
   }
-  __syncthreads();
-  // Inverse: column c of Winv by forward substitution, 8 lanes per column; W[i][c] (i>c) kept at S[c][i].
-  const int c = t >> 3, q = t & 7;
-  for (int i = 0; i < PB; ++i) {
-    // all lanes iterate uniformly; only columns with c < i do work
-    double part = 0.0;
-    if (c < i) {
-      // sum_{k=c}^{i-1} L[i][k] * W[k][c];  W[c][c] = dinv[c]; W[k][c] at S[c][k] for k>c
-      for (int k = c + q; k < i; k += 8) {
-        const double wkc = (k == c) ? dinv[c] : S[c * PBLD + k];
-        part = fma(S[i * PBLD + k], wkc, part);
-      }
-    }
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
-    if (c < i && q == 0) S[c * PBLD + i] = -part * dinv[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
-  __syncthreads();
   if (W) {
+    // W[x][y]: x > y at S[y][x], x == y in dinv, x < y zero
+    auto Wget = [&](int x, int y) -> double { return x > y ? S[y * PBLD + x] : (x == y ? dinv[x] : 0.0); };
+    constexpr int NBLK = PB / PNB;
+    for (int dist = 1; dist < NBLK; ++dist) {
+      const int nblk = NBLK - dist;                 // blocks (bj + dist, bj), bj = 0 .. nblk-1
+      for (int idx = t; idx < nblk * PNB * PNB; idx += 1024) {   // T = sum_k L_ik W_kj
+        const int b = idx / (PNB * PNB), r = (idx / PNB) % PNB, c = idx % PNB;
+        const int jb = b * PNB, ib = (b + dist) * PNB;
+        double s = 0.0;
+        for (int x = jb + c; x < ib; ++x) s = fma(S[(ib + r) * PBLD + x], Wget(x, jb + c), s);
+        T[b][r][c] = s;
+      }
+      __syncthreads();
+      for (int idx = t; idx < nblk * PNB * PNB; idx += 1024) {   // W_ij = -W_ii T
+        const int b = idx / (PNB * PNB), r = (idx / PNB) % PNB, c = idx % PNB;
+        const int jb = b * PNB, ib = (b + dist) * PNB;
+        double s = 0.0;
+        for (int m = 0; m <= r; ++m) s = fma(Wget(ib + r, ib + m), T[b][m][c], s);
+        S[(jb + c) * PBLD + ib + r] = -s;
+      }
+      __syncthreads();
+    }
     for (int idx = t; idx < PB * PB; idx += 1024) {
       const int i = idx >> 7, j = idx & 127;
-      double v = 0.0;
-      if (j < i) v = S[j * PBLD + i]; else if (j == i) v = dinv[i];
-      W[(int64_t)i * ld + j] = v;
+      W[(int64_t)i * ld + j] = Wget(i, j);
     }
   }
 }
