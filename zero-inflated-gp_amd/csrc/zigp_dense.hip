@@ -93,7 +93,7 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
   ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc);
   ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc);
   ZIGP_ENSURE(c, lt.A2, (size_t)Mp * Nc);
-  const int np = Mp / 32;   // partial rows of the fused column sums (one per 32 inducing rows)
+  const int np = Mp / 32;   // allocated partial rows per fused column sum (a kernel writes one per wave tile: 64 or 32 rows)
   ZIGP_ENSURE(c, lt.part, (size_t)3 * np * Nc);
   KernHyp hyp = make_hyp(ell_host, lt.var, D);
   {
@@ -308,7 +308,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   int64_t Nc = c->chunk;
   const int64_t span = has_rows ? (row_end - row_begin) : 0;
   if (span < Nc) Nc = std::max<int64_t>(1024, round_up(span, 1024));
-  const int pw_blocks = (int)(Nc / PW_THREADS);
+  const int pw_blocks = (int)(Nc / PW_PTS);
   ZIGP_ENSURE(c, c->pw_part, (size_t)pw_blocks * PW_ACC);
   ZIGP_HIP(c, hipMemsetAsync(c->pw_part.p, 0, sizeof(double) * pw_blocks * PW_ACC, c->stream));
   for (int h = 0; h < 2; ++h) {
@@ -337,13 +337,18 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     {
       ProfScope ps(c, PC_POINT);
       PwArgs a;
-      a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32; a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
+      a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32;
+      {
+        constexpr int RW1 = Shape<WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false>::value>::RW, RW2 = Shape<WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false>::value>::RW;
+        static_assert(RW1 >= 32 && RW2 >= 32, "partial-row planes are allocated for 32-row wave tiles");
+        a.np1_f = c->lat[0].Mp / RW1; a.np2_f = c->lat[0].Mp / RW2; a.np1_g = c->lat[1].Mp / RW1; a.np2_g = c->lat[1].Mp / RW2;
+      } a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
       a.var_f = p->var_f; a.var_g = p->var_g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
       a.gm_f = need_grad ? c->lat[0].gm.p : nullptr; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
       a.X = dX; a.D = D; a.mean_on = c->mean_on ? 1 : 0; a.mean_b = c->mean_b;
       for (int d = 0; d < MAXD; ++d) a.mean_a[d] = (d < D) ? c->mean_a[d] : 0.0;
       a.acc = c->pw_part.p; a.out9 = d_out9 ? d_out9 - row_begin : nullptr; a.ld9 = row_end - row_begin;
-      const int nblk = (int)(Nc / PW_THREADS);
+      const int nblk = (int)(Nc / PW_PTS);
       if (predict) hipLaunchKernelGGL(k_pointwise<true>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
       else hipLaunchKernelGGL(k_pointwise<false>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
       ZIGP_HIP(c, hipGetLastError());

@@ -116,10 +116,10 @@ struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
   }
 };
 
-// Store + fused column reductions over this wave's 64 rows (GPConditional's reduce_sum over the inducing index,
+// Store + fused column reductions over this wave's 16 * TM rows (GPConditional's reduce_sum over the inducing index,
 // onofftf/main.py:278,287,291,302):   out1[n] = sum_m w1[m] C[m,n]   (skipped if w1 == nullptr)
 //                                      out2[n] = sum_m w2[m] C[m,n]^2 (w2 == nullptr -> weight 1)
-// written to partial row (global row / 32) of out1/out2 (each [Mp/32][ldc]); the point-wise kernel adds the partial
+// written to partial row (global row / wave-tile rows) of out1/out2 (each [Mp / (16 TM)][ldc]); the point-wise kernel adds the partial
 // rows in index order, so the result does not depend on scheduling.
 struct EpiStoreColsum {
   const double* __restrict__ w1; const double* __restrict__ w2; double* __restrict__ out1; double* __restrict__ out2;
@@ -127,16 +127,14 @@ struct EpiStoreColsum {
   __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc;
     const int c_i = e.lane >> 4, c_j = e.lane & 15;
-#pragma unroll
-    for (int tp = 0; tp < TM / 2; ++tp) {   // one partial row per 32 rows (pair of 16-row sub-tiles)
+    {   // one partial row per wave tile (16 * TM rows)
       double s1[TN], s2[TN];
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) { s1[tn] = 0.0; s2[tn] = 0.0; }
 #pragma unroll
-      for (int tq = 0; tq < 2; ++tq)
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int tm = 2 * tp + tq;
           const int64_t gi = e.row0 + tm * 16 + 4 * r + c_i;
           const double a1 = w1 ? w1[gi] : 0.0, a2 = w2 ? w2[gi] : 1.0;
 #pragma unroll
@@ -147,7 +145,7 @@ struct EpiStoreColsum {
             s2[tn] = fma(a2 * v, v, s2[tn]);
           }
         }
-      const int64_t prow = (e.row0 >> 5) + tp;
+      const int64_t prow = e.row0 / (16 * TM);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {   // fixed-order combine of the four 16-lane row groups
         double a = s1[tn], b = s2[tn];

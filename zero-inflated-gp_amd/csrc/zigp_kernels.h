@@ -90,7 +90,8 @@ k_kuf_build(const double* __restrict__ X, int64_t N, int64_t n0, const double* _
 // ---------------------------------------------------------------------------------------------
 struct PwArgs {
   const double* part_f; const double* part_g;    // per latent [3][NP][Nc]: sum v A1, sum A1^2, sum s2 A2^2 partial rows (EpiStoreColsum)
-  int np_f, np_g;                                 // partial rows per quantity (Mp/32)
+  int np_f, np_g;                                 // allocated partial rows per quantity (plane stride np * Nc)
+  int np1_f, np2_f, np1_g, np2_g;                 // rows actually written: np1 by the A1 kernel (quantities 0, 1), np2 by the A2 kernel
   const double* Y; int64_t n0, row_end, Nc;
   double var_f, var_g, noise, g_offset, scale;
   double* gm_f; double* gv_f; double* gm_g; double* gv_g;
@@ -146,23 +147,43 @@ __device__ __forceinline__ PwOut pointwise_eval(double fm, double fv, double gmn
   return o;
 }
 
+// A block owns PW_PTS points; wave g of its PW_GROUPS waves adds the partial rows q = g, g + PW_GROUPS, ... (so that
+// Nc / PW_PTS = 512 blocks x 4 waves keep enough loads in flight to stream the partial-row planes), wave 0 adds the group sums
+// in group order (fixed order: bit-stable) and evaluates the point.
+constexpr int PW_PTS = 64, PW_GROUPS = PW_THREADS / PW_PTS;
 template <bool PREDICT>
 __global__ void __launch_bounds__(PW_THREADS)
 k_pointwise(PwArgs p) {
-  __shared__ double sh[4];
-  const int64_t n = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
-  double fm = 0.0, fsq = 0.0, fs2 = 0.0, gmn = 0.0, gsq = 0.0, gs2 = 0.0;
-  for (int q = 0; q < p.np_f; ++q) {
-    fm += p.part_f[(int64_t)(0 * p.np_f + q) * p.Nc + n];
-    fsq += p.part_f[(int64_t)(1 * p.np_f + q) * p.Nc + n];
-    fs2 += p.part_f[(int64_t)(2 * p.np_f + q) * p.Nc + n];
+  __shared__ double grp[6][PW_GROUPS][PW_PTS];
+  const int lane = threadIdx.x & (PW_PTS - 1), g = threadIdx.x / PW_PTS;
+  const int64_t n = (int64_t)blockIdx.x * PW_PTS + lane;
+  {
+    double fm = 0.0, fsq = 0.0, fs2 = 0.0, gmn = 0.0, gsq = 0.0, gs2 = 0.0;
+    for (int q = g; q < p.np1_f; q += PW_GROUPS) {
+      fm += p.part_f[(int64_t)(0 * p.np_f + q) * p.Nc + n];
+      fsq += p.part_f[(int64_t)(1 * p.np_f + q) * p.Nc + n];
+    }
+    for (int q = g; q < p.np2_f; q += PW_GROUPS) fs2 += p.part_f[(int64_t)(2 * p.np_f + q) * p.Nc + n];
+    for (int q = g; q < p.np1_g; q += PW_GROUPS) {
+      gmn += p.part_g[(int64_t)(0 * p.np_g + q) * p.Nc + n];
+      gsq += p.part_g[(int64_t)(1 * p.np_g + q) * p.Nc + n];
+    }
+    for (int q = g; q < p.np2_g; q += PW_GROUPS) gs2 += p.part_g[(int64_t)(2 * p.np_g + q) * p.Nc + n];
+    grp[0][g][lane] = fm; grp[1][g][lane] = fsq; grp[2][g][lane] = fs2;
+    grp[3][g][lane] = gmn; grp[4][g][lane] = gsq; grp[5][g][lane] = gs2;
   }
-  for (int q = 0; q < p.np_g; ++q) {
-    gmn += p.part_g[(int64_t)(0 * p.np_g + q) * p.Nc + n];
-    gsq += p.part_g[(int64_t)(1 * p.np_g + q) * p.Nc + n];
-    gs2 += p.part_g[(int64_t)(2 * p.np_g + q) * p.Nc + n];
+  __syncthreads();
+  if (g != 0) return;
+  double tot[6];
+#pragma unroll
+  for (int v = 0; v < 6; ++v) {
+    double a = grp[v][0][lane];
+#pragma unroll
+    for (int w = 1; w < PW_GROUPS; ++w) a += grp[v][w][lane];
+    tot[v] = a;
   }
-  const double fv = p.var_f - fsq + fs2, gvr = p.var_g - gsq + gs2;   // main.py:278,302
+  double fm = tot[0], gmn = tot[3];
+  const double fv = p.var_f - tot[1] + tot[2], gvr = p.var_g - tot[4] + tot[5];   // main.py:278,302
   gmn += p.g_offset;
   const bool valid = (p.n0 + n) < p.row_end;
   double xs[MAXD];
@@ -190,21 +211,17 @@ k_pointwise(PwArgs p) {
   if (p.gm_f) {
     p.gm_f[n] = sc * o.dfm; p.gv_f[n] = sc * o.dfv; p.gm_g[n] = sc * o.dgm; p.gv_g[n] = sc * o.dgv;
   }
-  double s0 = block_sum<4>(valid ? p.scale * o.ve : 0.0, sh);
-  double s1 = block_sum<4>(sc * o.dnoise, sh);
-  double s2 = block_sum<4>(sc * o.dfv, sh);
-  double s3 = block_sum<4>(sc * o.dgv, sh);
-  if (threadIdx.x == 0) {
-    double* a = p.acc + (int64_t)blockIdx.x * PW_ACC;
-    a[0] += s0; a[1] += s1; a[2] += s2; a[3] += s3;
-  }
+  // block sums = sums over this one wave; acc[block] keeps accumulating chunk after chunk
+  const double s0 = wave_sum(valid ? p.scale * o.ve : 0.0), s1 = wave_sum(sc * o.dnoise), s2 = wave_sum(sc * o.dfv), s3 = wave_sum(sc * o.dgv);
+  double* a = p.acc + (int64_t)blockIdx.x * PW_ACC;
+  if (lane == 0) { a[0] += s0; a[1] += s1; a[2] += s2; a[3] += s3; }
   if (p.mean_on) {   // d/d mean_b = sum gm_f, d/d mean_a[d] = sum gm_f x_d
     const double gmf = sc * o.dfm;
-    double sb = block_sum<4>(gmf, sh);
-    if (threadIdx.x == 0) p.acc[(int64_t)blockIdx.x * PW_ACC + 4] += sb;
+    const double sb = wave_sum(gmf);
+    if (lane == 0) a[4] += sb;
     for (int d = 0; d < p.D; ++d) {
-      double sa = block_sum<4>(gmf * xs[d], sh);
-      if (threadIdx.x == 0) p.acc[(int64_t)blockIdx.x * PW_ACC + 5 + d] += sa;
+      const double sa = wave_sum(gmf * xs[d]);
+      if (lane == 0) a[5 + d] += sa;
     }
   }
 }
