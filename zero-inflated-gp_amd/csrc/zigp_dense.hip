@@ -98,7 +98,7 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
   KernHyp hyp = make_hyp(ell_host, lt.var, D);
   {
     ProfScope ps(c, PC_KUF);
-    hipLaunchKernelGGL(k_kuf_build, dim3((unsigned)(Nc / 256), Mp / 16), dim3(256), 0, c->stream, dX, Nrows, n0, lt.Z.p, lt.M, hyp,
+    hipLaunchKernelGGL(k_kuf_build, dim3((unsigned)(Nc / 512), Mp / 16), dim3(256), 0, c->stream, dX, Nrows, n0, lt.Z.p, lt.M, hyp,
                        lt.K.p, Nc);
     ZIGP_HIP(c, hipGetLastError());
   }

@@ -57,29 +57,36 @@ __global__ void k_rbf_matrix(const double* __restrict__ X1, int64_t n1, const do
 
 // ---------------------------------------------------------------------------------------------
 // Kuf panel for one chunk: K[m][n] = var*exp(-0.5*|(z_m - x_n)/ell|^2), m < M ; 0 for padded rows.
-// (kern.K(X, Xnew), onofftf/main.py:266.)  grid (Nc/256, Mp/16); thread = one column n, 16 rows.
+// (kern.K(X, Xnew), onofftf/main.py:266.)  grid (Nc/512, Mp/16); thread = two adjacent columns, 16 rows.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_kuf_build(const double* __restrict__ X, int64_t N, int64_t n0, const double* __restrict__ Z, int M, KernHyp h,
             double* __restrict__ K, int64_t Nc) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;   // two adjacent columns: 16-byte stores
   const int m0 = blockIdx.y * 16;
-  double xs[MAXD];
-  const bool valid = (n0 + n) < N;
+  double xs[2][MAXD];
 #pragma unroll
-  for (int d = 0; d < MAXD; ++d) xs[d] = (d < h.D && valid) ? X[(n0 + n) * h.D + d] * h.inv_ell[d] : 0.0;
+  for (int e = 0; e < 2; ++e) {
+    const bool valid = (n0 + n + e) < N;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) xs[e][d] = (d < h.D && valid) ? X[(n0 + n + e) * h.D + d] * h.inv_ell[d] : 0.0;
+  }
 #pragma unroll 4
   for (int mm = 0; mm < 16; ++mm) {
     const int m = m0 + mm;
-    double v = 0.0;
+    double2 v = make_double2(0.0, 0.0);
     if (m < M) {
-      double r2 = 0.0;
+      double r0 = 0.0, r1 = 0.0;
 #pragma unroll
       for (int d = 0; d < MAXD; ++d)
-        if (d < h.D) { double t = Z[m * h.D + d] * h.inv_ell[d] - xs[d]; r2 = fma(t, t, r2); }
-      v = h.var * exp(-0.5 * r2);
+        if (d < h.D) {
+          const double zs = Z[m * h.D + d] * h.inv_ell[d];
+          const double t0 = zs - xs[0][d], t1 = zs - xs[1][d];
+          r0 = fma(t0, t0, r0); r1 = fma(t1, t1, r1);
+        }
+      v.x = h.var * exp(-0.5 * r0); v.y = h.var * exp(-0.5 * r1);
     }
-    K[(int64_t)m * Nc + n] = v;
+    *reinterpret_cast<double2*>(K + (int64_t)m * Nc + n) = v;
   }
 }
 
