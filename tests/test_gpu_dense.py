@@ -254,3 +254,24 @@ def test_mean_function_bad_arguments(engine):
         engine.elbo(dict(p, mean_a=np.ones(3)))
     with pytest.raises(ValueError):
         engine.elbo(dict(p, mean_b=float('nan')))
+
+
+def test_stream_overlap_is_bit_identical(engine):
+    """the side-stream schedule (kgrad / next Kuf panel under the SYRKs) only reorders independent kernels"""
+    X, Y, p = make_problem(9000, 130, 3, seed=8)
+    engine.set_chunk(2048)            # 5 chunks, the last one partial
+    engine.set_data(X, Y)
+    out = {}
+    for on in (True, False, True):
+        engine.set_overlap(on)
+        for prof in (False, True):    # timed chunks fall back to the single stream inside an overlapped step
+            engine.profile_enable(prof)
+            out[(on, prof)] = engine.elbo(p, jitter=1e-6, scale=1.3)
+    engine.profile_enable(False)
+    engine.set_overlap(True)
+    engine.set_chunk(32768)
+    ref = out[(False, False)]
+    for k, (ed, kl, g) in out.items():
+        assert ed == ref[0] and kl == ref[1], k
+        for name in g:
+            assert np.array_equal(np.asarray(g[name]), np.asarray(ref[2][name])), (k, name)

@@ -71,6 +71,7 @@ struct zigp_ctx {
   zigp::Latent lat[2];
   zigp::DevBuf pw_part;                 // pointwise block partials
   // mean function of f, m(x) = mean_b + mean_a . x (zigp_set_mean_function), and its gradient from the last zigp_elbo
+  bool overlap = true;                  // HBM-bound side kernels of a chunk run on stream2 under its SYRKs (zigp_set_overlap)
   bool mean_on = false;
   double mean_a[8] = {0}, mean_b = 0.0, mean_da[8] = {0}, mean_db = 0.0;   // 8 = zigp::MAXD (zigp_kernels.h)
   zigp::DevBuf out9;                    // predict outputs (9,Nc)
@@ -81,7 +82,7 @@ struct zigp_ctx {
   std::map<std::string, zigp::TileList> tiles;
   // profiling
   bool prof_on = false;
-  int prof_every = 4;                    // chunk-loop launches are timed on every prof_every-th chunk (event pairs cost ~10 us)
+  int prof_every = 8;                    // chunk-loop launches are timed on every prof_every-th chunk (event pairs cost ~10 us)
   bool prof_skip = false;                // set by the chunk loop for the chunks that are not sampled
   int64_t prof_total[ZIGP_NCLASS] = {0}; // all launches per class, sampled or not
   double prof_ms[ZIGP_NCLASS] = {0};

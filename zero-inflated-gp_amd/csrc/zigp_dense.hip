@@ -86,22 +86,21 @@ int latent_kl(zigp_ctx* c, Latent& lt) {
   return 0;
 }
 
-// Forward panels of one latent for the chunk starting at row n0: K, A1, A2 (+ H, J' when a gradient is wanted), column partials.
-int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D,
-                         const double* ell_host, bool need_grad) {
-  const int Mp = lt.Mp, nbm = Mp / BM, nbn = (int)(Nc / BN);
-  ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc);
-  ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc);
-  ZIGP_ENSURE(c, lt.A2, (size_t)Mp * Nc);
-  const int np = Mp / 32;   // allocated partial rows per fused column sum (a kernel writes one per wave tile: 64 or 32 rows)
-  ZIGP_ENSURE(c, lt.part, (size_t)3 * np * Nc);
+// Kuf panel of one latent for the chunk starting at row n0 (HBM-write bound; runs on the side stream under the previous chunk's SYRKs)
+int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D, const double* ell_host) {
+  const int Mp = lt.Mp;
   KernHyp hyp = make_hyp(ell_host, lt.var, D);
-  {
-    ProfScope ps(c, PC_KUF);
-    hipLaunchKernelGGL(k_kuf_build, dim3((unsigned)(Nc / 512), Mp / 16), dim3(256), 0, c->stream, dX, Nrows, n0, lt.Z.p, lt.M, hyp,
-                       lt.K.p, Nc);
-    ZIGP_HIP(c, hipGetLastError());
-  }
+  ProfScope ps(c, PC_KUF);
+  hipLaunchKernelGGL(k_kuf_build, dim3((unsigned)(Nc / 512), Mp / 16), dim3(256), 0, c->stream, dX, Nrows, n0, lt.Z.p, lt.M, hyp,
+                     lt.K.p, Nc);
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+
+// Forward panels of one latent for the chunk starting at row n0: A1, A2 (+ H, J' when a gradient is wanted), column partials.
+int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
+  const int Mp = lt.Mp, nbm = Mp / BM, nbn = (int)(Nc / BN);
+  const int np = Mp / 32;   // allocated partial rows per fused column sum (a kernel writes one per wave tile: 64 or 32 rows)
   TileList tl, tu;
   ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, tl));
   ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu));
@@ -117,8 +116,6 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrow
     ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), ep)));
   }
   if (need_grad) {
-    ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc);
-    ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc);
     {
       ProfScope ps(c, PC_GEMM_H, fl);   // H = (W diag(s^2)) A2
       ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wp.p, Mp, lt.A2.p, Nc, lt.H.p, Nc), EpiStore())));
@@ -145,11 +142,9 @@ int syr_slices(int nbm) {
   return best;
 }
 
-int latent_chunk_backward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D) {
-  const int Mp = lt.Mp, nbm = Mp / BM;
-  TileList ts;
-  ZIGP_TRY(tiles_syr2k(c, nbm, (int)(Nc / BK), syr_slices(nbm), ts));
-  const double fl = (double)lt.M * lt.M * (double)Nc;
+// Kuf-cotangent reductions of one latent and chunk (HBM-read bound; runs on the side stream under the chunk's SYRKs)
+int latent_chunk_kgrad(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D) {
+  const int Mp = lt.Mp;
   double* alpha = lt.vec.p + Mp;
   {
     ProfScope ps(c, PC_RED);
@@ -167,6 +162,15 @@ int latent_chunk_backward(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nro
 #undef ZIGP_KGRAD
     ZIGP_HIP(c, hipGetLastError());
   }
+  return 0;
+}
+
+// Rank-N update of the lower-triangular cotangent of one latent and chunk
+int latent_chunk_syrk(zigp_ctx* c, Latent& lt, int64_t Nc) {
+  const int Mp = lt.Mp, nbm = Mp / BM;
+  TileList ts;
+  ZIGP_TRY(tiles_syr2k(c, nbm, (int)(Nc / BK), syr_slices(nbm), ts));
+  const double fl = (double)lt.M * lt.M * (double)Nc;
   {
     ProfScope ps(c, PC_SYR2K, fl);   // planes += tril(A1 G A1^T)   (G = diag(gv) applied as k-scale on the B operand)
     GemmArgs g = mk_args(lt.A1.p, Nc, lt.A1.p, Nc, lt.dLpart.p, Mp);
@@ -315,6 +319,11 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     Latent& lt = c->lat[h];
     const int Mp = lt.Mp;
     ZIGP_ENSURE(c, lt.gm, Nc); ZIGP_ENSURE(c, lt.gv, Nc);
+    if (has_rows) {
+      ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A2, (size_t)Mp * Nc);
+      ZIGP_ENSURE(c, lt.part, (size_t)3 * (Mp / 32) * Nc);
+      if (need_grad) { ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc); }
+    }
     if (need_grad) {
       ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)KG_SPLIT * Mp * (2 + 2 * D));
       const int S = syr_slices(Mp / BM);
@@ -327,13 +336,34 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
       if (has_rows) ZIGP_HIP(c, hipMemsetAsync(lt.dLpart.p, 0, sizeof(double) * S * Mp * Mp, c->stream));
     }
   }
+  // ---- chunk loop.  The MFMA-bound GEMMs stay on the main stream; the HBM-bound kernels of a chunk -- the two Kuf-cotangent
+  // reductions and the two Kuf panels of the NEXT chunk -- run on the side stream underneath the chunk's two SYRKs:
+  //   main:  [wait side]  A1 A2 H J' (f, g)  point-wise  (record)  SYRK f  SYRK g
+  //   side:                                              (wait)    kgrad f  kgrad g  Kuf f'  Kuf g'  (record)
+  // K is only read by A1 and kgrad, J' / gm only by kgrad: the next chunk's GEMMs wait for the side stream, nothing else is
+  // shared.  A chunk whose kernels are being timed (profiling samples every prof_every-th chunk) runs everything on the main
+  // stream, so the per-kernel durations bench.py reports are those of kernels running alone.
   const int64_t Nc_full = Nc;
+  auto chunk_rows = [&](int64_t n0) { return std::min<int64_t>(Nc_full, round_up(row_end - n0, 1024)); };
+  auto sampled = [&](int64_t n0) {   // kernel timing (HIP events) covers FULL chunks only, so the averages describe full-size launches
+    if (!c->prof_on) return false;
+    if (row_end - row_begin <= Nc_full) return true;
+    return chunk_rows(n0) == Nc_full && (((n0 - row_begin) / Nc_full) % c->prof_every) == 0;
+  };
+  struct SideGuard { zigp_ctx* c; ~SideGuard() { c->stream = c->stream_main; c->prof_skip = false; } } side_guard{c};
+  bool side_busy = false;
+  if (has_rows) {
+    c->prof_skip = c->prof_on && !sampled(row_begin);
+    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], dX, Nrows, row_begin, chunk_rows(row_begin), D, ell_h[h]));
+  }
   for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc_full) {
-    // the last (partial) chunk shrinks to the next multiple of 1024 rows
-    Nc = std::min<int64_t>(Nc_full, round_up(row_end - n0, 1024));
-    // kernel timing (HIP events) samples every prof_every-th FULL chunk, so the averages describe full-size launches
-    c->prof_skip = c->prof_on && (Nc != Nc_full || (((n0 - row_begin) / Nc_full) % c->prof_every) != 0) && (row_end - row_begin > Nc_full);
-    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], dX, Nrows, n0, Nc, D, ell_h[h], need_grad));
+    Nc = chunk_rows(n0);   // the last (partial) chunk shrinks to the next multiple of 1024 rows
+    const int64_t n1 = n0 + Nc_full;
+    const bool has_next = n1 < row_end;
+    const bool timed = sampled(n0), timed_next = has_next && sampled(n1);
+    c->prof_skip = c->prof_on && !timed;
+    if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
+    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], Nc, need_grad));
     {
       ProfScope ps(c, PC_POINT);
       PwArgs a;
@@ -342,7 +372,8 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
         constexpr int RW1 = Shape<WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false>::value>::RW, RW2 = Shape<WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false>::value>::RW;
         static_assert(RW1 >= 32 && RW2 >= 32, "partial-row planes are allocated for 32-row wave tiles");
         a.np1_f = c->lat[0].Mp / RW1; a.np2_f = c->lat[0].Mp / RW2; a.np1_g = c->lat[1].Mp / RW1; a.np2_g = c->lat[1].Mp / RW2;
-      } a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
+      }
+      a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
       a.var_f = p->var_f; a.var_g = p->var_g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
       a.gm_f = need_grad ? c->lat[0].gm.p : nullptr; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
       a.X = dX; a.D = D; a.mean_on = c->mean_on ? 1 : 0; a.mean_b = c->mean_b;
@@ -353,9 +384,33 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
       else hipLaunchKernelGGL(k_pointwise<false>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
       ZIGP_HIP(c, hipGetLastError());
     }
-    if (need_grad)
-      for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_backward(c, c->lat[h], dX, Nrows, n0, Nc, D));
+    // side work of this chunk: its kgrads and the next chunk's Kuf panels (gradient mode only: without the SYRKs there is
+    // nothing on the main stream to hide them under)
+    const bool kgrad_side = c->overlap && need_grad && !timed;
+    const bool kuf_side = kgrad_side && has_next && !timed_next;
+    if (kgrad_side) {
+      ZIGP_HIP(c, hipEventRecord(c->ev_fork, c->stream_main));
+      ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      c->stream = c->stream2;
+      for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], dX, Nrows, n0, Nc, D));
+      if (kuf_side)
+        for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], dX, Nrows, n1, chunk_rows(n1), D, ell_h[h]));
+      ZIGP_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+      side_busy = true;
+      c->stream = c->stream_main;
+    }
+    if (need_grad) {
+      if (!kgrad_side)
+        for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], dX, Nrows, n0, Nc, D));
+      for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_syrk(c, c->lat[h], Nc));
+    }
+    if (has_next && !kuf_side) {   // a timed next chunk gets its panels from the main stream, with the side stream drained
+      if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
+      c->prof_skip = c->prof_on && !timed_next;
+      for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], dX, Nrows, n1, chunk_rows(n1), D, ell_h[h]));
+    }
   }
+  if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
   c->prof_skip = false;
   if (predict) { ZIGP_HIP(c, hipStreamSynchronize(c->stream)); prof_collect(c); return 0; }
   if (need_grad)
@@ -499,6 +554,12 @@ int zigp_destroy(zigp_ctx* c) {
 
 const char* zigp_last_error(zigp_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int zigp_last_info(zigp_ctx* c) { return c ? c->info : 0; }
+
+int zigp_set_overlap(zigp_ctx* c, int32_t on) {
+  if (!c) return ZIGP_EARG;
+  c->overlap = on != 0;
+  return ZIGP_OK;
+}
 
 int zigp_set_chunk(zigp_ctx* c, int64_t chunk_rows) {
   if (!c) return ZIGP_EARG;

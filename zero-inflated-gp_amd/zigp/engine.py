@@ -301,6 +301,10 @@ class DenseEngine:
         return out
 
     # ---- measurement ----
+    def set_overlap(self, on=True):
+        """side-stream overlap of the HBM-bound kernels (default on); results are bit-identical either way"""
+        _check(self.lib, self.ctx, self.lib.zigp_set_overlap(self.ctx, 1 if on else 0))
+
     def profile_enable(self, on=True):
         _check(self.lib, self.ctx, self.lib.zigp_profile_enable(self.ctx, 1 if on else 0))
 
