@@ -10,7 +10,7 @@
 //     16-lane groups (LDS broadcast is free).  The accumulator layout then equals the 16x16x4 one:
 //     acc[r] of lane l = C[4r + l/16][l%16].
 //   * workgroup tile 128x128, BK = 16, as 4 waves (2x2, 64x64 wave tiles, 64 accumulators/lane) or 8 waves
-//     (2x4, 64x32 wave tiles, 32 accumulators/lane); two workgroups share a CU.  MFMA issue is never
+//     (4x2, 32x64 wave tiles, 32 accumulators/lane); two workgroups share a CU.  MFMA issue is never
 //     dependency-bound (>= 32 independent accumulators).
 //   * operand tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into an
 //     NSTAGE-deep ring.  One wave-instruction writes 1 KB linearly, so bank conflicts are removed
@@ -21,6 +21,8 @@
 //     (b) for m/n-contiguous tiles ([16 k][128], one k-row per instruction) by giving each row its own
 //         M0 base with a 144-double stride (odd k rows land 128 B further round the banks).
 //     One s_barrier per BK step; counted vmcnt keeps NSTAGE-2 stages in flight across it.
+//   * a workgroup runs a host-built UNIT of list entries (GemmArgs::per consecutive tiles, each with its own k range and k
+//     direction); the default lists are one tile per workgroup in LPT order, see tiles_trmm / tiles_syr2k in zigp_host.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
