@@ -74,3 +74,39 @@ def test_cfg3_predict_first_rows_match_oracle(engine, cfg3):
     for i in range(9):
         r = ref[i].reshape(-1)
         assert np.max(np.abs(out[i] - r)) <= 1e-7 * max(np.max(np.abs(r)), 1e-300), i
+
+
+def test_cfg3_stress_lengthscale_accuracy(engine):
+    """SURVEY.md §8d stress variant: cfg3 geometry with lengthscale 0.2 (cond(Kuu) ~ 1e8 at M = 1024, jitter 1e-6).  GPU and
+    oracle are both judged against an 80-bit evaluation of GPConditional on a few points (the GPU must stay within 10x of the
+    oracle's own error), and the ELBO on a slice must still agree to 1e-6."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import zigp_oracle as o
+    import zigp_oracle_torch as ot
+    from test_gpu_dense import _longdouble_conditional, _cond
+    X, Y, p = bench.synth(4096, 1024, 3)
+    p = dict(p, ell_f=np.full(3, 0.2), ell_g=np.full(3, 0.2))
+    c = _cond(p, 1e-6)
+    npts = 24
+    out = engine.predict(p, X[:npts], jitter=1e-6)
+    ref = o.build_predict(X[:npts], p, 1e-6)
+    for tag, im, iv in (('f', 3, 4), ('g', 5, 6)):
+        tm, tv = _longdouble_conditional(X[:npts], p['Z' + tag], p['ell_' + tag], p['var_' + tag], p['u_%sm' % tag], p['u_%ss_sqrt' % tag], 1e-6)
+        tm, tv = tm.astype(np.float64), tv.astype(np.float64)
+        for nm, idx, truth in (('mean', im, tm), ('var', iv, tv)):
+            e_gpu = np.max(np.abs(out[idx] - truth)) / np.max(np.abs(truth))
+            e_orc = np.max(np.abs(ref[idx].reshape(-1) - truth)) / np.max(np.abs(truth))
+            print('stress cond %.1e %s%s: gpu vs 80-bit %.2e, oracle vs 80-bit %.2e' % (c, tag, nm, e_gpu, e_orc))
+            assert e_gpu < max(1e-6, 10 * e_orc), (tag, nm, e_gpu, e_orc)
+    engine.set_chunk(32768)
+    engine.set_data(X, Y)
+    ed, kl, g = engine.elbo(p, jitter=1e-6)
+    e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X, Y, p, 1e-6, chunk=2048)
+    print('stress elbo rel %.2e kl rel %.2e' % (abs((ed - kl) - e_r) / abs(e_r), abs(kl - kl_r) / abs(kl_r)))
+    assert abs((ed - kl) - e_r) <= 1e-6 * abs(e_r)      # north-star tolerance
+    for k in ('u_fm', 'u_fs_sqrt', 'noise', 'var_f'):
+        a, b = np.asarray(g[k]).reshape(-1), np.asarray(g_r[k]).reshape(-1)
+        e = np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+        print('  stress grad %s relerr %.2e' % (k, e))
+        assert e <= max(1e-6, 1e-13 * c), (k, e)
