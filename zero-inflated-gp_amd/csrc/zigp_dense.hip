@@ -309,9 +309,16 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   }
   ZIGP_TRY(check_info(c, "Kuu"));
 
+  // chunk rows: the row range is cut into ceil(span / chunk) chunks of (nearly) equal size, a multiple of 1024, so that the
+  // last chunk is not a sliver whose GEMMs leave most of the 512 workgroup slots empty (N = 1e5, chunk 32768: 4 x 25600)
   int64_t Nc = c->chunk;
   const int64_t span = has_rows ? (row_end - row_begin) : 0;
-  if (span < Nc) Nc = std::max<int64_t>(1024, round_up(span, 1024));
+  if (span > 0) {
+    const int64_t nchunks = (span + c->chunk - 1) / c->chunk;
+    Nc = std::max<int64_t>(1024, round_up((span + nchunks - 1) / nchunks, 1024));
+  } else {
+    Nc = 1024;
+  }
   const int pw_blocks = (int)(Nc / PW_PTS);
   ZIGP_ENSURE(c, c->pw_part, (size_t)pw_blocks * PW_ACC);
   ZIGP_HIP(c, hipMemsetAsync(c->pw_part.p, 0, sizeof(double) * pw_blocks * PW_ACC, c->stream));
