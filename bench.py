@@ -138,7 +138,7 @@ def main():
         traffic = None
         try:
             if (M, args.chunk, D) == (1024, 32768, 3):
-                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01e_pmc_hbm_traffic.json')))
+                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01h_pmc_hbm_traffic.json')))
                 sym = PROF_KERNELS[dom].split('>')[0].replace('gemm_f64_kernel<', '').split(',')
                 for name, v in tr.items():
                     args_ = name.split('gemm_f64_kernel<')[-1].split('>')[0].replace(' ', '').split(',') if 'gemm_f64_kernel<' in name else []

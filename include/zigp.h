@@ -155,9 +155,10 @@ int zigp_kron_head_predict(zigp_ctx* ctx, const zigp_kron_params* p, int32_t lik
                            double jitter, double f_mu, double* out4);
 
 /* ---- measurement hooks (bench.py) ---- */
-/* Stream overlap inside zigp_elbo (default on): the HBM-bound kernels of a row chunk (Kuf-cotangent reductions, the next
- * chunk's Kuf panels) run on a second HIP stream underneath the chunk's two MFMA-bound rank-N updates.  Results are
- * bit-identical either way; off = every kernel alone on one stream (A/B measurements). */
+/* Stream overlap inside zigp_elbo (default off): when on, the HBM-bound kernels of a row chunk (Kuf-cotangent reductions,
+ * the next chunk's Kuf panels) run on a second HIP stream underneath the chunk's two MFMA-bound rank-N updates.  Results
+ * are bit-identical either way and the step is ~0.8 % shorter (tools/overlap_ab.py); it is off by default so that every
+ * kernel runs alone on one stream and per-kernel durations (HIP events, rocprofv3 --stats) mean what they say. */
 int zigp_set_overlap(zigp_ctx* ctx, int32_t on);
 /* Accumulated HIP-event time (ms), launch count and algorithmic flops per kernel class since the last reset,
  * measured with HIP events on the stream the kernels run on.  Classes (gemm_f64_kernel template arguments are

@@ -302,7 +302,7 @@ class DenseEngine:
 
     # ---- measurement ----
     def set_overlap(self, on=True):
-        """side-stream overlap of the HBM-bound kernels (default on); results are bit-identical either way"""
+        """side-stream overlap of the HBM-bound kernels (default off, ~0.8 % faster when on); results are bit-identical either way"""
         _check(self.lib, self.ctx, self.lib.zigp_set_overlap(self.ctx, 1 if on else 0))
 
     def profile_enable(self, on=True):
