@@ -4,7 +4,9 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/zero-inflated-g
 import bench, zigp, torch
 N, M = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100000, 512)
 X, Y, p = bench.synth(N, M, 3)
-e = zigp.DenseEngine(0); e.set_data_device(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+e = zigp.DenseEngine(0)
+if len(sys.argv) > 3: e.set_chunk(int(sys.argv[3]))
+e.set_data_device(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
 for _ in range(3): e.elbo(p)
 t0 = time.time()
 for _ in range(20): e.elbo(p)
