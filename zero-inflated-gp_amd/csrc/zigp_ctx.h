@@ -53,6 +53,27 @@ struct Latent {
 
 struct KronState;   // Kronecker-path buffers (zigp_kron.hip)
 
+// Page-locked host staging for the small per-step transfers (parameters in, sums and gradients out).  A copy between
+// device and PAGEABLE host memory makes the runtime stage and wait; through this arena the H2D copies are truly
+// asynchronous and all D2H results of a call are collected by its single final stream synchronisation.  Blocks are never
+// moved or freed while a call is in flight: alloc() only appends, reset() (start of every API call -- the previous
+// call ended with a synchronisation) rewinds.
+struct PinnedArena {
+  struct Block { char* p; size_t cap, used; };
+  std::vector<Block> blocks;
+  void reset() { for (auto& b : blocks) b.used = 0; }
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    for (auto& b : blocks)
+      if (b.cap - b.used >= bytes) { void* r = b.p + b.used; b.used += bytes; return r; }
+    Block nb; nb.cap = bytes > ((size_t)1 << 20) ? bytes : ((size_t)1 << 20); nb.used = bytes; nb.p = nullptr;
+    if (hipHostMalloc((void**)&nb.p, nb.cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    blocks.push_back(nb);
+    return nb.p;
+  }
+  void release() { for (auto& b : blocks) (void)hipHostFree(b.p); blocks.clear(); }
+};
+
 }  // namespace zigp
 
 struct zigp_ctx {
@@ -77,6 +98,7 @@ struct zigp_ctx {
   zigp::DevBuf out9;                    // predict outputs (9,Nc)
   zigp::DevBuf scratch, scratch2;       // misc
   int* d_info = nullptr;
+  zigp::PinnedArena pinned;             // host staging of the per-step transfers
   zigp::KronState* kron = nullptr;
   void (*kron_free)(zigp::KronState*) = nullptr;
   std::map<std::string, zigp::TileList> tiles;

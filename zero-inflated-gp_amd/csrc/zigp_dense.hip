@@ -292,6 +292,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   const bool has_rows = row_end > row_begin;
   HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
   const double* ell_h[2] = {p->ell_f, p->ell_g};
+  ZIGP_TRY(begin_staged_call(c));
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
   for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_upload(c, c->lat[h], hl[h], D));
   {
@@ -307,7 +308,8 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     }
     ZIGP_TRY(ts.join());
   }
-  ZIGP_TRY(check_info(c, "Kuu"));
+  int* hinfo = nullptr;
+  ZIGP_TRY(request_info(c, &hinfo));   // read after the final synchronisation
 
   // chunk rows: the row range is cut into ceil(span / chunk) chunks of (nearly) equal size, a multiple of 1024, so that the
   // last chunk is not a sliver whose GEMMs leave most of the 512 workgroup slots empty (N = 1e5, chunk 32768: 4 x 25600)
@@ -419,7 +421,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   }
   if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
   c->prof_skip = false;
-  if (predict) { ZIGP_HIP(c, hipStreamSynchronize(c->stream)); prof_collect(c); return 0; }
+  if (predict) { ZIGP_HIP(c, hipStreamSynchronize(c->stream)); prof_collect(c); return info_result(c, hinfo, "Kuu"); }
   if (need_grad)
   {
     TwoStream ts(c);
@@ -432,24 +434,21 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   }
 
   // ---- gather results on the host (fixed-order final sums) ----
-  std::vector<double> hpw((size_t)pw_blocks * PW_ACC);
-  ZIGP_HIP(c, hipMemcpyAsync(hpw.data(), c->pw_part.p, sizeof(double) * hpw.size(), hipMemcpyDeviceToHost, c->stream));
-  std::vector<double> hvec[2], hdu[2], hdsq[2], hkrow[2];
+  double* hpw = nullptr;
+  ZIGP_TRY(download(c, c->pw_part.p, (size_t)pw_blocks * PW_ACC, &hpw));
+  double *hvec[2] = {nullptr, nullptr}, *hdu[2] = {nullptr, nullptr}, *hdsq[2] = {nullptr, nullptr}, *hkrow[2] = {nullptr, nullptr};
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
-    if (include_kl || need_grad) {
-      hvec[h].resize((size_t)3 * lt.Mp + 8);
-      ZIGP_HIP(c, hipMemcpyAsync(hvec[h].data(), lt.vec.p, sizeof(double) * hvec[h].size(), hipMemcpyDeviceToHost, c->stream));
-    }
+    if (include_kl || need_grad) ZIGP_TRY(download(c, lt.vec.p, (size_t)3 * lt.Mp + 8, &hvec[h]));
     if (need_grad) {
-      hdu[h].resize(lt.Mp); hdsq[h].resize(lt.Mp); hkrow[h].resize((size_t)KG_SPLIT * lt.Mp * (2 + 2 * D));
-      ZIGP_HIP(c, hipMemcpyAsync(hdu[h].data(), lt.du.p, sizeof(double) * lt.Mp, hipMemcpyDeviceToHost, c->stream));
-      ZIGP_HIP(c, hipMemcpyAsync(hdsq[h].data(), lt.dsq.p, sizeof(double) * lt.Mp, hipMemcpyDeviceToHost, c->stream));
-      ZIGP_HIP(c, hipMemcpyAsync(hkrow[h].data(), lt.krow.p, sizeof(double) * hkrow[h].size(), hipMemcpyDeviceToHost, c->stream));
+      ZIGP_TRY(download(c, lt.du.p, lt.Mp, &hdu[h]));
+      ZIGP_TRY(download(c, lt.dsq.p, lt.Mp, &hdsq[h]));
+      ZIGP_TRY(download(c, lt.krow.p, (size_t)KG_SPLIT * lt.Mp * (2 + 2 * D), &hkrow[h]));
     }
   }
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
+  ZIGP_TRY(info_result(c, hinfo, "Kuu"));
   double s_ve = 0, s_dn = 0, s_gvf = 0, s_gvg = 0;
   for (int b = 0; b < pw_blocks; ++b) { s_ve += hpw[PW_ACC * b]; s_dn += hpw[PW_ACC * b + 1]; s_gvf += hpw[PW_ACC * b + 2]; s_gvg += hpw[PW_ACC * b + 3]; }
   c->mean_db = 0.0;
@@ -551,6 +550,7 @@ int zigp_destroy(zigp_ctx* c) {
   for (auto& kv : c->tiles) if (kv.second.d) (void)hipFree(kv.second.d);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->d_info) (void)hipFree(c->d_info);
+  c->pinned.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -652,6 +652,7 @@ int zigp_prior_kl(zigp_ctx* c, const zigp_params* p, double jitter, double* kl2)
   if (!kl2) return fail_arg(c, "zigp_prior_kl: kl2 is NULL");
   ZIGP_HIP(c, hipSetDevice(c->device));
   HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
+  ZIGP_TRY(begin_staged_call(c));
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
   for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_upload(c, c->lat[h], hl[h], p->D));
   for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], p->D, jitter, true));

@@ -151,6 +151,27 @@ static int tiles_full(zigp_ctx* c, int nbm, int nbn, int nk, TileList& tl) {
   }, tl);
 }
 
+// Deferred Cholesky status: request_info() stages the device flag with the other results of the call, info_result() reads
+// it after the call's final synchronisation.  A failed factorisation leaves L / W unfinished; the kernels that follow then
+// compute garbage from them, but all their indexing is data independent, so nothing needs a mid-call round trip.
+static int request_info(zigp_ctx* c, int** out) {
+  int* h = (int*)c->pinned.alloc(sizeof(int));
+  if (!h) { c->err = "hipHostMalloc failed for the staging arena"; return ZIGP_EHIP; }
+  ZIGP_HIP(c, hipMemcpyAsync(h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  *out = h;
+  return 0;
+}
+static int info_result(zigp_ctx* c, const int* hinfo, const char* what) {
+  const int h = *hinfo;
+  if (h != 0) {
+    c->info = h;
+    char b[256];
+    snprintf(b, sizeof(b), "Cholesky decomposition was not successful for %s: the input might not be positive definite (pivot %d)", what, h);
+    c->err = b;
+    return ZIGP_ENOTPD;
+  }
+  return 0;
+}
 static int check_info(zigp_ctx* c, const char* what) {
   int h = 0;
   ZIGP_HIP(c, hipMemcpyAsync(&h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -231,10 +252,33 @@ static inline KernHyp make_hyp(const double* ell, double var, int D) {
   return h;
 }
 
+// ---- small transfers through the pinned arena (zigp_ctx.h) ----
+// Start of an API call that stages transfers: make sure nothing of an earlier call (one that returned an error before its
+// final synchronisation, say) is still reading or writing the arena, then rewind it.
+static int begin_staged_call(zigp_ctx* c) {
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream_main));
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream2));
+  c->pinned.reset();
+  return 0;
+}
+static inline double* pinned_doubles(zigp_ctx* c, size_t n) { return (double*)c->pinned.alloc(sizeof(double) * (n ? n : 1)); }
+#define ZIGP_PINNED(ctx, ptr, n)                                                         \
+  double* ptr = pinned_doubles((ctx), (n));                                              \
+  if (!ptr) { (ctx)->err = "hipHostMalloc failed for the staging arena"; return ZIGP_EHIP; }
+// device <- host image of n doubles zero-padded to npad: one staged copy, no memset launch
 static int upload_padded(zigp_ctx* c, DevBuf& b, const double* src, size_t n, size_t npad) {
   ZIGP_ENSURE(c, b, npad);
-  ZIGP_HIP(c, hipMemsetAsync(b.p, 0, sizeof(double) * npad, c->stream));
-  if (n) ZIGP_HIP(c, hipMemcpyAsync(b.p, src, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  ZIGP_PINNED(c, h, npad);
+  if (n) memcpy(h, src, sizeof(double) * n);
+  if (npad > n) memset(h + n, 0, sizeof(double) * (npad - n));
+  ZIGP_HIP(c, hipMemcpyAsync(b.p, h, sizeof(double) * npad, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+// host <- device: the returned pinned pointer holds the data after the next synchronisation of c->stream
+static int download(zigp_ctx* c, const double* dev, size_t n, double** out) {
+  ZIGP_PINNED(c, h, n);
+  ZIGP_HIP(c, hipMemcpyAsync(h, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  *out = h;
   return 0;
 }
 

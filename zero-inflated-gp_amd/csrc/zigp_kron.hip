@@ -37,7 +37,6 @@ struct KronLatent {
 struct KronState {
   KronLatent lat[2];
   DevBuf X, Y, acc, out9;
-  std::vector<std::vector<double>> stage;   // host images of the padded (M0q x M1q) grids; alive until the step's final sync
 };
 
 static void kron_free(KronState* k) {
@@ -395,12 +394,13 @@ int factor_forward(zigp_ctx* c, KronFactor& f, int M, int D, int col0, const dou
 }
 
 int upload_grid(zigp_ctx* c, DevBuf& b, const double* src, int M0, int M1, int Mq0, int Mq1, bool square) {
-  c->kron->stage.emplace_back((size_t)Mq0 * Mq1, 0.0);
-  std::vector<double>& h = c->kron->stage.back();
+  const size_t n = (size_t)Mq0 * Mq1;
+  ZIGP_PINNED(c, h, n);   // padded image staged in page-locked memory: the copy is asynchronous
+  memset(h, 0, sizeof(double) * n);
   for (int i = 0; i < M0; ++i)
     for (int j = 0; j < M1; ++j) { const double v = src[(size_t)i * M1 + j]; h[(size_t)i * Mq1 + j] = square ? v * v : v; }
-  ZIGP_ENSURE(c, b, h.size());
-  ZIGP_HIP(c, hipMemcpyAsync(b.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+  ZIGP_ENSURE(c, b, n);
+  ZIGP_HIP(c, hipMemcpyAsync(b.p, h, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   return 0;
 }
 
@@ -530,13 +530,12 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;   // single-latent heads use the f latent only; g_offset is then f_mu
   if (!c->kron) { c->kron = new (std::nothrow) KronState(); c->kron_free = kron_free; if (!c->kron) { c->err = "out of memory"; return ZIGP_EHIP; } }
   KronState& ks = *c->kron;
-  ks.stage.clear();   // every call ends with a stream synchronisation, so the previous step's images are no longer in flight
+  ZIGP_TRY(begin_staged_call(c));
   const bool need_grad = grads != nullptr && !predict;
   const int D0 = p->D0, D1 = p->D1, ldx = D0 + D1;
   const int64_t Nc = std::max<int64_t>(1024, round_up(N, 1024));
-  ZIGP_ENSURE(c, ks.X, (size_t)N * ldx);
-  ZIGP_HIP(c, hipMemcpyAsync(ks.X.p, X, sizeof(double) * N * ldx, hipMemcpyHostToDevice, c->stream));
-  if (Y) { ZIGP_ENSURE(c, ks.Y, (size_t)N); ZIGP_HIP(c, hipMemcpyAsync(ks.Y.p, Y, sizeof(double) * N, hipMemcpyHostToDevice, c->stream)); }
+  ZIGP_TRY(upload_padded(c, ks.X, X, (size_t)N * ldx, (size_t)N * ldx));   // the minibatch, staged like the parameters
+  if (Y) ZIGP_TRY(upload_padded(c, ks.Y, Y, (size_t)N, (size_t)N));
   HostKronLatent hl[2] = {{{p->M0f, p->M1f}, {p->Z0f, p->Z1f}, {p->ell0f, p->ell1f}, {p->var0f, p->var1f}, p->u_fm, p->u_fs_sqrt},
                           {{p->M0g, p->M1g}, {p->Z0g, p->Z1g}, {p->ell0g, p->ell1g}, {p->var0g, p->var1g}, p->u_gm, p->u_gs_sqrt}};
   if (nlat == 1) hl[1] = hl[0];
@@ -550,17 +549,17 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
     }
     ZIGP_TRY(ts.join());
   }
-  ZIGP_TRY(check_info(c, "a Kronecker factor of Kuu"));
+  int* hinfo = nullptr;
+  ZIGP_TRY(request_info(c, &hinfo));   // read after the final synchronisation
   // KL scalars (value) -- before the backward pass overwrites nothing it needs
-  std::vector<double> hkl[2];
+  double* hkl[2] = {nullptr, nullptr};
   if (include_kl && !predict) {
     for (int h = 0; h < nlat; ++h) {
       KronLatent& lt = ks.lat[h];
       const int Mq0 = lt.f[0].Mq, Mq1 = lt.f[1].Mq;
       hipLaunchKernelGGL(k_kron_kl, dim3(1), dim3(256), 0, c->stream, lt.U.p, lt.Al.p, lt.S.p, lt.vec.p, lt.vec.p + Mq0, lt.f[0].L.p, lt.f[1].L.p,
                          lt.f[0].M, lt.f[1].M, Mq0, Mq1, lt.vec.p + Mq0 + Mq1);
-      hkl[h].resize(8);
-      ZIGP_HIP(c, hipMemcpyAsync(hkl[h].data(), lt.vec.p + Mq0 + Mq1, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+      ZIGP_TRY(download(c, lt.vec.p + Mq0 + Mq1, 8, &hkl[h]));
     }
   }
   {
@@ -592,15 +591,15 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
     ZIGP_HIP(c, hipGetLastError());
     ZIGP_HIP(c, hipMemcpyAsync(out9, ks.out9.p, sizeof(double) * rows * N, hipMemcpyDeviceToHost, c->stream));
     ZIGP_HIP(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return info_result(c, hinfo, "a Kronecker factor of Kuu");
   }
   if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<false>, dim3(blocks), dim3(PW_THREADS), 0, c->stream, a);
   else hipLaunchKernelGGL(k_kron_head_pointwise<false>, dim3(blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
   ZIGP_HIP(c, hipGetLastError());
-  std::vector<double> hacc((size_t)blocks * 4);
-  ZIGP_HIP(c, hipMemcpyAsync(hacc.data(), ks.acc.p, sizeof(double) * hacc.size(), hipMemcpyDeviceToHost, c->stream));
+  double* hacc = nullptr;
+  ZIGP_TRY(download(c, ks.acc.p, (size_t)blocks * 4, &hacc));
 
-  std::vector<double> hkrow[2][2], hG[2][2], hgu[2], hgs[2];
+  double *hkrow[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *hgu[2] = {nullptr, nullptr}, *hgs[2] = {nullptr, nullptr};
   if (need_grad) {
     TwoStream ts(c);
     ZIGP_TRY(ts.fork());
@@ -617,20 +616,19 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
                            include_kl ? 0.5 * (double)lt.f[1 - q].M : 0.0, (int64_t)Mq * Mq, f.G.p);
         hipLaunchKernelGGL(k_kuu_grad, dim3(Mq), dim3(256), 0, c->stream, f.G.p, f.K.p, jitter, f.Z.p, f.M, f.D, (int64_t)Mq, f.krow.p);
         ZIGP_HIP(c, hipGetLastError());
-        hkrow[h][q].resize((size_t)Mq * (2 + 2 * f.D));
-        ZIGP_HIP(c, hipMemcpyAsync(hkrow[h][q].data(), f.krow.p, sizeof(double) * hkrow[h][q].size(), hipMemcpyDeviceToHost, c->stream));
+        ZIGP_TRY(download(c, f.krow.p, (size_t)Mq * (2 + 2 * f.D), &hkrow[h][q]));
       }
       // u, s gradients (reuse T0 / T1 as outputs)
       hipLaunchKernelGGL(k_kron_us, dim3(ceil_div((int64_t)M0 * M1, 256)), dim3(256), 0, c->stream, lt.dU.p, lt.Al.p, lt.dS2.p, lt.S.p, lt.vec.p,
                          lt.vec.p + Mq0, M0, M1, Mq1, include_kl ? 1 : 0, lt.T0.p, lt.T1.p);
       ZIGP_HIP(c, hipGetLastError());
-      hgu[h].resize((size_t)M0 * M1); hgs[h].resize((size_t)M0 * M1);
-      ZIGP_HIP(c, hipMemcpyAsync(hgu[h].data(), lt.T0.p, sizeof(double) * M0 * M1, hipMemcpyDeviceToHost, c->stream));
-      ZIGP_HIP(c, hipMemcpyAsync(hgs[h].data(), lt.T1.p, sizeof(double) * M0 * M1, hipMemcpyDeviceToHost, c->stream));
+      ZIGP_TRY(download(c, lt.T0.p, (size_t)M0 * M1, &hgu[h]));
+      ZIGP_TRY(download(c, lt.T1.p, (size_t)M0 * M1, &hgs[h]));
     }
     ZIGP_TRY(ts.join());
   }
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+  ZIGP_TRY(info_result(c, hinfo, "a Kronecker factor of Kuu"));
   double s_ve = 0, s_dn = 0, s_gv[2] = {0, 0};
   for (int b = 0; b < blocks; ++b) { s_ve += hacc[4 * b]; s_dn += hacc[4 * b + 1]; s_gv[0] += hacc[4 * b + 2]; s_gv[1] += hacc[4 * b + 3]; }
   if (elbo_data) *elbo_data = s_ve;
@@ -668,8 +666,9 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
         // Knn = var0 * var1 enters var_n directly (scripts/onoff.py:196-200)
         gvar[h][q] = dv / f.var + s_gv[h] * ks.lat[h].f[1 - q].var;
       }
-      if (gu[h]) memcpy(gu[h], hgu[h].data(), sizeof(double) * hgu[h].size());
-      if (gs[h]) memcpy(gs[h], hgs[h].data(), sizeof(double) * hgs[h].size());
+      const size_t ng = (size_t)ks.lat[h].f[0].M * ks.lat[h].f[1].M;
+      if (gu[h]) memcpy(gu[h], hgu[h], sizeof(double) * ng);
+      if (gs[h]) memcpy(gs[h], hgs[h], sizeof(double) * ng);
     }
     grads->var0f = gvar[0][0]; grads->var1f = gvar[0][1];
     grads->var0g = nlat == 2 ? gvar[1][0] : 0.0; grads->var1g = nlat == 2 ? gvar[1][1] : 0.0;
