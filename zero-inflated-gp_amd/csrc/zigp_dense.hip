@@ -59,7 +59,7 @@ int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double j
                      (int64_t)h.M, hyp, jitter, lt.Kuu.p, (int64_t)Mp, (int64_t)Mp, (int64_t)Mp);
   ZIGP_HIP(c, hipGetLastError());
   ZIGP_HIP(c, hipMemcpyAsync(lt.L.p, lt.Kuu.p, sizeof(double) * Mp * Mp, hipMemcpyDeviceToDevice, c->stream));
-  ZIGP_TRY(potrf_trtri(c, lt.L.p, lt.W.p, lt.T1.p, Mp, want_W));
+  ZIGP_TRY(potrf_trtri(c, lt.L.p, lt.W.p, lt.T1.p, Mp, want_W, lt.M));
   return 0;
 }
 
@@ -755,7 +755,7 @@ int zigp_test_potrf_trtri(zigp_ctx* c, int64_t n, const double* A, double* L, do
     ZIGP_ENSURE(c, dl, ha.size()); ZIGP_ENSURE(c, dw, ha.size()); ZIGP_ENSURE(c, dt, ha.size());
     ZIGP_HIP(c, hipMemcpyAsync(dl.p, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice, c->stream));
     ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
-    ZIGP_TRY(potrf_trtri(c, dl.p, dw.p, dt.p, Mp, true));
+    ZIGP_TRY(potrf_trtri(c, dl.p, dw.p, dt.p, Mp, true, (int)n));
     ZIGP_TRY(check_info(c, "A"));
     std::vector<double> ho(ha.size());
     if (L) {

@@ -189,7 +189,9 @@ static int check_info(zigp_ctx* c, const char* what) {
 // ------------------------------------------------------------------------------------------------
 // L = chol(A) in place in `Lb` (which holds a copy of A on entry), W = L^-1.  Mp multiple of 128.
 // ------------------------------------------------------------------------------------------------
-static int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool want_W) {
+// Mreal = rows that are not identity padding (diagonal blocks factor only the panels that hold real rows)
+static int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool want_W, int Mreal = -1) {
+  if (Mreal < 0 || Mreal > Mp) Mreal = Mp;
   const int nb = Mp / BM;
   const int kb = BM / BK;  // k-steps per block
   // c->d_info is cleared by the caller (several factorizations may share one check_info)
@@ -198,7 +200,8 @@ static int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, 
   for (int j = 0; j < nb; ++j) {
     double* Ajj = Lb + (int64_t)j * BM * Mp + (int64_t)j * BM;
     double* Wjj = Wb + (int64_t)j * BM * Mp + (int64_t)j * BM;
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(1024), shm, c->stream, Ajj, Ajj, Wjj, (int64_t)Mp, j * BM, c->d_info);
+    const int nreal_j = std::max(0, std::min(BM, Mreal - j * BM));
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(1024), shm, c->stream, Ajj, Ajj, Wjj, (int64_t)Mp, j * BM, c->d_info, (nreal_j + PNB - 1) / PNB);
     ZIGP_HIP(c, hipGetLastError());
     if (j + 1 < nb) {
       TileList tp, ts;

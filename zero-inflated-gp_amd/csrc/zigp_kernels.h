@@ -511,7 +511,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 //   T = sum_k L_ik W_kj,  W_ij = -W_ii T.
 // LDS image: S[i][j], j <= i: L;  W[i][c], i > c, lives at S[c][i];  diag(W) in dinv.  ~25 workgroup barriers in total.
 __global__ void __launch_bounds__(1024)
-k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __restrict__ W, int64_t ld, int j0, int* info) {
+k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __restrict__ W, int64_t ld, int j0, int* info, int npan) {
+  // npan = number of 32-column panels that hold real rows; the rest of the block is identity padding (L = W = I there)
   extern __shared__ double S[];   // [128][129]
   __shared__ double dinv[PB];
   __shared__ double T[3][PNB][PNB + 1];
@@ -522,8 +523,10 @@ k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __res
     S[i * PBLD + j] = (j <= i) ? A[(int64_t)i * ld + j] : 0.0;
   }
   if (t == 0) fail = 0;
+  if (t < PB) dinv[t] = 1.0;
   __syncthreads();
-  for (int jb = 0; jb < PB; jb += PNB) {
+  const int nreal = npan * PNB;
+  for (int jb = 0; jb < nreal; jb += PNB) {
     if (t < 64) {   // (1)
       const int r = t & 31;                      // lanes 32..63 shadow lanes 0..31 (they never store)
       double a[PNB];
@@ -592,7 +595,7 @@ k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __res
     __syncthreads();
     __syncthreads();
     if (fail) return;
-    const int nbelow = PB - jb - PNB;   // rows under the diagonal block
+    const int nbelow = nreal - jb - PNB;   // real rows under the diagonal block
     // (2) L21[i][c] = sum_{k<=c} A21[i][k] W11[c][k]   (in place: all sums first, then the stores)
     double v[3];
 #pragma unroll
@@ -633,7 +636,7 @@ k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __res
   if (W) {
     // W[x][y]: x > y at S[y][x], x == y in dinv, x < y zero
     auto Wget = [&](int x, int y) -> double { return x > y ? S[y * PBLD + x] : (x == y ? dinv[x] : 0.0); };
-    constexpr int NBLK = PB / PNB;
+    const int NBLK = npan;
     for (int dist = 1; dist < NBLK; ++dist) {
       const int nblk = NBLK - dist;                 // blocks (bj + dist, bj), bj = 0 .. nblk-1
       for (int idx = t; idx < nblk * PNB * PNB; idx += 1024) {   // T = sum_k L_ik W_kj
