@@ -155,6 +155,9 @@ int zigp_kron_head_predict(zigp_ctx* ctx, const zigp_kron_params* p, int32_t lik
                            double jitter, double f_mu, double* out4);
 
 /* ---- measurement hooks (bench.py) ---- */
+/* Diagnostic: eager vs hipGraph-replayed Kronecker minibatch step; out_ms = {eager ms/step, replay ms/step} (tools/kron_graph.py). */
+int zigp_test_kron_graph(zigp_ctx* ctx, const zigp_kron_params* p, const double* X, const double* Y, int64_t N,
+                         double jitter, double scale, int32_t iters, double* out_ms);
 /* Stream overlap inside zigp_elbo (default off): when on, the HBM-bound kernels of a row chunk (Kuf-cotangent reductions,
  * the next chunk's Kuf panels) run on a second HIP stream underneath the chunk's two MFMA-bound rank-N updates.  Results
  * are bit-identical either way and the step is ~0.8 % shorter (tools/overlap_ab.py); it is off by default so that every

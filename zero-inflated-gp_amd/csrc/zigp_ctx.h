@@ -92,6 +92,7 @@ struct zigp_ctx {
   zigp::Latent lat[2];
   zigp::DevBuf pw_part;                 // pointwise block partials
   // mean function of f, m(x) = mean_b + mean_a . x (zigp_set_mean_function), and its gradient from the last zigp_elbo
+  bool capturing = false;               // diagnostic (zigp_test_kron_graph): enqueue only, no synchronisation or host post-processing
   bool overlap = false;                 // zigp_set_overlap: HBM-bound side kernels of a chunk run on stream2 under its SYRKs
   bool mean_on = false;
   double mean_a[8] = {0}, mean_b = 0.0, mean_da[8] = {0}, mean_db = 0.0;   // 8 = zigp::MAXD (zigp_kernels.h)

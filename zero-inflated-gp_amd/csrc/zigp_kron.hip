@@ -11,6 +11,7 @@
 // K_p^-1 comes from the blocked Cholesky + triangular inverse of the dense path (the reference uses an LU inverse,
 // tf.matrix_inverse :192; the two agree to O(cond * eps)).  All O(M_p^2 N) / O(M0 M1 N) products and every reduction over N run
 // on the fp64 MFMA GEMM core (operands padded to 128); the reverse pass is hand-derived.
+#include <chrono>
 #include "zigp_host.h"
 
 using namespace zigp;
@@ -530,7 +531,7 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;   // single-latent heads use the f latent only; g_offset is then f_mu
   if (!c->kron) { c->kron = new (std::nothrow) KronState(); c->kron_free = kron_free; if (!c->kron) { c->err = "out of memory"; return ZIGP_EHIP; } }
   KronState& ks = *c->kron;
-  ZIGP_TRY(begin_staged_call(c));
+  if (!c->capturing) ZIGP_TRY(begin_staged_call(c));
   const bool need_grad = grads != nullptr && !predict;
   const int D0 = p->D0, D1 = p->D1, ldx = D0 + D1;
   const int64_t Nc = std::max<int64_t>(1024, round_up(N, 1024));
@@ -627,6 +628,7 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
     }
     ZIGP_TRY(ts.join());
   }
+  if (c->capturing) return 0;
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   ZIGP_TRY(info_result(c, hinfo, "a Kronecker factor of Kuu"));
   double s_ve = 0, s_dn = 0, s_gv[2] = {0, 0};
@@ -720,6 +722,42 @@ int zigp_kron_head_predict(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, 
   if (N == 0) return ZIGP_OK;
   ZIGP_HIP(c, hipSetDevice(c->device));
   return kron_run(c, p, Xnew, nullptr, N, jitter, 1.0, f_mu, 0, true, out4, nullptr, nullptr, nullptr, lik, nullptr);
+}
+
+
+// Diagnostic: what replaying the minibatch step as a hipGraph would buy.  Runs the step eagerly (allocations, tile lists and
+// kernel attributes settle), captures the same enqueue sequence from both streams into a graph, and times `iters` replays
+// against `iters` eager steps.  The captured scalars (hyperparameters are kernel arguments today) are those of `p`, so the
+// replays recompute the same step; out_ms = {eager ms/step, graph ms/step}.
+int zigp_test_kron_graph(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
+                         int32_t iters, double* out_ms) {
+  if (!c || !out_ms || iters <= 0) return ZIGP_EARG;
+  ZIGP_TRY(validate_kron(c, p));
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  double ed = 0, kl = 0;
+  zigp_kron_grads g;
+  memset(&g, 0, sizeof(g));   // NULL outputs: gradients are computed and downloaded, not copied out
+  for (int w = 0; w < 3; ++w) ZIGP_TRY(kron_run(c, p, X, Y, N, jitter, scale, 0.0, 1, false, nullptr, &ed, &kl, &g));
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) ZIGP_TRY(kron_run(c, p, X, Y, N, jitter, scale, 0.0, 1, false, nullptr, &ed, &kl, &g));
+  out_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+  ZIGP_TRY(begin_staged_call(c));
+  hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  ZIGP_HIP(c, hipStreamBeginCapture(c->stream_main, hipStreamCaptureModeGlobal));
+  c->capturing = true;
+  const int rc = kron_run(c, p, X, Y, N, jitter, scale, 0.0, 1, false, nullptr, &ed, &kl, &g);
+  c->capturing = false;
+  c->stream = c->stream_main;
+  hipError_t e = hipStreamEndCapture(c->stream_main, &graph);
+  if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  ZIGP_HIP(c, e);
+  ZIGP_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  for (int w = 0; w < 3; ++w) { ZIGP_HIP(c, hipGraphLaunch(exec, c->stream_main)); ZIGP_HIP(c, hipStreamSynchronize(c->stream_main)); }
+  t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) { ZIGP_HIP(c, hipGraphLaunch(exec, c->stream_main)); ZIGP_HIP(c, hipStreamSynchronize(c->stream_main)); }
+  out_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+  (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+  return ZIGP_OK;
 }
 
 }  // extern "C"
