@@ -228,11 +228,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   constexpr int WNW = Shape<WAVES>::WNW, WTN = Shape<WAVES>::WTN, TNW = Shape<WAVES>::TNW, CHUNKS = Shape<WAVES>::CHUNKS;
   constexpr int RW = Shape<WAVES>::RW, TMW = Shape<WAVES>::TMW;
   // the 4-base A map costs 3 VGPRs more: used where the B tile is m/n-contiguous (1 base register), not in the K/K kernels
-#ifdef ZIGP_A_NEWMAP_8W
-  constexpr bool A_NEWMAP = (BLAY == LAY_MNCONTIG) || WAVES == 8;
-#else
   constexpr bool A_NEWMAP = (BLAY == LAY_MNCONTIG);
-#endif
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS destinations and wave-level skips stay on the SALU
