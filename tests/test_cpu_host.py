@@ -110,6 +110,12 @@ def test_pack_unpack_roundtrip():
     assert (ed, kl) == (3.0, 4.0)
     for k in GRAD_KEYS:
         assert np.array_equal(np.asarray(g[k]), np.asarray(g2[k]))
+    # optional mean-function gradients ride along when present (zigp_set_mean_function)
+    gm = dict(g, mean_a=rs.randn(3), mean_b=0.75)
+    vec, shapes = pack(1.0, 2.0, gm)
+    assert vec.size == 2 + sum(np.asarray(v).size for v in gm.values())
+    _, _, g3 = unpack(vec, shapes)
+    assert np.array_equal(g3['mean_a'], gm['mean_a']) and g3['mean_b'] == 0.75 and set(g3) == set(gm)
 
 
 class _OracleShardEngine:

@@ -275,3 +275,18 @@ def test_stream_overlap_is_bit_identical(engine):
         assert ed == ref[0] and kl == ref[1], k
         for name in g:
             assert np.array_equal(np.asarray(g[name]), np.asarray(ref[2][name])), (k, name)
+
+
+def test_mean_function_shards_sum_to_full(engine):
+    """per-shard partial gradients of the mean function add up (what ShardedELBO all-reduces)"""
+    X, Y, p = make_problem(5000, 64, 2, seed=4)
+    p = dict(p, mean_a=np.array([0.3, -0.2]), mean_b=0.1)
+    engine.set_chunk(2048)
+    engine.set_data(X, Y)
+    ed, kl, g = engine.elbo(p)
+    parts = [engine.elbo(p, rows=r, include_kl=(i == 0)) for i, r in enumerate(((0, 1777), (1777, 3100), (3100, 5000)))]
+    engine.set_chunk(32768)
+    assert abs(sum(q[0] for q in parts) - ed) <= 1e-11 * abs(ed)
+    for k in ('mean_a', 'mean_b', 'u_fm', 'noise'):
+        s = sum(np.asarray(q[2][k], dtype=float) for q in parts)
+        assert np.max(np.abs(s - np.asarray(g[k], dtype=float))) <= 1e-9 * max(np.max(np.abs(np.asarray(g[k], dtype=float))), 1e-300), k
