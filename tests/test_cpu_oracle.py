@@ -148,3 +148,25 @@ def test_head_numpy_and_torch_oracles_agree():
             fd = (o.kron_head_elbo(X, Y, dict(p, noise=0.05 + 1e-7), lik, 1e-5, 3.0, 0.1)[0]
                   - o.kron_head_elbo(X, Y, dict(p, noise=0.05 - 1e-7), lik, 1e-5, 3.0, 0.1)[0]) / 2e-7
             assert abs(fd - float(g['noise'])) < 1e-5 * abs(fd)
+
+
+def test_mean_function_in_both_oracles():
+    """fmean + mean_function(Xnew) (OnOffSVGP.py:134) for Constant / Linear: numpy == torch twin, autograd == central differences."""
+    import zigp_oracle as o
+    import zigp_oracle_torch as ot
+    from conftest import make_problem
+    X, Y, p = make_problem(300, 20, 2, seed=12)
+    p = dict(p, mean_a=np.array([0.4, -0.7]), mean_b=0.25)
+    e_np = o.elbo(X, Y, p, 1e-6, scale=2.0)[0]
+    e_t, _, _, g = ot.elbo_and_grad(X, Y, p, 1e-6, scale=2.0)
+    assert abs(e_np - e_t) <= 1e-10 * abs(e_t)
+    assert np.allclose(o.build_predict(X, p, 1e-6)[3], o.build_predict(X, {k: v for k, v in p.items() if not k.startswith('mean_')}, 1e-6)[3]
+                       + X @ p['mean_a'].reshape(-1, 1) + 0.25, rtol=0, atol=1e-13)
+    h = 1e-6
+    fd_b = (o.elbo(X, Y, dict(p, mean_b=0.25 + h), 1e-6, scale=2.0)[0] - o.elbo(X, Y, dict(p, mean_b=0.25 - h), 1e-6, scale=2.0)[0]) / (2 * h)
+    assert abs(fd_b - float(g['mean_b'])) <= 1e-6 * max(1.0, abs(fd_b))
+    for d in range(2):
+        ap, am = p['mean_a'].copy(), p['mean_a'].copy()
+        ap[d] += h; am[d] -= h
+        fd = (o.elbo(X, Y, dict(p, mean_a=ap), 1e-6, scale=2.0)[0] - o.elbo(X, Y, dict(p, mean_a=am), 1e-6, scale=2.0)[0]) / (2 * h)
+        assert abs(fd - float(g['mean_a'][d])) <= 1e-6 * max(1.0, abs(fd))
