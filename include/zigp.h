@@ -177,7 +177,7 @@ int zigp_profile_enable(zigp_ctx* ctx, int32_t on);
 int zigp_profile_get(zigp_ctx* ctx, double* ms /*[ZIGP_NCLASS]*/, int64_t* launches /*[ZIGP_NCLASS]*/,
                      double* flops /*[ZIGP_NCLASS] algorithmic*/);
 int zigp_profile_reset(zigp_ctx* ctx);
-/* Event pairs cost ~10 us each, so launches of the chunk loop are TIMED on every 4th full-size chunk only (ms / launches /
+/* Event pairs cost ~10 us each, so launches of the chunk loop are TIMED on every 8th full-size chunk only (ms / launches /
  * flops above describe those sampled launches); zigp_profile_totals returns the number of launches per class, sampled or not. */
 int zigp_profile_totals(zigp_ctx* ctx, int64_t* total_launches /*[ZIGP_NCLASS]*/);
 
