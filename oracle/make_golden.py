@@ -6,6 +6,8 @@ G2  g2_dense_oracle.npz : outputs of this repo's CPU restatement (oracle/zigp_or
     inputs: the 9-tuple, KL_f, KL_g, ELBO and the full gradient.  NOT produced by the reference
     (TensorFlow/GPflow are not installable): these fixtures freeze the oracle so that a later edit
     cannot silently change it; they do not pin it to the reference ("parity unpinned").
+G4  g4_kron_oracle.npz : this repo's literal Kronecker restatements (on/off, Gaussian and Bernoulli heads) frozen on a seeded
+    minibatch; like G2 it guards the oracle against drift, it does not pin it to the reference.
 G3  g3_utils_pptr.npz : outputs of the REFERENCE's own `preprocessing` class (onofftf/utils_pptr.py, NumPy/pandas only,
     imported in place) on a seeded synthetic station table: time filter, location/time scaling, kernel_params.
 """
@@ -88,9 +90,40 @@ def g3():
     np.savez_compressed(os.path.join(OUT, 'g3_utils_pptr.npz'), **out)
 
 
+def kron_problem(seed=3, N=180, M0=5, M1=6):
+    """seeded pptr-like minibatch + Kronecker parameter set (2 spatial columns, 1 temporal)"""
+    rs = np.random.RandomState(seed)
+    X = np.hstack([rs.rand(N, 2) * 10.0, rs.rand(N, 1)])
+    Y = np.where(rs.rand(N) > 0.6, np.abs(np.sin(X[:, 0]) + 0.3 * rs.randn(N)), 0.0)[:, None]
+    p = dict(Zf=[rs.rand(M0, 2) * 10.0, np.linspace(0, 1, M1)[:, None]], Zg=[rs.rand(M0, 2) * 10.0, np.linspace(0, 1, M1)[:, None]],
+             ell_f=[np.array([3.0, 3.6]), np.array([0.3])], ell_g=[np.array([2.4, 3.0]), np.array([0.45])],
+             var_f=[np.array([2.0]), np.array([1.5])], var_g=[np.array([1.2]), np.array([0.9])],
+             u_fm=0.1 * rs.randn(M0 * M1, 1), u_gm=0.1 * rs.randn(M0 * M1, 1),
+             u_fs_sqrt=0.5 + rs.rand(M0 * M1, 1), u_gs_sqrt=0.5 + rs.rand(M0 * M1, 1), noise=0.05)
+    return X, Y, p
+
+
+def g4():
+    """G4 g4_kron_oracle.npz : this repo's LITERAL Kronecker restatements (scripts/onoff.py:143-319, svgp.py, classifier.py) frozen on a
+    seeded minibatch: on/off ELBO + 9-tuple, Gaussian and Bernoulli head ELBOs + predictions.  Not produced by the reference."""
+    import zigp_oracle as o
+    X, Y, p = kron_problem()
+    out = {}
+    e, d, klf, klg = o.kron_elbo(X, Y, p, 1e-5, scale=4.0, g_offset=0.0)
+    out.update(onoff_elbo=e, onoff_data=d, onoff_klf=klf, onoff_klg=klg,
+               onoff_pred=np.stack([q.reshape(-1) for q in o.kron_build_predict(X, p, 1e-6, -1.0)]))
+    ph = {k: p[k] for k in ('Zf', 'ell_f', 'var_f', 'u_fm', 'u_fs_sqrt', 'noise')}
+    for lik, Yl in (('gaussian', Y), ('bernoulli', (Y > 0) * 1.0)):
+        e, d, kl = o.kron_head_elbo(X, Yl, ph, lik, 1e-5, scale=4.0, f_mu=0.2)
+        out.update({lik + '_elbo': e, lik + '_data': d, lik + '_kl': kl,
+                    lik + '_pred': np.stack([np.asarray(q).reshape(-1) for q in o.kron_head_predict(X, ph, lik, 1e-6, 0.2)])})
+    np.savez_compressed(os.path.join(OUT, 'g4_kron_oracle.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     g1()
     g2()
     g3()
+    g4()
     print(os.listdir(OUT))

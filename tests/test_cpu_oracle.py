@@ -170,3 +170,22 @@ def test_mean_function_in_both_oracles():
         ap[d] += h; am[d] -= h
         fd = (o.elbo(X, Y, dict(p, mean_a=ap), 1e-6, scale=2.0)[0] - o.elbo(X, Y, dict(p, mean_a=am), 1e-6, scale=2.0)[0]) / (2 * h)
         assert abs(fd - float(g['mean_a'][d])) <= 1e-6 * max(1.0, abs(fd))
+
+
+def test_kron_oracle_frozen_against_g4():
+    """the literal Kronecker restatements (on/off, Gaussian and Bernoulli heads) still reproduce tests/golden/g4_kron_oracle.npz"""
+    import zigp_oracle as o
+    from make_golden import kron_problem
+    g = np.load(os.path.join(GOLD, 'g4_kron_oracle.npz'))
+    X, Y, p = kron_problem()
+    e, d, klf, klg = o.kron_elbo(X, Y, p, 1e-5, scale=4.0, g_offset=0.0)
+    for got, key in ((e, 'onoff_elbo'), (d, 'onoff_data'), (klf, 'onoff_klf'), (klg, 'onoff_klg')):
+        assert abs(got - float(g[key])) <= 1e-11 * abs(float(g[key])), key
+    pred = np.stack([q.reshape(-1) for q in o.kron_build_predict(X, p, 1e-6, -1.0)])
+    assert np.max(np.abs(pred - g['onoff_pred'])) <= 1e-10 * np.max(np.abs(g['onoff_pred']))
+    ph = {k: p[k] for k in ('Zf', 'ell_f', 'var_f', 'u_fm', 'u_fs_sqrt', 'noise')}
+    for lik, Yl in (('gaussian', Y), ('bernoulli', (Y > 0) * 1.0)):
+        e, d, kl = o.kron_head_elbo(X, Yl, ph, lik, 1e-5, scale=4.0, f_mu=0.2)
+        assert abs(e - float(g[lik + '_elbo'])) <= 1e-11 * abs(float(g[lik + '_elbo'])) and abs(kl - float(g[lik + '_kl'])) <= 1e-11 * abs(kl)
+        pr = np.stack([np.asarray(q).reshape(-1) for q in o.kron_head_predict(X, ph, lik, 1e-6, 0.2)])
+        assert np.max(np.abs(pr - g[lik + '_pred'])) <= 1e-10 * np.max(np.abs(g[lik + '_pred']))
