@@ -155,7 +155,7 @@ def main():
                 hbm[k] = {'GBps': nbytes / (prof[k]['ms'] * 1e-3 / prof[k]['launches']) / 1e9, 'bytes_per_launch': nbytes}
         mfma_util = None
         try:
-            mu = json.load(open(os.path.join(ROOT, 'profiles', 'r01c_pmc_mfma_util.json')))
+            mu = json.load(open(os.path.join(ROOT, 'profiles', 'r01h_pmc_mfma_util.json')))
             mfma_util = {k.split('gemm_f64_kernel')[-1].split('(')[0]: round(v['mfma_busy_frac_of_simd_cycles'], 3)
                          for k, v in mu.items() if v['launches'] >= 8 and v['avg_us_under_pmc'] > 300}
         except Exception:
