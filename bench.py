@@ -83,6 +83,11 @@ def main():
         dist = dist_mod
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
 
+    from zigp import build as zigp_build
+    if local_rank == 0:
+        zigp_build.ensure()                   # builds libzigp.so only if the snapshot does not carry it (git checkout)
+    if dist is not None:
+        dist.barrier()
     import zigp
     from zigp.parallel import ShardedELBO
     N, M, D, jitter = args.rows, args.M, args.D, 1e-6

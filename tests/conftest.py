@@ -20,7 +20,7 @@ def pytest_sessionstart(session):
     from zigp import build as zb
     if not os.path.exists(zb.LIB):
         try:
-            zb.build()
+            zb.ensure()
         except Exception as e:          # reported by the tests that need the library
             sys.stderr.write('conftest: could not build libzigp.so: %s\n' % e)
 

@@ -39,5 +39,10 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def ensure():
+    """Build only when the library file is absent (a git checkout; a gpurun snapshot carries the built file)."""
+    return LIB if os.path.exists(LIB) else build(force=True)
+
+
 if __name__ == '__main__':
     print(build(force=True, verbose=True))
