@@ -128,7 +128,8 @@ int zigp_kron_predict(zigp_ctx* ctx, const zigp_kron_params* p, const double* Xn
 
 /* Mean function of the latent f: m(x) = b + a . x, added to fmean before the likelihood and in zigp_predict
  * (`fmean = fmean + self.mean_function(Xnew)`, onoffgpf/OnOffSVGP.py:29,134).  Covers GPflow's Zero (the reference default:
- * D = 0, b = 0 -- the state after zigp_create), Constant (D = 0, b = c) and Linear with one output (a[D], b).  The setting
+ * D = -1 -- the state after zigp_create; a and b are ignored), Constant (D = 0, b = c; enabled also when c == 0, so that the
+ * parameter still receives its gradient) and Linear with one output (a[D], b).  The setting
  * persists in the context.  zigp_get_mean_function_grad returns d(scale * sum var_exp)/d(a, b) of the LAST zigp_elbo
  * called with grads != NULL (zeros when the mean function is off); like the other gradients it is a per-shard partial
  * sum under data-parallel use. */
@@ -180,6 +181,9 @@ int zigp_profile_reset(zigp_ctx* ctx);
 /* Event pairs cost ~10 us each, so launches of the chunk loop are TIMED on every 8th full-size chunk only (ms / launches /
  * flops above describe those sampled launches); zigp_profile_totals returns the number of launches per class, sampled or not. */
 int zigp_profile_totals(zigp_ctx* ctx, int64_t* total_launches /*[ZIGP_NCLASS]*/);
+/* every = 1: time EVERY launch of the chunk loop, the partial last chunk included (sums are then exact, the step is ~1 % slower:
+ * bench.py's separate profiled pass); every = n > 1: full-size chunks only, every n-th (default 8). */
+int zigp_profile_sampling(zigp_ctx* ctx, int32_t every);
 
 /* ---- diagnostics used by the parity tests (building blocks through the same kernels) ---- */
 /* C (m,n) = op(A) * op(B) with the fp64 MFMA GEMM core; transA/transB as BLAS; all dims padded internally. */

@@ -247,6 +247,22 @@ def test_mean_function_matches_oracle(engine, kind):
     engine.set_chunk(32768)
 
 
+def test_constant_mean_at_zero_still_gets_its_gradient(engine):
+    """GPflow's Constant() defaults to c = 0 and an optimiser may land on 0: 'enabled' must not depend on the value."""
+    import zigp_oracle_torch as ot
+    X, Y, p = make_problem(1500, 48, 2, seed=33, ell=0.4)
+    engine.set_data(X, Y)
+    p = dict(p, mean_b=0.0)
+    ed, kl, g = engine.elbo(p, jitter=1e-6)
+    e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X, Y, p, 1e-6)
+    assert abs(ed - d_r) <= 1e-8 * abs(d_r)
+    assert abs(g_r['mean_b']) > 1e-3 and abs(g['mean_b'] - g_r['mean_b']) <= 1e-6 * abs(g_r['mean_b'])   # tolerance 1e-6, fp64
+    p = dict(p, mean_a=np.zeros(2))
+    ed, kl, g = engine.elbo(p, jitter=1e-6)
+    e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X, Y, p, 1e-6)
+    assert np.max(np.abs(np.asarray(g['mean_a']) - np.asarray(g_r['mean_a']))) <= 1e-6 * np.max(np.abs(np.asarray(g_r['mean_a'])))
+
+
 def test_mean_function_bad_arguments(engine):
     X, Y, p = make_problem(200, 16, 2, seed=3)
     engine.set_data(X, Y)

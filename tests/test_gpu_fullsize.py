@@ -110,3 +110,80 @@ def test_cfg3_stress_lengthscale_accuracy(engine):
         e = np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
         print('  stress grad %s relerr %.2e' % (k, e))
         assert e <= max(1e-6, 1e-13 * c), (k, e)
+
+
+# ---- BASELINE.json configs[1]: N = 1e5, D = 3, M = 512 ---------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def cfg2(engine):
+    sys.path.insert(0, ROOT)
+    import bench
+    X, Y, p = bench.synth(100000, 512, 3)
+    return X, Y, p
+
+
+def test_cfg2_chunk_invariance_shard_additivity_and_slice_vs_oracle(engine, cfg2):
+    import zigp_oracle_torch as ot
+    X, Y, p = cfg2
+    N = X.shape[0]
+    engine.set_chunk(32768)
+    engine.set_data(X, Y)
+    ed, kl, g = engine.elbo(p)
+    engine.set_chunk(8192)
+    ed2, kl2, g2 = engine.elbo(p)
+    engine.set_chunk(32768)
+    assert abs(ed - ed2) <= 1e-11 * abs(ed) and kl == kl2
+    for k in g:
+        assert np.max(np.abs(np.asarray(g[k]) - np.asarray(g2[k]))) <= 1e-8 * max(np.max(np.abs(np.asarray(g[k]))), 1e-300), k
+    cuts = [0, 33333, 70001, N]
+    parts = [engine.elbo(p, rows=(cuts[i], cuts[i + 1]), include_kl=(i == 0)) for i in range(3)]
+    assert abs(sum(q[0] for q in parts) - ed) <= 1e-11 * abs(ed)
+    for k in g:
+        s = sum(np.asarray(q[2][k]) for q in parts)
+        assert np.max(np.abs(s - np.asarray(g[k]))) <= 1e-8 * max(np.max(np.abs(np.asarray(g[k]))), 1e-300), k
+    n = 6000
+    eds, kls, gs = engine.elbo(p, rows=(50000, 50000 + n))
+    e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X[50000:50000 + n], Y[50000:50000 + n], p, 1e-6, chunk=3000)
+    print('cfg2 slice: data rel %.2e kl rel %.2e' % (abs(eds - d_r) / abs(d_r), abs(kls - kl_r) / abs(kl_r)))
+    assert abs(eds - d_r) <= 1e-8 * abs(d_r) and abs(kls - kl_r) <= 1e-9 * abs(kl_r)
+    for k in ot.PARAM_KEYS:
+        a, b = np.asarray(gs[k]).reshape(-1), np.asarray(g_r[k]).reshape(-1)
+        assert np.max(np.abs(a - b)) <= 1e-6 * max(np.max(np.abs(b)), 1e-300), k     # tolerance 1e-6 relative, fp64
+    out = engine.predict(p, X[:4000])
+    import zigp_oracle as o
+    ref = o.build_predict(X[:4000], p, 1e-6)
+    for i in range(9):
+        r = ref[i].reshape(-1)
+        assert np.max(np.abs(out[i] - r)) <= 1e-7 * max(np.max(np.abs(r)), 1e-300), i
+
+
+# ---- BASELINE.json configs[0], literally: toydata.mat, M = 50, Z as zero-inflated-gpflow.ipynb:107 --------------------------
+def test_cfg1_toydata_M50_matches_oracle(engine):
+    import scipy.io
+    import zigp_oracle as o
+    import zigp_oracle_torch as ot
+    d = scipy.io.loadmat(os.path.join(ROOT, 'tests', 'golden', 'toydata.mat'))
+    X, Y = d['x'].astype(np.float64), d['y'].astype(np.float64)
+    assert X.shape == (450, 1)
+    Z = np.delete(np.linspace(0, 10, 51, endpoint=False), 0)[:, None]      # ipynb:107 pattern with num_inducing = 51 -> M = 50
+    assert Z.shape == (50, 1)
+    ru = np.random.RandomState(5)
+    p = dict(Zf=Z.copy(), Zg=Z.copy(), u_fm=0.01 * ru.randn(50, 1), u_gm=0.01 * ru.randn(50, 1),      # OnOffSVGP.py:56-57 scale
+             u_fs_sqrt=np.ones((50, 1)), u_gs_sqrt=np.ones((50, 1)),                                   # :60-63
+             ell_f=np.array([2.0]), ell_g=np.array([2.0]), var_f=1.0, var_g=5.0, noise=0.01)          # ipynb:99-104,134
+    engine.set_chunk(32768)
+    engine.set_data(X, Y)
+    ed, kl, g = engine.elbo(p, jitter=1e-6)
+    e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X, Y, p, 1e-6)
+    Kuu = o.rbf_K(Z, Z, p['ell_f'], 1.0) + 1e-6 * np.eye(50)
+    print('cfg1 literal: cond(Kuu) %.2e, elbo rel %.2e, kl rel %.2e' % (np.linalg.cond(Kuu), abs((ed - kl) - e_r) / abs(e_r), abs(kl - kl_r) / abs(kl_r)))
+    assert abs((ed - kl) - e_r) <= 1e-6 * abs(e_r)          # north-star tolerance: 1e-6 relative, fp64
+    for k in ot.PARAM_KEYS:
+        a, b = np.asarray(g[k]).reshape(-1), np.asarray(g_r[k]).reshape(-1)
+        e = np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+        print('  cfg1 grad %s relerr %.2e' % (k, e))
+        assert e <= 1e-5, (k, e)     # cond(Kuu) ~ 1e9 at M = 50, l = 2 on [0,10]: gradients through K^-1 carry cond * eps
+    out = engine.predict(p, X, jitter=1e-6)
+    ref = o.build_predict(X, p, 1e-6)
+    for i in range(9):
+        r = ref[i].reshape(-1)
+        assert np.max(np.abs(out[i] - r)) <= 1e-6 * max(np.max(np.abs(r)), 1e-300), i

@@ -25,6 +25,18 @@ def durations(counter):
     return {k: tot[k] / cnt[k] for k in tot}
 
 
+
+def run_meta():
+    """provenance: hash of the kernel sources and the configuration the counters were collected on (bench.py only quotes a
+    summary whose hash and (M, chunk, D) match the run it is printed with)"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'zero-inflated-gp_amd'))
+    from zigp import build as zb
+    return {'csrc_hash': zb.source_hash(), 'M': int(os.environ.get('PMC_M', 1024)), 'chunk': int(os.environ.get('PMC_CHUNK', 32768)),
+            'D': int(os.environ.get('PMC_D', 3)), 'rows': int(os.environ.get('ROWS', 262144)),
+            'command': 'bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs --profile-steps 0 --no-overlap --rows $ROWS'}
+
 mf, n = per_kernel('SQ_VALU_MFMA_BUSY_CYCLES')
 gui, _ = per_kernel('GRBM_GUI_ACTIVE')
 sqb, _ = per_kernel('SQ_BUSY_CYCLES')
@@ -36,4 +48,5 @@ for k in mf:
     cyc = gui[k] / 8.0
     out[k] = {'launches': n[k], 'avg_us_under_pmc': dur.get(k, 0.0), 'mfma_busy_frac_of_simd_cycles': mf[k] / (cyc * 1024.0),
               'clock_GHz': cyc / (dur[k] * 1e3) if dur.get(k) else None, 'raw': {'SQ_VALU_MFMA_BUSY_CYCLES': mf[k], 'GRBM_GUI_ACTIVE': gui[k], 'SQ_BUSY_CYCLES': sqb.get(k)}}
+out['_meta'] = run_meta()
 print(json.dumps(out, indent=1))

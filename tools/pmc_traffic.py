@@ -21,6 +21,18 @@ def per_kernel(path, counter):
     return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
 
 
+
+def run_meta():
+    """provenance: hash of the kernel sources and the configuration the counters were collected on (bench.py only quotes a
+    summary whose hash and (M, chunk, D) match the run it is printed with)"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'zero-inflated-gp_amd'))
+    from zigp import build as zb
+    return {'csrc_hash': zb.source_hash(), 'M': int(os.environ.get('PMC_M', 1024)), 'chunk': int(os.environ.get('PMC_CHUNK', 32768)),
+            'D': int(os.environ.get('PMC_D', 3)), 'rows': int(os.environ.get('ROWS', 262144)),
+            'command': 'bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs --profile-steps 0 --no-overlap --rows $ROWS'}
+
 f = per_kernel(sys.argv[1], 'FETCH_SIZE')
 w = per_kernel(sys.argv[2], 'WRITE_SIZE')
 out = {}
@@ -31,4 +43,5 @@ for k in f:
     wk = w.get(k, (0.0, 0))[0]
     out[k] = {'launches': n, 'fetch_KB_raw_per_launch': fk, 'write_KB_raw_per_launch': wk,
               'hbm_bytes_per_launch_corrected': (2.0 * fk + wk) * 1024.0}
+out['_meta'] = run_meta()
 print(json.dumps(out, indent=1))

@@ -356,7 +356,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   auto chunk_rows = [&](int64_t n0) { return std::min<int64_t>(Nc_full, round_up(row_end - n0, 1024)); };
   auto sampled = [&](int64_t n0) {   // kernel timing (HIP events) covers FULL chunks only, so the averages describe full-size launches
     if (!c->prof_on) return false;
-    if (row_end - row_begin <= Nc_full) return true;
+    if (c->prof_every <= 1 || row_end - row_begin <= Nc_full) return true;   // every launch, the partial last chunk included
     return chunk_rows(n0) == Nc_full && (((n0 - row_begin) / Nc_full) % c->prof_every) == 0;
   };
   struct SideGuard { zigp_ctx* c; ~SideGuard() { c->stream = c->stream_main; c->prof_skip = false; } } side_guard{c};
@@ -580,13 +580,18 @@ static_assert(MAXD == 8, "zigp_ctx::mean_a / mean_da hold MAXD entries");
 
 int zigp_set_mean_function(zigp_ctx* c, const double* a, int32_t D, double b) {
   if (!c) return ZIGP_EARG;
-  if (D < 0 || D > MAXD || (D > 0 && !a)) return fail_arg(c, "zigp_set_mean_function: need 0 <= D <= 8 and a[D]");
+  if (D < -1 || D > MAXD || (D > 0 && !a)) return fail_arg(c, "zigp_set_mean_function: need -1 <= D <= 8 and a[D]");
+  if (D < 0) {   // Zero: no mean function, nothing to differentiate
+    for (int d = 0; d < MAXD; ++d) c->mean_a[d] = 0.0;
+    c->mean_b = 0.0; c->mean_on = false;
+    return ZIGP_OK;
+  }
   if (!std::isfinite(b)) return fail_arg(c, "zigp_set_mean_function: b must be finite");
   for (int d = 0; d < D; ++d)
     if (!std::isfinite(a[d])) return fail_arg(c, "zigp_set_mean_function: a must be finite");
   for (int d = 0; d < MAXD; ++d) c->mean_a[d] = (d < D) ? a[d] : 0.0;
   c->mean_b = b;
-  c->mean_on = (D > 0) || (b != 0.0);   // D = 0, b = 0 is GPflow's Zero: the point-wise kernel skips the term
+  c->mean_on = true;   // "enabled" is independent of the values: a Constant at exactly 0 still gets its gradient
   return ZIGP_OK;
 }
 
@@ -696,6 +701,12 @@ int zigp_profile_get(zigp_ctx* c, double* ms, int64_t* launches, double* flops) 
   if (!c) return ZIGP_EARG;
   prof_collect(c);
   for (int i = 0; i < ZIGP_NCLASS; ++i) { if (ms) ms[i] = c->prof_ms[i]; if (launches) launches[i] = c->prof_n[i]; if (flops) flops[i] = c->prof_flops[i]; }
+  return ZIGP_OK;
+}
+int zigp_profile_sampling(zigp_ctx* c, int32_t every) {
+  if (!c) return ZIGP_EARG;
+  if (every < 1) return fail_arg(c, "zigp_profile_sampling: every must be >= 1");
+  c->prof_every = every;
   return ZIGP_OK;
 }
 int zigp_profile_totals(zigp_ctx* c, int64_t* total_launches) {

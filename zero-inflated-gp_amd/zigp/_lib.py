@@ -83,6 +83,7 @@ SIGNATURES = {
     'zigp_profile_get': (C.c_int, [C.c_void_p, dp, C.POINTER(C.c_int64), dp]),
     'zigp_profile_reset': (C.c_int, [C.c_void_p]),
     'zigp_profile_totals': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    'zigp_profile_sampling': (C.c_int, [C.c_void_p, C.c_int32]),
     'zigp_test_gemm': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, dp, dp, dp]),
     'zigp_test_potrf_trtri': (C.c_int, [C.c_void_p, C.c_int64, dp, dp, dp]),
 }

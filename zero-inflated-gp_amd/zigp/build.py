@@ -8,18 +8,31 @@ CSRC = os.path.join(ROOT, 'csrc')
 LIBDIR = os.path.join(ROOT, 'lib')
 LIB = os.path.join(LIBDIR, 'libzigp.so')
 SOURCES = ['zigp_lib.hip']
-HEADERS = ['zigp_dense.hip', 'zigp_kron.hip', 'zigp_gemm.h', 'zigp_ctx.h', 'zigp_kernels.h', 'zigp_host.h', '../../include/zigp.h']
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(('.h', '.hip')) and f not in SOURCES) + ['../../include/zigp.h']
+
+
+HASHFILE = LIB + '.srchash'
+
+
+def source_hash():
+    """sha256 over every file the library is built from (file mtimes do not survive a snapshot copy; contents do)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p):
+            h.update(f.encode())
+            h.update(open(p, 'rb').read())
+    for k in ('ZIGP_EXTRA_FLAGS', 'ZIGP_NSTAGE', 'ZIGP_WAVES_DEFAULT'):
+        h.update(('%s=%s' % (k, os.environ.get(k, ''))).encode())
+    return h.hexdigest()
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    """True when the library is missing or was built from other sources than the ones on disk"""
+    if not os.path.exists(LIB) or not os.path.exists(HASHFILE):
         return True
-    t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+    return open(HASHFILE).read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -36,12 +49,15 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed:\n' + r.stdout + r.stderr)
+    with open(HASHFILE, 'w') as f:
+        f.write(source_hash() + '\n')
     return LIB
 
 
 def ensure():
-    """Build only when the library file is absent (a git checkout; a gpurun snapshot carries the built file)."""
-    return LIB if os.path.exists(LIB) else build(force=True)
+    """Make sure lib/libzigp.so matches the sources on disk: builds when the file is absent (a git checkout) or stale (an edit
+    to csrc/ or include/zigp.h after the last build); a gpurun snapshot carries the built file and its source hash."""
+    return build(force=False)
 
 
 if __name__ == '__main__':

@@ -65,6 +65,7 @@ class DenseEngine:
         rc = self.lib.zigp_create(C.byref(self.ctx), int(device))
         if rc != 0:
             raise ZigpError('zigp_create failed (rc=%d): no usable HIP device %d' % (rc, device))
+        self.device = int(device)
         self.N = 0
         self.D = 0
         self._keep = None
@@ -95,8 +96,16 @@ class DenseEngine:
 
     def set_data_device(self, X_t, Y_t):
         """Adopt torch CUDA float64 tensors (no copy); they are kept alive by this object."""
+        import torch
         N, D = X_t.shape
-        assert X_t.is_contiguous() and Y_t.is_contiguous() and str(X_t.dtype) == 'torch.float64'
+        if not (X_t.is_cuda and Y_t.is_cuda and X_t.device.index == self.device and Y_t.device.index == self.device):
+            raise ValueError('set_data_device: tensors must live on cuda:%d, the engine\'s device' % self.device)
+        if not (X_t.is_contiguous() and Y_t.is_contiguous() and X_t.dtype == torch.float64 and Y_t.dtype == torch.float64):
+            raise ValueError('set_data_device: need contiguous float64 tensors')
+        if Y_t.numel() != N:
+            raise ValueError('Y must have N entries')
+        # the engine's streams are non-blocking: nothing orders them after the torch stream that produced the tensors
+        torch.cuda.current_stream(self.device).synchronize()
         self._keep = (X_t, Y_t)
         _check(self.lib, self.ctx, self.lib.zigp_set_data_device(self.ctx, C.c_void_p(X_t.data_ptr()), C.c_void_p(Y_t.data_ptr()), N, D))
         self.N, self.D = N, D
@@ -130,7 +139,7 @@ class DenseEngine:
         Constant, 'mean_a' (+ 'mean_b') its Linear; neither is Zero.  Returns len(mean_a) when one is set, else None."""
         a, b = p.get('mean_a'), p.get('mean_b')
         if a is None and b is None:
-            _check(self.lib, self.ctx, self.lib.zigp_set_mean_function(self.ctx, None, 0, 0.0))
+            _check(self.lib, self.ctx, self.lib.zigp_set_mean_function(self.ctx, None, -1, 0.0))
             return None
         a = np.zeros(0) if a is None else as_f64(a).reshape(-1)
         if a.size not in (0, D):
@@ -307,6 +316,10 @@ class DenseEngine:
 
     def profile_enable(self, on=True):
         _check(self.lib, self.ctx, self.lib.zigp_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_sampling(self, every=8):
+        """every=1 times every launch of the chunk loop (exact sums); n > 1 samples every n-th full-size chunk"""
+        _check(self.lib, self.ctx, self.lib.zigp_profile_sampling(self.ctx, int(every)))
 
     def profile_reset(self):
         _check(self.lib, self.ctx, self.lib.zigp_profile_reset(self.ctx))
