@@ -510,18 +510,18 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // then the off-diagonal 32x32 blocks of W = L^-1 by block forward substitution, all blocks of one block-diagonal at a time:
 //   T = sum_k L_ik W_kj,  W_ij = -W_ii T.
 // LDS image: S[i][j], j <= i: L;  W[i][c], i > c, lives at S[c][i];  diag(W) in dinv.  ~25 workgroup barriers in total.
-__global__ void __launch_bounds__(1024)
-k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __restrict__ W, int64_t ld, int j0, int* info, int npan) {
-  // npan = number of 32-column panels that hold real rows; the rest of the block is identity padding (L = W = I there)
-  extern __shared__ double S[];   // [128][129]
-  __shared__ double dinv[PB];
-  __shared__ double T[3][PNB][PNB + 1];
-  __shared__ int fail;
+// Body shared by k_potrf_diag and the fused Kronecker factor kernel (zigp_kronf.hip): on entry S[i][j], j <= i, holds the lower
+// triangle of the SPD block (identity beyond the real rows); on exit L in the lower triangle, W = L^-1 as described above
+// (only if want_W).  Returns false when a pivot was not positive (info set, S unfinished).  All 1024 threads must call it.
+struct PotrfShared { double dinv[PB]; double T[3][PNB][PNB + 1]; int fail; };
+__device__ __forceinline__ double potrf_wget(const double* S, const double* dinv, int x, int y) {
+  return x > y ? S[y * PBLD + x] : (x == y ? dinv[x] : 0.0);
+}
+__device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int j0, int* info, int npan, bool want_W) {
+  double* dinv = psh.dinv;
+  double (*T)[PNB][PNB + 1] = psh.T;
+  int& fail = psh.fail;
   const int t = threadIdx.x;
-  for (int idx = t; idx < PB * PB; idx += 1024) {
-    const int i = idx >> 7, j = idx & 127;
-    S[i * PBLD + j] = (j <= i) ? A[(int64_t)i * ld + j] : 0.0;
-  }
   if (t == 0) fail = 0;
   if (t < PB) dinv[t] = 1.0;
   __syncthreads();
@@ -585,7 +585,7 @@ k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __res
       }
     }
     __syncthreads();
-    if (fail) return;
+    if (fail) return false;
     {   // scatter the diagonal block: L11 -> lower triangle, inv(L11)^T -> upper triangle, its diagonal -> dinv
       const int r = t >> 5, k = t & 31;
       if (k <= r) S[(jb + r) * PBLD + jb + k] = T[0][r][k];
@@ -593,8 +593,6 @@ k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __res
       if (k == r) dinv[jb + r] = T[1][r][r];
     }
     __syncthreads();
-    __syncthreads();
-    if (fail) return;
     const int nbelow = nreal - jb - PNB;   // real rows under the diagonal block
     // (2) L21[i][c] = sum_{k<=c} A21[i][k] W11[c][k]   (in place: all sums first, then the stores)
     double v[3];
@@ -627,15 +625,9 @@ k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __res
     }
     __syncthreads();
   }
-  if (L) {
-    for (int idx = t; idx < PB * PB; idx += 1024) {
-      const int i = idx >> 7, j = idx & 127;
-      L[(int64_t)i * ld + j] = (j <= i) ? S[i * PBLD + j] : 0.0;
-    }
-  }
-  if (W) {
+  if (want_W) {
     // W[x][y]: x > y at S[y][x], x == y in dinv, x < y zero
-    auto Wget = [&](int x, int y) -> double { return x > y ? S[y * PBLD + x] : (x == y ? dinv[x] : 0.0); };
+    auto Wget = [&](int x, int y) -> double { return potrf_wget(S, dinv, x, y); };
     const int NBLK = npan;
     for (int dist = 1; dist < NBLK; ++dist) {
       const int nblk = NBLK - dist;                 // blocks (bj + dist, bj), bj = 0 .. nblk-1
@@ -656,9 +648,32 @@ k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __res
       }
       __syncthreads();
     }
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(1024)
+k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __restrict__ W, int64_t ld, int j0, int* info, int npan) {
+  // npan = number of 32-column panels that hold real rows; the rest of the block is identity padding (L = W = I there)
+  extern __shared__ double S[];   // [128][129]
+  __shared__ PotrfShared psh;
+  const int t = threadIdx.x;
+  for (int idx = t; idx < PB * PB; idx += 1024) {
+    const int i = idx >> 7, j = idx & 127;
+    S[i * PBLD + j] = (j <= i) ? A[(int64_t)i * ld + j] : 0.0;
+  }
+  __syncthreads();
+  if (!potrf_diag_lds(S, psh, j0, info, npan, W != nullptr)) return;
+  if (L) {
     for (int idx = t; idx < PB * PB; idx += 1024) {
       const int i = idx >> 7, j = idx & 127;
-      W[(int64_t)i * ld + j] = Wget(i, j);
+      L[(int64_t)i * ld + j] = (j <= i) ? S[i * PBLD + j] : 0.0;
+    }
+  }
+  if (W) {
+    for (int idx = t; idx < PB * PB; idx += 1024) {
+      const int i = idx >> 7, j = idx & 127;
+      W[(int64_t)i * ld + j] = potrf_wget(S, psh.dinv, i, j);
     }
   }
 }

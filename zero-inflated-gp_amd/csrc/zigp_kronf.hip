@@ -1,0 +1,632 @@
+// Fused Kronecker (space x time) path for small inducing grids (every factor <= 16 * KF_NBMAX points): scripts/onoff.py:143-319,
+// onofftf/main.py:350-387, onofftf/onoffpred.py:127-200.  Same factored algebra as zigp_kron.hip (see its header), but nothing
+// of size O(M N) ever reaches HBM: a WAVE owns a tile of 16 points and keeps every per-point vector in registers in the
+// operand layout of v_mfma_f64_4x4x4 (4 blocks), whose B operand and D result share one lane layout
+//     V[q] of lane l  =  V(row 4 q + l / 16, point l % 16)
+// so the result of one product feeds the next one with no shuffle or LDS round trip.  The M_p x M_p / M_0 x M_1 matrices
+// (P_p = K_p^-1, Alpha, S2 and the transposes) are read from global memory (L1 / L2 resident: 8 KB each at 32 x 32) in
+// A-FRAGMENT ORDER, one coalesced 32-byte load per lane and 16 x 16 x 4 product.  Launches per step:
+//   k_kf_factor   one workgroup per factor: K_p + jitter, Cholesky + triangular inverse in LDS, P_p = W^T W, logdet, diag(P_p)
+//   k_kf_latent   one workgroup per latent: Alpha = P0 U P1, T0 = U P1, T1 = P0 U, KL scalars, fragment images
+//   k_kf_forward  q0, q1, mean, S-term per point (part[4][N])                      (kron_inf value, scripts/onoff.py:186-213)
+//   k_kron_pointwise / k_kron_head_pointwise (zigp_kron.hip)                       (probit moments, likelihood, reverse pass)
+//   k_kf_backward recomputes the forward tile, hand-derived reverse pass; the sums over points (dAlpha, dS2, dP_p and the
+//                 kernel-cotangent moments) accumulate in MFMA accumulators across the wave's tiles -> one partial per wave
+//   k_kf_reduce   fixed-order sum of the per-wave partials
+//   k_kf_finish   one workgroup per latent: the M x M reverse pass (dU, dP_p -> dK_p -> dZ, dell, dvar; KL gradient)
+// plus ONE staged host->device copy (parameters + minibatch) and ONE device->host copy (results).
+#include "zigp_host.h"
+
+namespace zigp {
+
+constexpr int KF_NBMAX = 2;       // 16-row blocks per factor handled by the register-resident kernels (M_p <= 32)
+constexpr int KF_LD = 18;         // LDS row stride (doubles) of a [rows][16 points] tile: A- and B-fragment reads are conflict free
+constexpr int KF_WAVES = 4;       // waves per workgroup (each wave works alone on its own tiles)
+
+struct KfFac {
+  int M, nb, D, col0;
+  double inv_ell[MAXD];
+  double var;
+  double zc[MAXD];          // centre of the moment sums (mid-range of Z_p): sum t (x - z)^k is rebuilt from sum t (x - zc)^k
+  const double* Z;          // [M][D]
+  const double* PF;         // P_p in A-fragment order [nb][4 nb][16][4]
+};
+struct KfLat {
+  KfFac f[2];
+  const double *AlF, *S2F;      // [nb0][4 nb1][16][4]   rows = factor-0 index, k = factor-1 index
+  const double *AlTF, *S2TF;    // [nb1][4 nb0][16][4]   the transposes
+  double* part;                 // [4][Npad]: q0, q1, mean, S-term
+  const double *gm, *gv, *dq0, *dq1;   // [Npad] cotangents from the point-wise kernel
+  double* acc;                  // [waves][KF_ACC_BLOCKS][4][64] per-wave partial sums
+  double knn;
+};
+struct KfArgs {
+  KfLat lat[2];
+  const double* X; int64_t N, Npad; int ldx;
+  int tpw;        // tiles per wave
+  int ntiles;     // Npad / 16
+};
+
+// accumulator blocks of the backward kernel (16 x 16 each), compile-time layout for KF_NBMAX
+constexpr int KF_B_AL = 0;
+constexpr int KF_B_S2 = KF_B_AL + KF_NBMAX * KF_NBMAX;
+constexpr int KF_B_P0 = KF_B_S2 + KF_NBMAX * KF_NBMAX;
+constexpr int KF_B_P1 = KF_B_P0 + KF_NBMAX * KF_NBMAX;
+constexpr int KF_B_K0 = KF_B_P1 + KF_NBMAX * KF_NBMAX;
+constexpr int KF_B_K1 = KF_B_K0 + KF_NBMAX;
+constexpr int KF_ACC_BLOCKS = KF_B_K1 + KF_NBMAX;
+constexpr int KF_ACC_DOUBLES = KF_ACC_BLOCKS * 256;
+
+__device__ __forceinline__ double kf_mfma(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+// order LDS traffic of ONE wave: the stores above must be visible to (and not sink below) the loads that follow
+__device__ __forceinline__ void kf_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// out[4 rb + r] += sum_ks F(rb, ks)[r] * in[ks]:   out (16 nba rows) = A (16 nba x 4 ksn) . in (4 ksn rows), A in fragment order
+template <int NBA, int QK>
+__device__ __forceinline__ void kf_frag_mm(double (&out)[4 * NBA], const double* __restrict__ F, int nba, int ksn, const double (&in)[QK], int slot) {
+  const double4* __restrict__ F4 = reinterpret_cast<const double4*>(F);
+#pragma unroll
+  for (int rb = 0; rb < NBA; ++rb) {
+    if (rb < nba) {
+#pragma unroll
+      for (int ks = 0; ks < QK; ++ks) {
+        if (ks < ksn) {
+          const double4 a = F4[(rb * ksn + ks) * 16 + slot];
+          out[4 * rb + 0] = kf_mfma(a.x, in[ks], out[4 * rb + 0]);
+          out[4 * rb + 1] = kf_mfma(a.y, in[ks], out[4 * rb + 1]);
+          out[4 * rb + 2] = kf_mfma(a.z, in[ks], out[4 * rb + 2]);
+          out[4 * rb + 3] = kf_mfma(a.w, in[ks], out[4 * rb + 3]);
+        }
+      }
+    }
+  }
+}
+
+// K_p tile of this wave: K[q] = k_p(z_{4q+g}, x_n) for the lane's point n, 0 for padding rows / points   (kern.K(Z_p, xnew), :199-201)
+template <int Q>
+__device__ __forceinline__ void kf_ktile(double (&K)[Q], const KfFac& f, const double* __restrict__ xrow, bool valid, int g) {
+  double xs[MAXD];
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) xs[d] = (d < f.D && valid) ? xrow[f.col0 + d] * f.inv_ell[d] : 0.0;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int m = 4 * q + g;
+    double v = 0.0;
+    if (q < 4 * f.nb && m < f.M && valid) {
+      double r2 = 0.0;
+#pragma unroll
+      for (int d = 0; d < MAXD; ++d)
+        if (d < f.D) { const double t = f.Z[m * f.D + d] * f.inv_ell[d] - xs[d]; r2 = fma(t, t, r2); }
+      v = f.var * exp(-0.5 * r2);
+    }
+    K[q] = v;
+  }
+}
+
+// sum over the 4 row groups (lanes l, l^16, l^32, l^48): every lane ends with the column total, fixed order
+__device__ __forceinline__ double kf_colsum(double v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+constexpr int KF_Q = 4 * KF_NBMAX;   // registers per [16 nb][16] tile quantity
+
+struct KfFwdTile { double K0[KF_Q], K1[KF_Q], A0[KF_Q], A1[KF_Q], B0[KF_Q], C0[KF_Q]; };
+
+// forward pieces of one tile: A_p = P_p K_p, B0 = Alpha K1, C0 = S2 A1^2
+__device__ __forceinline__ void kf_forward_tile(KfFwdTile& t, const KfLat& L, const double* __restrict__ xrow, bool valid, int g, int slot) {
+  const KfFac &f0 = L.f[0], &f1 = L.f[1];
+  kf_ktile<KF_Q>(t.K0, f0, xrow, valid, g);
+  kf_ktile<KF_Q>(t.K1, f1, xrow, valid, g);
+#pragma unroll
+  for (int q = 0; q < KF_Q; ++q) { t.A0[q] = 0.0; t.A1[q] = 0.0; t.B0[q] = 0.0; t.C0[q] = 0.0; }
+  kf_frag_mm<KF_NBMAX, KF_Q>(t.A0, f0.PF, f0.nb, 4 * f0.nb, t.K0, slot);
+  kf_frag_mm<KF_NBMAX, KF_Q>(t.A1, f1.PF, f1.nb, 4 * f1.nb, t.K1, slot);
+  kf_frag_mm<KF_NBMAX, KF_Q>(t.B0, L.AlF, f0.nb, 4 * f1.nb, t.K1, slot);
+  double sq[KF_Q];
+#pragma unroll
+  for (int q = 0; q < KF_Q; ++q) sq[q] = t.A1[q] * t.A1[q];
+  kf_frag_mm<KF_NBMAX, KF_Q>(t.C0, L.S2F, f0.nb, 4 * f1.nb, sq, slot);
+}
+
+// ---- forward: part[0..3][n] = q0 = k0.a0, q1 = k1.a1, mean = k0^T Alpha k1, st = (a0^2)^T S2 (a1^2) -------------------------
+__global__ void __launch_bounds__(64 * KF_WAVES)
+k_kf_forward(KfArgs a) {
+  const KfLat& L = a.lat[blockIdx.y];
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
+  const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
+  const int t1 = min((w + 1) * a.tpw, a.ntiles);
+  for (int tile = w * a.tpw; tile < t1; ++tile) {
+    const int64_t pn = (int64_t)tile * 16 + n;
+    const bool valid = pn < a.N;
+    KfFwdTile t;
+    kf_forward_tile(t, L, a.X + (valid ? pn : 0) * a.ldx, valid, g, slot);
+    double q0 = 0.0, q1 = 0.0, mu = 0.0, st = 0.0;
+#pragma unroll
+    for (int q = 0; q < KF_Q; ++q) {
+      q0 = fma(t.K0[q], t.A0[q], q0);
+      q1 = fma(t.K1[q], t.A1[q], q1);
+      mu = fma(t.K0[q], t.B0[q], mu);
+      st = fma(t.A0[q] * t.A0[q], t.C0[q], st);
+    }
+    q0 = kf_colsum(q0); q1 = kf_colsum(q1); mu = kf_colsum(mu); st = kf_colsum(st);
+    if (g == 0) { L.part[pn] = q0; L.part[a.Npad + pn] = q1; L.part[2 * a.Npad + pn] = mu; L.part[3 * a.Npad + pn] = st; }
+  }
+}
+
+// tile in registers -> LDS image [row][KF_LD]
+__device__ __forceinline__ void kf_store_tile(double* T, const double (&V)[KF_Q], int nb, int g, int n) {
+#pragma unroll
+  for (int q = 0; q < KF_Q; ++q)
+    if (q < 4 * nb) T[(4 * q + g) * KF_LD + n] = V[q];
+}
+// acc[(rb, cb)] += A(rows of rb, 16 points) . B(16 points, cols of cb), A / B from LDS tiles (rows x points), optional squares and
+// per-point scale on B;  MODE 0: plain, 1: both squared
+template <int NBR, int NBC, int MODE>
+__device__ __forceinline__ void kf_accum(double (&acc)[NBR * NBC][4], const double* TA, int nbr, const double* TB, int nbc,
+                                         const double (&sck)[4], bool scaled, int lane) {
+  const int ai = lane & 3, kk = lane >> 4, bj = lane & 15;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    double bf[NBC];
+#pragma unroll
+    for (int cb = 0; cb < NBC; ++cb) {
+      double b = (cb < nbc) ? TB[(16 * cb + bj) * KF_LD + 4 * ks + kk] : 0.0;
+      if (MODE == 1) b *= b;
+      if (scaled) b *= sck[ks];
+      bf[cb] = b;
+    }
+#pragma unroll
+    for (int rb = 0; rb < NBR; ++rb) {
+      if (rb < nbr) {
+        double af[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double v = TA[(16 * rb + 4 * r + ai) * KF_LD + 4 * ks + kk];
+          if (MODE == 1) v *= v;
+          af[r] = v;
+        }
+#pragma unroll
+        for (int cb = 0; cb < NBC; ++cb)
+          if (cb < nbc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rb * NBC + cb][r] = kf_mfma(af[r], bf[cb], acc[rb * NBC + cb][r]);
+          }
+      }
+    }
+  }
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------------------
+// per point, with gm / gv the cotangents of mean / var and dq_p = -gv q_other:
+//   B1 = Alpha^T K0, C1 = S2^T A0^2 ;  dA_p = 2 gv A_p . C_p ;  dK_p = gm B_p + 2 dq_p A_p + P_p dA_p ;  E_p = dq_p K_p + dA_p
+//   dAlpha += K0 diag(gm) K1^T ; dS2 += A0^2 diag(gv) (A1^2)^T ; dP_p += E_p K_p^T
+//   moments of t_p = dK_p . K_p against {1, x - zc, (x - zc)^2}  (-> d var_p, d Z_p, d ell_p in k_kf_finish)
+__global__ void __launch_bounds__(64 * KF_WAVES, 1)
+k_kf_backward(KfArgs a) {
+  extern __shared__ double lds[];
+  const KfLat& L = a.lat[blockIdx.y];
+  const KfFac &f0 = L.f[0], &f1 = L.f[1];
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
+  const int wib = threadIdx.x >> 6;
+  const int w = blockIdx.x * KF_WAVES + wib;
+  constexpr int TILE = 16 * KF_NBMAX * KF_LD;
+  double* bK0 = lds + wib * 4 * TILE; double* bK1 = bK0 + TILE; double* c0 = bK1 + TILE; double* c1 = c0 + TILE;
+  double accAl[KF_NBMAX * KF_NBMAX][4], accS2[KF_NBMAX * KF_NBMAX][4], accP0[KF_NBMAX * KF_NBMAX][4], accP1[KF_NBMAX * KF_NBMAX][4];
+  double accK0[KF_NBMAX][4], accK1[KF_NBMAX][4];
+#pragma unroll
+  for (int b = 0; b < KF_NBMAX * KF_NBMAX; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { accAl[b][r] = 0.0; accS2[b][r] = 0.0; accP0[b][r] = 0.0; accP1[b][r] = 0.0; }
+#pragma unroll
+  for (int b = 0; b < KF_NBMAX; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { accK0[b][r] = 0.0; accK1[b][r] = 0.0; }
+  const double one4[4] = {1.0, 1.0, 1.0, 1.0};
+
+  const int t1 = min((w + 1) * a.tpw, a.ntiles);
+  for (int tile = w * a.tpw; tile < t1; ++tile) {
+    const int64_t pn = (int64_t)tile * 16 + n;
+    const bool valid = pn < a.N;
+    const double* xrow = a.X + (valid ? pn : 0) * a.ldx;
+    KfFwdTile t;
+    kf_forward_tile(t, L, xrow, valid, g, slot);
+    const double gmn = L.gm[pn], gvn = L.gv[pn], dq0n = L.dq0[pn], dq1n = L.dq1[pn];   // zero for padding points (scale 0 in the point-wise kernel)
+    double B1[KF_Q], C1[KF_Q], sq[KF_Q];
+#pragma unroll
+    for (int q = 0; q < KF_Q; ++q) { B1[q] = 0.0; C1[q] = 0.0; sq[q] = t.A0[q] * t.A0[q]; }
+    kf_frag_mm<KF_NBMAX, KF_Q>(B1, L.AlTF, f1.nb, 4 * f0.nb, t.K0, slot);
+    kf_frag_mm<KF_NBMAX, KF_Q>(C1, L.S2TF, f1.nb, 4 * f0.nb, sq, slot);
+    double dA0[KF_Q], dA1[KF_Q], PdA0[KF_Q], PdA1[KF_Q];
+#pragma unroll
+    for (int q = 0; q < KF_Q; ++q) {
+      dA0[q] = 2.0 * gvn * t.A0[q] * t.C0[q];
+      dA1[q] = 2.0 * gvn * t.A1[q] * C1[q];
+      PdA0[q] = 0.0; PdA1[q] = 0.0;
+    }
+    kf_frag_mm<KF_NBMAX, KF_Q>(PdA0, f0.PF, f0.nb, 4 * f0.nb, dA0, slot);
+    kf_frag_mm<KF_NBMAX, KF_Q>(PdA1, f1.PF, f1.nb, 4 * f1.nb, dA1, slot);
+    // ---- LDS images for the sums over points (k index = point): K tiles, E tiles
+    kf_store_tile(bK0, t.K0, f0.nb, g, n);
+    kf_store_tile(bK1, t.K1, f1.nb, g, n);
+    {
+      double E[KF_Q];
+#pragma unroll
+      for (int q = 0; q < KF_Q; ++q) E[q] = fma(dq0n, t.K0[q], dA0[q]);
+      kf_store_tile(c0, E, f0.nb, g, n);
+#pragma unroll
+      for (int q = 0; q < KF_Q; ++q) E[q] = fma(dq1n, t.K1[q], dA1[q]);
+      kf_store_tile(c1, E, f1.nb, g, n);
+    }
+    kf_wave_sync();
+    double gmk[4], gvk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { gmk[ks] = __shfl(gmn, 4 * ks + g, 64); gvk[ks] = __shfl(gvn, 4 * ks + g, 64); }
+    kf_accum<KF_NBMAX, KF_NBMAX, 0>(accAl, bK0, f0.nb, bK1, f1.nb, gmk, true, lane);
+    kf_accum<KF_NBMAX, KF_NBMAX, 0>(accP0, c0, f0.nb, bK0, f0.nb, one4, false, lane);
+    kf_accum<KF_NBMAX, KF_NBMAX, 0>(accP1, c1, f1.nb, bK1, f1.nb, one4, false, lane);
+    kf_wave_sync();
+    kf_store_tile(c0, t.A0, f0.nb, g, n);
+    kf_store_tile(c1, t.A1, f1.nb, g, n);
+    kf_wave_sync();
+    kf_accum<KF_NBMAX, KF_NBMAX, 1>(accS2, c0, f0.nb, c1, f1.nb, gvk, true, lane);
+    kf_wave_sync();
+    {
+      double tt[KF_Q];
+#pragma unroll
+      for (int q = 0; q < KF_Q; ++q) tt[q] = fma(gmn, t.B0[q], fma(2.0 * dq0n, t.A0[q], PdA0[q])) * t.K0[q];
+      kf_store_tile(c0, tt, f0.nb, g, n);
+#pragma unroll
+      for (int q = 0; q < KF_Q; ++q) tt[q] = fma(gmn, B1[q], fma(2.0 * dq1n, t.A1[q], PdA1[q])) * t.K1[q];
+      kf_store_tile(c1, tt, f1.nb, g, n);
+    }
+    kf_wave_sync();
+    // moments: acc(rows of factor p, col j) += sum_n t_p[row, n] psi_j(x_n),  psi = {1, xc_d, xc_d^2}
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const KfFac& f = L.f[p];
+      double xc[MAXD];
+#pragma unroll
+      for (int d = 0; d < MAXD; ++d) xc[d] = (d < f.D && valid) ? xrow[f.col0 + d] - f.zc[d] : 0.0;
+      const double* T = p == 0 ? c0 : c1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        double psi = (n == 0) ? 1.0 : 0.0;
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d)
+          if (d < f.D) {
+            const double xv = __shfl(xc[d], 4 * ks + g, 64);
+            if (n == 1 + d) psi = xv;
+            if (n == 1 + f.D + d) psi = xv * xv;
+          }
+#pragma unroll
+        for (int rb = 0; rb < KF_NBMAX; ++rb)
+          if (rb < f.nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double av = T[(16 * rb + 4 * r + (lane & 3)) * KF_LD + 4 * ks + g];
+              if (p == 0) accK0[rb][r] = kf_mfma(av, psi, accK0[rb][r]);
+              else accK1[rb][r] = kf_mfma(av, psi, accK1[rb][r]);
+            }
+          }
+      }
+    }
+    kf_wave_sync();
+  }
+  // per-wave partials, [block][r][lane]
+  double* out = L.acc + (int64_t)w * KF_ACC_DOUBLES;
+#pragma unroll
+  for (int b = 0; b < KF_NBMAX * KF_NBMAX; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      out[((KF_B_AL + b) * 4 + r) * 64 + lane] = accAl[b][r];
+      out[((KF_B_S2 + b) * 4 + r) * 64 + lane] = accS2[b][r];
+      out[((KF_B_P0 + b) * 4 + r) * 64 + lane] = accP0[b][r];
+      out[((KF_B_P1 + b) * 4 + r) * 64 + lane] = accP1[b][r];
+    }
+#pragma unroll
+  for (int b = 0; b < KF_NBMAX; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      out[((KF_B_K0 + b) * 4 + r) * 64 + lane] = accK0[b][r];
+      out[((KF_B_K1 + b) * 4 + r) * 64 + lane] = accK1[b][r];
+    }
+}
+
+// ---- fixed-order sum of the per-wave partials; un-permutes the accumulator layout into row-major matrices ---------------------
+// work layout per latent (doubles): dAl [32][32], dS2 [32][32], dP0 [32][32], dP1 [32][32], Kr0 [32][16], Kr1 [32][16]   (32 = 16 KF_NBMAX)
+constexpr int KF_MQ = 16 * KF_NBMAX;
+constexpr int KF_W_AL = 0, KF_W_S2 = KF_MQ * KF_MQ, KF_W_P0 = 2 * KF_MQ * KF_MQ, KF_W_P1 = 3 * KF_MQ * KF_MQ, KF_W_K0 = 4 * KF_MQ * KF_MQ,
+              KF_W_K1 = KF_W_K0 + KF_MQ * 16, KF_W_TOTAL = KF_W_K1 + KF_MQ * 16;
+constexpr int KF_RED_GROUPS = 16;
+__global__ void __launch_bounds__(256)
+k_kf_reduce(const double* __restrict__ acc0, const double* __restrict__ acc1, int nwaves, double* __restrict__ work0, double* __restrict__ work1) {
+  __shared__ double sh[KF_RED_GROUPS][16];
+  const double* acc = blockIdx.y == 0 ? acc0 : acc1;
+  double* work = blockIdx.y == 0 ? work0 : work1;
+  const int e = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
+  const int per = (nwaves + KF_RED_GROUPS - 1) / KF_RED_GROUPS;
+  const int w0 = grp * per, w1 = min(w0 + per, nwaves);
+  double s = 0.0;
+  for (int w = w0; w < w1; ++w) s += acc[(int64_t)w * KF_ACC_DOUBLES + e];
+  sh[grp][threadIdx.x & 15] = s;
+  __syncthreads();
+  if (grp != 0) return;
+  double tot = 0.0;
+#pragma unroll
+  for (int q = 0; q < KF_RED_GROUPS; ++q) tot += sh[q][threadIdx.x & 15];
+  // e = (block * 4 + r) * 64 + lane  ->  element (16 rb + 4 r + lane / 16, 16 cb + lane % 16) of its matrix
+  const int lane = e & 63, r = (e >> 6) & 3, blk = e >> 8;
+  const int ri = 4 * r + (lane >> 4), cj = lane & 15;
+  int base, rb, cb, ld;
+  if (blk < KF_B_K0) {
+    const int which = blk / (KF_NBMAX * KF_NBMAX), b = blk % (KF_NBMAX * KF_NBMAX);
+    base = which * KF_MQ * KF_MQ; rb = b / KF_NBMAX; cb = b % KF_NBMAX; ld = KF_MQ;
+  } else {
+    const int b = blk - KF_B_K0;
+    base = (b < KF_NBMAX) ? KF_W_K0 : KF_W_K1; rb = b % KF_NBMAX; cb = 0; ld = 16;
+  }
+  work[base + (16 * rb + ri) * ld + 16 * cb + cj] = tot;
+}
+
+// =============================================================================================================================
+// M x M stages
+// =============================================================================================================================
+struct KfFactorJob {
+  const double* Z; int M, D, Mq; double inv_ell[MAXD]; double var;   // Mq = 16 nb
+  double* K;        // [128][128] identity padded Kuu factor + jitter (kept for the Kuu-gradient reductions)
+  double* P;        // [Mq][Mq] row-major K^-1 (zero padded)
+  double* PF;       // fragment order
+  double* dvec;     // [Mq] diag(P), then dvec[Mq] = logdet K = sum log L_ii^2
+};
+struct KfFactorArgs { KfFactorJob job[4]; double jitter; int* info; };
+
+// fragment image of a row-major matrix: F[((rb * ksn + ks) * 16 + slot) * 4 + r] = A(16 rb + 4 r + slot % 4, 4 ks + slot / 4)
+__device__ __forceinline__ void kf_write_frag(double* __restrict__ F, int nbr, int ksn, int t, int nthreads, const double* __restrict__ A, int64_t lda,
+                                              bool transposed) {
+  const int total = nbr * ksn * 64;
+  for (int idx = t; idx < total; idx += nthreads) {
+    const int r = idx & 3, slot = (idx >> 2) & 15, blk = idx >> 6, ks = blk % ksn, rb = blk / ksn;
+    const int row = 16 * rb + 4 * r + (slot & 3), k = 4 * ks + (slot >> 2);
+    F[idx] = transposed ? A[(int64_t)k * lda + row] : A[(int64_t)row * lda + k];
+  }
+}
+
+
+// One workgroup (1024 threads) per factor: K_p = k_p(Z_p) + jitter I (scripts/onoff.py:188-190), L = chol(K_p) and W = L^-1 in LDS
+// (tf.cholesky onofftf/main.py:355; the explicit inverse of scripts/onoff.py:192 is formed as P = W^T W), logdet, diag(P).
+__global__ void __launch_bounds__(1024)
+k_kf_factor(KfFactorArgs a) {
+  extern __shared__ double S[];   // [128][129]
+  __shared__ PotrfShared psh;
+  __shared__ double red[16];
+  const KfFactorJob& jb = a.job[blockIdx.x];
+  const int t = threadIdx.x, M = jb.M, Mq = jb.Mq, D = jb.D;
+  for (int idx = t; idx < PB * PB; idx += 1024) {
+    const int i = idx >> 7, j = idx & 127;
+    double v;
+    if (i < M && j < M) {
+      double r2 = 0.0;
+      for (int d = 0; d < D; ++d) { const double q = (jb.Z[i * D + d] - jb.Z[j * D + d]) * jb.inv_ell[d]; r2 = fma(q, q, r2); }
+      v = jb.var * exp(-0.5 * r2) + ((i == j) ? a.jitter : 0.0);     // same expression as k_rbf_matrix
+    } else {
+      v = (i == j) ? 1.0 : 0.0;
+    }
+    jb.K[idx] = v;
+    S[i * PBLD + j] = (j <= i) ? v : 0.0;
+  }
+  __syncthreads();
+  if (!potrf_diag_lds(S, psh, 1000 * (int)blockIdx.x, a.info, (M + PNB - 1) / PNB, true)) return;
+  // logdet K = sum log L_ii^2 (fixed order: strided partials, then 16 wave sums in order)
+  {
+    double ld = 0.0;
+    for (int i = t; i < M; i += 1024) { const double l = S[i * PBLD + i]; ld += log(l * l); }
+    ld = wave_sum(ld);
+    if ((t & 63) == 0) red[t >> 6] = ld;
+    __syncthreads();
+    if (t == 0) { double q = 0.0; for (int w = 0; w < 16; ++w) q += red[w]; jb.dvec[Mq] = q; }
+  }
+  // P = W^T W:  P[i][j] = sum_{k >= max(i,j)} W[k][i] W[k][j]
+  for (int idx = t; idx < Mq * Mq; idx += 1024) {
+    const int i = idx / Mq, j = idx - i * Mq;
+    double v = 0.0;
+    if (i < M && j < M) {
+      for (int k = max(i, j); k < M; ++k) v = fma(potrf_wget(S, psh.dinv, k, i), potrf_wget(S, psh.dinv, k, j), v);
+    }
+    jb.P[idx] = v;
+    if (i == j) jb.dvec[i] = v;
+  }
+  __syncthreads();   // P is re-read below by other threads of this workgroup
+  kf_write_frag(jb.PF, Mq / 16, Mq / 4, t, 1024, jb.P, Mq, false);
+}
+
+// C (m x n) = op(A) (m x k) * op(B) (k x n), row-major operands in global memory (L1-resident sizes), all threads of the workgroup
+template <bool TA, bool TB, bool ACC>
+__device__ __forceinline__ void kf_small_mm(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B,
+                                            int ldb, int m, int n, int k, double alpha = 1.0) {
+  for (int idx = threadIdx.x; idx < m * n; idx += blockDim.x) {
+    const int i = idx / n, j = idx - i * n;
+    double v = 0.0;
+    for (int q = 0; q < k; ++q) v = fma(TA ? A[q * lda + i] : A[i * lda + q], TB ? B[j * ldb + q] : B[q * ldb + j], v);
+    if (ACC) C[i * ldc + j] += alpha * v; else C[i * ldc + j] = alpha * v;
+  }
+}
+
+struct KfLatentJob {
+  int M0, M1, Mq0, Mq1;
+  const double *P0, *P1, *dvec0, *dvec1;     // from k_kf_factor
+  const double *u, *s;                       // [M0*M1] from the parameter pack
+  double *U, *S2, *T0, *T1, *Al;             // [Mq0][Mq1] zero padded: U, s^2, U P1, P0 U, Alpha = P0 U P1
+  double *AlF, *S2F, *AlTF, *S2TF;           // fragment images
+  double* klv;                               // [8]: sum U.Alpha, sum log s^2, sum d0 d1 s^2, logdet K0, logdet K1
+};
+struct KfLatentArgs { KfLatentJob job[2]; };
+
+__global__ void __launch_bounds__(1024)
+k_kf_latent(KfLatentArgs a) {
+  __shared__ double sh[16];
+  const KfLatentJob& jb = a.job[blockIdx.x];
+  const int t = threadIdx.x, M0 = jb.M0, M1 = jb.M1, Mq0 = jb.Mq0, Mq1 = jb.Mq1;
+  for (int idx = t; idx < Mq0 * Mq1; idx += 1024) {
+    const int i = idx / Mq1, j = idx - i * Mq1;
+    const bool in = i < M0 && j < M1;
+    const double sv = in ? jb.s[i * M1 + j] : 0.0;
+    jb.U[idx] = in ? jb.u[i * M1 + j] : 0.0;
+    jb.S2[idx] = sv * sv;
+  }
+  __syncthreads();
+  kf_small_mm<false, false, false>(jb.T0, Mq1, jb.U, Mq1, jb.P1, Mq1, Mq0, Mq1, Mq1);      // T0 = U P1
+  kf_small_mm<false, false, false>(jb.T1, Mq1, jb.P0, Mq0, jb.U, Mq1, Mq0, Mq1, Mq0);      // T1 = P0 U
+  __syncthreads();
+  kf_small_mm<false, false, false>(jb.Al, Mq1, jb.P0, Mq0, jb.T0, Mq1, Mq0, Mq1, Mq0);     // Alpha = P0 (U P1)   (= __kron_mv, :193)
+  __syncthreads();
+  kf_write_frag(jb.AlF, Mq0 / 16, Mq1 / 4, t, 1024, jb.Al, Mq1, false);
+  kf_write_frag(jb.S2F, Mq0 / 16, Mq1 / 4, t, 1024, jb.S2, Mq1, false);
+  kf_write_frag(jb.AlTF, Mq1 / 16, Mq0 / 4, t, 1024, jb.Al, Mq1, true);
+  kf_write_frag(jb.S2TF, Mq1 / 16, Mq0 / 4, t, 1024, jb.S2, Mq1, true);
+  // KL scalars (GaussKLkron, onofftf/main.py:350-387, factored): fixed-order sums
+  double av = 0.0, bv = 0.0, cv = 0.0;
+  for (int idx = t; idx < M0 * M1; idx += 1024) {
+    const int i = idx / M1, j = idx - i * M1;
+    const int64_t o = (int64_t)i * Mq1 + j;
+    const double sv = jb.s[idx];
+    av = fma(jb.U[o], jb.Al[o], av);
+    bv += log(sv * sv);
+    cv = fma(jb.dvec0[i] * jb.dvec1[j], sv * sv, cv);
+  }
+  double vals[3] = {av, bv, cv};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    double v = wave_sum(vals[q]);
+    __syncthreads();
+    if ((t & 63) == 0) sh[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) { double r = 0.0; for (int w = 0; w < 16; ++w) r += sh[w]; jb.klv[q] = r; }
+  }
+  if (t == 0) { jb.klv[3] = jb.dvec0[Mq0]; jb.klv[4] = jb.dvec1[Mq1]; }
+}
+
+// One workgroup per latent: the M x M reverse pass.  Inputs: the summed accumulators (k_kf_reduce) and the forward matrices.
+//   dU = P0 dAl P1 ;  dP0 += dAl T0^T ;  dP1 += T1^T dAl                                   (Alpha = P0 U P1)
+//   KL:  dP_p -= 1/4 (Q_p + Q_p^T) + 1/2 diag(w_p),  Q0 = T0 U^T, Q1 = U^T T1, w0_i = sum_j d1_j s2_ij, w1_j = sum_i d0_i s2_ij
+//   dK_p = -P_p sym(dP_p) P_p - kl * 1/2 M_other P_p  ->  Kuu-style reductions against K_p into krow_p; data moments added
+//   gu = dU - kl Alpha ;  gs = 2 s dS2 - kl (-1/s + d0_i d1_j s)
+struct KfFinishJob {
+  int M0, M1, Mq0, Mq1, D0, D1;
+  const double *P0, *P1, *dvec0, *dvec1, *K0, *K1, *Z0, *Z1;
+  double zc0[MAXD], zc1[MAXD];
+  const double *U, *S2, *T0, *T1, *Al, *s;
+  double* work;        // KF_W_TOTAL summed accumulators, then scratch: X0, X1, Q (3 x [KF_MQ][KF_MQ]) behind it
+  double *krow0, *krow1, *gu, *gs;     // outputs: [M0][2 + 2 D0], [M1][2 + 2 D1], [M0*M1], [M0*M1]
+};
+struct KfFinishArgs { KfFinishJob job[2]; double jitter; int with_kl; };
+
+__device__ __forceinline__ void kf_factor_backward(const KfFinishJob& jb, int p, double* dP, const double* Kr, double* X, double* G, double jitter,
+                                                   bool with_kl) {
+  const int t = threadIdx.x;
+  const int M = p == 0 ? jb.M0 : jb.M1, Mq = p == 0 ? jb.Mq0 : jb.Mq1, Mo = p == 0 ? jb.M1 : jb.M0, D = p == 0 ? jb.D0 : jb.D1;
+  const double* P = p == 0 ? jb.P0 : jb.P1;
+  const double* Kuu = p == 0 ? jb.K0 : jb.K1;
+  const double* Z = p == 0 ? jb.Z0 : jb.Z1;
+  const double* zc = p == 0 ? jb.zc0 : jb.zc1;
+  double* krow = p == 0 ? jb.krow0 : jb.krow1;
+  // X = sym(dP) P ; G = -P X - coef P
+  for (int idx = t; idx < Mq * Mq; idx += blockDim.x) {
+    const int i = idx / Mq, j = idx - i * Mq;
+    double v = 0.0;
+    for (int q = 0; q < Mq; ++q) v = fma(0.5 * (dP[i * KF_MQ + q] + dP[q * KF_MQ + i]), P[q * Mq + j], v);
+    X[i * KF_MQ + j] = v;
+  }
+  __syncthreads();
+  const double coef = with_kl ? 0.5 * (double)Mo : 0.0;
+  for (int idx = t; idx < Mq * Mq; idx += blockDim.x) {
+    const int i = idx / Mq, j = idx - i * Mq;
+    double v = 0.0;
+    for (int q = 0; q < Mq; ++q) v = fma(P[i * Mq + q], X[q * KF_MQ + j], v);
+    G[i * KF_MQ + j] = -v - coef * P[i * Mq + j];
+  }
+  __syncthreads();
+  // krow[m][c]: Kuu part (as k_kuu_grad, Kz = K_p - jitter I) + data moments rebuilt around z_m
+  const int W = 2 + 2 * D;
+  for (int idx = t; idx < M * W; idx += blockDim.x) {
+    const int m = idx / W, c = idx - m * W;
+    double v = 0.0;
+    if (c <= 2 * D) {
+      const int d = (c == 0) ? 0 : (c - 1) % D;
+      const double zm = Z[m * D + d];
+      for (int j = 0; j < M; ++j) {
+        const double kz = Kuu[m * PB + j] - ((m == j) ? jitter : 0.0);
+        const double tt = G[m * KF_MQ + j] * kz;
+        const double df = Z[j * D + d] - zm;
+        v += (c == 0) ? tt : ((c <= D) ? 2.0 * tt * df : tt * df * df);
+      }
+      const double s0 = Kr[m * 16];
+      if (c == 0) v += s0;
+      else {
+        const double dz = zm - zc[d], s1 = Kr[m * 16 + 1 + d];
+        if (c <= D) v += s1 - dz * s0;
+        else v += Kr[m * 16 + 1 + D + d] - 2.0 * dz * s1 + dz * dz * s0;
+      }
+    }
+    krow[idx] = v;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+k_kf_finish(KfFinishArgs a) {
+  const KfFinishJob& jb = a.job[blockIdx.x];
+  const int t = threadIdx.x, M0 = jb.M0, M1 = jb.M1, Mq0 = jb.Mq0, Mq1 = jb.Mq1;
+  const bool kl = a.with_kl != 0;
+  double* dAl = jb.work + KF_W_AL; double* dS2 = jb.work + KF_W_S2; double* dP0 = jb.work + KF_W_P0; double* dP1 = jb.work + KF_W_P1;
+  const double* Kr0 = jb.work + KF_W_K0; const double* Kr1 = jb.work + KF_W_K1;
+  double* X = jb.work + KF_W_TOTAL; double* G = X + KF_MQ * KF_MQ; double* Q = G + KF_MQ * KF_MQ; double* dU = Q + KF_MQ * KF_MQ;
+  // X = dAl P1 ; dU = P0 X
+  kf_small_mm<false, false, false>(X, KF_MQ, dAl, KF_MQ, jb.P1, Mq1, Mq0, Mq1, Mq1);
+  // dP0 += dAl T0^T ; dP1 += T1^T dAl
+  kf_small_mm<false, true, true>(dP0, KF_MQ, dAl, KF_MQ, jb.T0, Mq1, Mq0, Mq0, Mq1);
+  kf_small_mm<true, false, true>(dP1, KF_MQ, jb.T1, Mq1, dAl, KF_MQ, Mq1, Mq1, Mq0);
+  __syncthreads();
+  kf_small_mm<false, false, false>(dU, KF_MQ, jb.P0, Mq0, X, KF_MQ, Mq0, Mq1, Mq0);
+  __syncthreads();
+  // u / s gradients
+  for (int idx = t; idx < M0 * M1; idx += 1024) {
+    const int i = idx / M1, j = idx - i * M1;
+    const double sv = jb.s[idx];
+    double gu = dU[i * KF_MQ + j], gs = 2.0 * sv * dS2[i * KF_MQ + j];
+    if (kl) { gu -= jb.Al[i * Mq1 + j]; gs -= (-1.0 / sv + jb.dvec0[i] * jb.dvec1[j] * sv); }
+    jb.gu[idx] = gu; jb.gs[idx] = gs;
+  }
+  // KL pieces on dP_p, then the factor reverse passes
+  for (int p = 0; p < 2; ++p) {
+    const int Mq = p == 0 ? Mq0 : Mq1;
+    double* dP = p == 0 ? dP0 : dP1;
+    __syncthreads();
+    if (kl) {
+      if (p == 0) kf_small_mm<false, true, false>(Q, KF_MQ, jb.T0, Mq1, jb.U, Mq1, Mq0, Mq0, Mq1);     // Q0 = T0 U^T
+      else kf_small_mm<true, false, false>(Q, KF_MQ, jb.U, Mq1, jb.T1, Mq1, Mq1, Mq1, Mq0);           // Q1 = U^T T1
+      __syncthreads();
+      for (int idx = t; idx < Mq * Mq; idx += 1024) {
+        const int i = idx / Mq, j = idx - i * Mq;
+        if (j > i) continue;
+        double v = 0.5 * (dP[i * KF_MQ + j] + dP[j * KF_MQ + i]) - 0.25 * (Q[i * KF_MQ + j] + Q[j * KF_MQ + i]);
+        if (i == j) {
+          double w = 0.0;
+          if (p == 0) { for (int o = 0; o < M1; ++o) w = fma(jb.dvec1[o], jb.S2[i * Mq1 + o], w); }
+          else { for (int o = 0; o < M0; ++o) w = fma(jb.dvec0[o], jb.S2[o * Mq1 + i], w); }
+          v -= 0.5 * w;
+        }
+        dP[i * KF_MQ + j] = v; dP[j * KF_MQ + i] = v;
+      }
+      __syncthreads();
+    }
+    kf_factor_backward(jb, p, dP, p == 0 ? Kr0 : Kr1, X, G, a.jitter, kl);
+  }
+}
+
+}  // namespace zigp
