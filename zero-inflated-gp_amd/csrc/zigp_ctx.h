@@ -52,6 +52,7 @@ struct Latent {
 };
 
 struct KronState;   // Kronecker-path buffers (zigp_kron.hip)
+struct KfState;     // fused Kronecker path (zigp_kronf.hip)
 
 // Page-locked host staging for the small per-step transfers (parameters in, sums and gradients out).  A copy between
 // device and PAGEABLE host memory makes the runtime stage and wait; through this arena the H2D copies are truly
@@ -102,6 +103,9 @@ struct zigp_ctx {
   zigp::PinnedArena pinned;             // host staging of the per-step transfers
   zigp::KronState* kron = nullptr;
   void (*kron_free)(zigp::KronState*) = nullptr;
+  zigp::KfState* kronf = nullptr;
+  void (*kronf_free)(zigp::KfState*) = nullptr;
+  bool kron_legacy = false;             // diagnostic: force the panel (GEMM-core) Kronecker path
   std::map<std::string, zigp::TileList> tiles;
   // profiling
   bool prof_on = false;

@@ -547,6 +547,7 @@ int zigp_destroy(zigp_ctx* c) {
   DevBuf* bs[] = {&c->ownX, &c->ownY, &c->pw_part, &c->out9, &c->scratch, &c->scratch2};
   for (DevBuf* b : bs) b->release();
   if (c->kron && c->kron_free) c->kron_free(c->kron);
+  if (c->kronf && c->kronf_free) c->kronf_free(c->kronf);
   for (auto& kv : c->tiles) if (kv.second.d) (void)hipFree(kv.second.d);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->d_info) (void)hipFree(c->d_info);

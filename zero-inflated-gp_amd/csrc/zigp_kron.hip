@@ -523,11 +523,27 @@ int latent_backward(zigp_ctx* c, KronLatent& lt, const double* dX, int64_t N, in
 
 }  // namespace
 
+#include "zigp_kronf.hip"
+
 namespace {
 
+int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
+                    double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
+                    int lik, double* d_offset);
+
+// small grids go through the fused register-resident kernels (zigp_kronf.hip); larger factors through the panel path below
 int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
              double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
              int lik = ZIGP_LIK_ONOFF, double* d_offset = nullptr) {
+  const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;
+  if (!c->capturing && !c->kron_legacy && kf_eligible(p, nlat))
+    return kronf_run(c, p, X, Y, N, jitter, scale, g_offset, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset);
+  return kron_run_panels(c, p, X, Y, N, jitter, scale, g_offset, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset);
+}
+
+int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
+                    double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
+                    int lik, double* d_offset) {
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;   // single-latent heads use the f latent only; g_offset is then f_mu
   if (!c->kron) { c->kron = new (std::nothrow) KronState(); c->kron_free = kron_free; if (!c->kron) { c->err = "out of memory"; return ZIGP_EHIP; } }
   KronState& ks = *c->kron;

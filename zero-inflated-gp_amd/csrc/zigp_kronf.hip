@@ -629,4 +629,273 @@ k_kf_finish(KfFinishArgs a) {
   }
 }
 
+
+// =============================================================================================================================
+// host orchestration
+// =============================================================================================================================
+struct KfState {
+  DevBuf in, mat, pts, acc, res, out;
+};
+static void kf_free(KfState* k) {
+  DevBuf* bs[] = {&k->in, &k->mat, &k->pts, &k->acc, &k->res, &k->out};
+  for (DevBuf* b : bs) b->release();
+  delete k;
+}
+
+// the register-resident kernels cover factors of up to 16 KF_NBMAX inducing points and 7 input columns (1 + 2 D moment columns <= 16)
+static bool kf_eligible(const zigp_kron_params* p, int nlat) {
+  const int lim = 16 * KF_NBMAX;
+  if (p->D0 > 7 || p->D1 > 7) return false;
+  if (p->M0f > lim || p->M1f > lim) return false;
+  if (nlat == 2 && (p->M0g > lim || p->M1g > lim)) return false;
+  return true;
+}
+
+struct KfHostLatent { int M[2]; const double* Z[2]; const double* ell[2]; double var[2]; const double* u; const double* s; };
+
+// per-factor / per-latent regions of KfState::mat (doubles)
+constexpr size_t KF_FAC_K = 0, KF_FAC_P = (size_t)PB * PB, KF_FAC_PF = KF_FAC_P + KF_MQ * KF_MQ, KF_FAC_DV = KF_FAC_PF + KF_MQ * KF_MQ,
+                 KF_FAC_SIZE = KF_FAC_DV + KF_MQ + 8;
+constexpr size_t KF_LAT_U = 0, KF_LAT_S2 = 1 * KF_MQ * KF_MQ, KF_LAT_T0 = 2 * KF_MQ * KF_MQ, KF_LAT_T1 = 3 * KF_MQ * KF_MQ, KF_LAT_AL = 4 * KF_MQ * KF_MQ,
+                 KF_LAT_ALF = 5 * KF_MQ * KF_MQ, KF_LAT_S2F = 6 * KF_MQ * KF_MQ, KF_LAT_ALTF = 7 * KF_MQ * KF_MQ, KF_LAT_S2TF = 8 * KF_MQ * KF_MQ,
+                 KF_LAT_KLV = 9 * KF_MQ * KF_MQ, KF_LAT_WORK = KF_LAT_KLV + 8, KF_LAT_SIZE = KF_LAT_WORK + KF_W_TOTAL + 4 * KF_MQ * KF_MQ;
+// per-latent region of KfState::res
+constexpr int KF_KROW_W = 2 + 2 * MAXD;
+constexpr size_t KF_RES_KLV = 0, KF_RES_KROW0 = 8, KF_RES_KROW1 = KF_RES_KROW0 + KF_MQ * KF_KROW_W, KF_RES_GU = KF_RES_KROW1 + KF_MQ * KF_KROW_W,
+                 KF_RES_GS = KF_RES_GU + KF_MQ * KF_MQ, KF_RES_SIZE = KF_RES_GS + KF_MQ * KF_MQ;
+
+static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
+                     double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
+                     int lik, double* d_offset) {
+  const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;
+  if (!c->kronf) { c->kronf = new (std::nothrow) KfState(); c->kronf_free = kf_free; if (!c->kronf) { c->err = "out of memory"; return ZIGP_EHIP; } }
+  KfState& ks = *c->kronf;
+  ZIGP_TRY(begin_staged_call(c));
+  const bool need_grad = grads != nullptr && !predict;
+  const int D0 = p->D0, D1 = p->D1, ldx = D0 + D1;
+  const int64_t Npad = std::max<int64_t>(1024, round_up(N, 1024));
+  KfHostLatent hl[2] = {{{p->M0f, p->M1f}, {p->Z0f, p->Z1f}, {p->ell0f, p->ell1f}, {p->var0f, p->var1f}, p->u_fm, p->u_fs_sqrt},
+                        {{p->M0g, p->M1g}, {p->Z0g, p->Z1g}, {p->ell0g, p->ell1g}, {p->var0g, p->var1g}, p->u_gm, p->u_gs_sqrt}};
+  if (nlat == 1) hl[1] = hl[0];
+  // ---- one staged host -> device copy: X, Y, per latent Z0, Z1, u, s
+  size_t off_x = 0, off_y = (size_t)N * ldx, off = off_y + (size_t)N;
+  size_t off_z[2][2], off_u[2], off_s[2];
+  for (int h = 0; h < nlat; ++h) {
+    off_z[h][0] = off; off += (size_t)hl[h].M[0] * D0;
+    off_z[h][1] = off; off += (size_t)hl[h].M[1] * D1;
+    off_u[h] = off; off += (size_t)hl[h].M[0] * hl[h].M[1];
+    off_s[h] = off; off += (size_t)hl[h].M[0] * hl[h].M[1];
+  }
+  const size_t n_in = off;
+  ZIGP_ENSURE(c, ks.in, n_in);
+  {
+    ZIGP_PINNED(c, hin, n_in);
+    memcpy(hin + off_x, X, sizeof(double) * N * ldx);
+    if (Y) memcpy(hin + off_y, Y, sizeof(double) * N); else memset(hin + off_y, 0, sizeof(double) * N);
+    for (int h = 0; h < nlat; ++h) {
+      memcpy(hin + off_z[h][0], hl[h].Z[0], sizeof(double) * hl[h].M[0] * D0);
+      memcpy(hin + off_z[h][1], hl[h].Z[1], sizeof(double) * hl[h].M[1] * D1);
+      memcpy(hin + off_u[h], hl[h].u, sizeof(double) * hl[h].M[0] * hl[h].M[1]);
+      memcpy(hin + off_s[h], hl[h].s, sizeof(double) * hl[h].M[0] * hl[h].M[1]);
+    }
+    ZIGP_HIP(c, hipMemcpyAsync(ks.in.p, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, c->stream));
+  }
+  ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+  ZIGP_ENSURE(c, ks.mat, (size_t)4 * KF_FAC_SIZE + 2 * KF_LAT_SIZE);
+  const int pw_blocks = (int)(Npad / PW_THREADS);
+  const size_t pts_lat = (size_t)8 * Npad;   // part[4], gm, gv, dq0, dq1
+  ZIGP_ENSURE(c, ks.pts, 2 * pts_lat);
+  const size_t n_res = (size_t)2 * KF_RES_SIZE + (size_t)pw_blocks * 4;
+  ZIGP_ENSURE(c, ks.res, n_res);
+  auto fac = [&](int h, int q) { return ks.mat.p + (size_t)(2 * h + q) * KF_FAC_SIZE; };
+  auto lat = [&](int h) { return ks.mat.p + (size_t)4 * KF_FAC_SIZE + (size_t)h * KF_LAT_SIZE; };
+  auto pts = [&](int h) { return ks.pts.p + (size_t)h * pts_lat; };
+  auto res = [&](int h) { return ks.res.p + (size_t)h * KF_RES_SIZE; };
+  double* d_pwacc = ks.res.p + (size_t)2 * KF_RES_SIZE;
+
+  // ---- factor stage
+  static bool attr_set = false;
+  if (!attr_set) {
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * PB * PBLD)));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_backward), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(double) * KF_WAVES * 4 * 16 * KF_NBMAX * KF_LD)));
+    attr_set = true;
+  }
+  int Mq[2][2];
+  double zc[2][2][MAXD];
+  {
+    KfFactorArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    for (int h = 0; h < nlat; ++h)
+      for (int q = 0; q < 2; ++q) {
+        KfFactorJob& jb = fa.job[2 * h + q];
+        const int M = hl[h].M[q], D = q == 0 ? D0 : D1;
+        Mq[h][q] = (int)round_up(M, 16);
+        jb.Z = ks.in.p + off_z[h][q]; jb.M = M; jb.D = D; jb.Mq = Mq[h][q];
+        for (int d = 0; d < MAXD; ++d) jb.inv_ell[d] = d < D ? 1.0 / hl[h].ell[q][d] : 0.0;
+        jb.var = hl[h].var[q];
+        jb.K = fac(h, q) + KF_FAC_K; jb.P = fac(h, q) + KF_FAC_P; jb.PF = fac(h, q) + KF_FAC_PF; jb.dvec = fac(h, q) + KF_FAC_DV;
+        for (int d = 0; d < MAXD; ++d) {
+          double lo = 0.0, hi = 0.0;
+          if (d < D) {
+            lo = hi = hl[h].Z[q][d];
+            for (int m = 1; m < M; ++m) { const double z = hl[h].Z[q][(size_t)m * D + d]; lo = std::min(lo, z); hi = std::max(hi, z); }
+          }
+          zc[h][q][d] = 0.5 * (lo + hi);
+        }
+      }
+    fa.jitter = jitter; fa.info = c->d_info;
+    hipLaunchKernelGGL(k_kf_factor, dim3(2 * nlat), dim3(1024), sizeof(double) * PB * PBLD, c->stream, fa);
+    ZIGP_HIP(c, hipGetLastError());
+  }
+  int* hinfo = nullptr;
+  ZIGP_TRY(request_info(c, &hinfo));
+  {
+    KfLatentArgs la;
+    memset(&la, 0, sizeof(la));
+    for (int h = 0; h < nlat; ++h) {
+      KfLatentJob& jb = la.job[h];
+      jb.M0 = hl[h].M[0]; jb.M1 = hl[h].M[1]; jb.Mq0 = Mq[h][0]; jb.Mq1 = Mq[h][1];
+      jb.P0 = fac(h, 0) + KF_FAC_P; jb.P1 = fac(h, 1) + KF_FAC_P; jb.dvec0 = fac(h, 0) + KF_FAC_DV; jb.dvec1 = fac(h, 1) + KF_FAC_DV;
+      jb.u = ks.in.p + off_u[h]; jb.s = ks.in.p + off_s[h];
+      double* L = lat(h);
+      jb.U = L + KF_LAT_U; jb.S2 = L + KF_LAT_S2; jb.T0 = L + KF_LAT_T0; jb.T1 = L + KF_LAT_T1; jb.Al = L + KF_LAT_AL;
+      jb.AlF = L + KF_LAT_ALF; jb.S2F = L + KF_LAT_S2F; jb.AlTF = L + KF_LAT_ALTF; jb.S2TF = L + KF_LAT_S2TF;
+      jb.klv = res(h) + KF_RES_KLV;
+    }
+    hipLaunchKernelGGL(k_kf_latent, dim3(nlat), dim3(1024), 0, c->stream, la);
+    ZIGP_HIP(c, hipGetLastError());
+  }
+  // ---- point stage
+  KfArgs ka;
+  memset(&ka, 0, sizeof(ka));
+  ka.X = ks.in.p + off_x; ka.N = N; ka.Npad = Npad; ka.ldx = ldx; ka.ntiles = (int)(Npad / 16);
+  for (int h = 0; h < nlat; ++h) {
+    KfLat& L = ka.lat[h];
+    for (int q = 0; q < 2; ++q) {
+      KfFac& f = L.f[q];
+      const int D = q == 0 ? D0 : D1;
+      f.M = hl[h].M[q]; f.nb = Mq[h][q] / 16; f.D = D; f.col0 = q == 0 ? 0 : D0;
+      for (int d = 0; d < MAXD; ++d) { f.inv_ell[d] = d < D ? 1.0 / hl[h].ell[q][d] : 0.0; f.zc[d] = zc[h][q][d]; }
+      f.var = hl[h].var[q];
+      f.Z = ks.in.p + off_z[h][q]; f.PF = fac(h, q) + KF_FAC_PF;
+    }
+    double* Lm = lat(h);
+    L.AlF = Lm + KF_LAT_ALF; L.S2F = Lm + KF_LAT_S2F; L.AlTF = Lm + KF_LAT_ALTF; L.S2TF = Lm + KF_LAT_S2TF;
+    double* P = pts(h);
+    L.part = P; L.gm = P + 4 * Npad; L.gv = P + 5 * Npad; L.dq0 = P + 6 * Npad; L.dq1 = P + 7 * Npad;
+    L.knn = hl[h].var[0] * hl[h].var[1];
+  }
+  {
+    const int waves = std::min(ka.ntiles, 2048);
+    ka.tpw = (ka.ntiles + waves - 1) / waves;
+    const int nw = (ka.ntiles + ka.tpw - 1) / ka.tpw;
+    hipLaunchKernelGGL(k_kf_forward, dim3((nw + KF_WAVES - 1) / KF_WAVES, nlat), dim3(64 * KF_WAVES), 0, c->stream, ka);
+    ZIGP_HIP(c, hipGetLastError());
+  }
+  KronPwArgs a;
+  const int gl_ = nlat - 1;   // latent whose buffers stand in for g (unused by the single-latent kernels)
+  a.part_f = pts(0); a.part_g = pts(gl_); a.Y = Y ? ks.in.p + off_y : nullptr; a.N = N; a.Nc = Npad;
+  a.knn_f = p->var0f * p->var1f; a.knn_g = p->var0g * p->var1g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
+  a.gm_f = need_grad ? pts(0) + 4 * Npad : nullptr; a.gv_f = pts(0) + 5 * Npad; a.gm_g = pts(gl_) + 4 * Npad; a.gv_g = pts(gl_) + 5 * Npad;
+  a.dq0_f = pts(0) + 6 * Npad; a.dq1_f = pts(0) + 7 * Npad; a.dq0_g = pts(gl_) + 6 * Npad; a.dq1_g = pts(gl_) + 7 * Npad;
+  a.acc = d_pwacc; a.out9 = nullptr; a.ld9 = N;
+  if (predict) {
+    const int rows = nlat == 2 ? 9 : 4;
+    ZIGP_ENSURE(c, ks.out, (size_t)rows * N);
+    a.out9 = ks.out.p;
+    if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<true>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_kron_head_pointwise<true>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
+    ZIGP_HIP(c, hipGetLastError());
+    ZIGP_HIP(c, hipMemcpyAsync(out9, ks.out.p, sizeof(double) * rows * N, hipMemcpyDeviceToHost, c->stream));
+    ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+    return info_result(c, hinfo, "a Kronecker factor of Kuu");
+  }
+  if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_kron_head_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
+  ZIGP_HIP(c, hipGetLastError());
+  if (need_grad) {
+    const int waves = std::min(ka.ntiles, 1024 / nlat);   // one wave per SIMD of the chip: the kernel holds ~400 registers per lane
+    ka.tpw = (ka.ntiles + waves - 1) / waves;
+    const int nw = (ka.ntiles + ka.tpw - 1) / ka.tpw;
+    const int nwg = (nw + KF_WAVES - 1) / KF_WAVES, nw_alloc = nwg * KF_WAVES;
+    ZIGP_ENSURE(c, ks.acc, (size_t)2 * nw_alloc * KF_ACC_DOUBLES);
+    for (int h = 0; h < nlat; ++h) ka.lat[h].acc = ks.acc.p + (size_t)h * nw_alloc * KF_ACC_DOUBLES;
+    hipLaunchKernelGGL(k_kf_backward, dim3(nwg, nlat), dim3(64 * KF_WAVES), sizeof(double) * KF_WAVES * 4 * 16 * KF_NBMAX * KF_LD, c->stream, ka);
+    ZIGP_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(k_kf_reduce, dim3(KF_ACC_DOUBLES / 16, nlat), dim3(256), 0, c->stream, ka.lat[0].acc, ka.lat[gl_].acc, nw_alloc,
+                       lat(0) + KF_LAT_WORK, lat(gl_) + KF_LAT_WORK);
+    ZIGP_HIP(c, hipGetLastError());
+    KfFinishArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    for (int h = 0; h < nlat; ++h) {
+      KfFinishJob& jb = fa.job[h];
+      jb.M0 = hl[h].M[0]; jb.M1 = hl[h].M[1]; jb.Mq0 = Mq[h][0]; jb.Mq1 = Mq[h][1]; jb.D0 = D0; jb.D1 = D1;
+      jb.P0 = fac(h, 0) + KF_FAC_P; jb.P1 = fac(h, 1) + KF_FAC_P; jb.dvec0 = fac(h, 0) + KF_FAC_DV; jb.dvec1 = fac(h, 1) + KF_FAC_DV;
+      jb.K0 = fac(h, 0) + KF_FAC_K; jb.K1 = fac(h, 1) + KF_FAC_K; jb.Z0 = ks.in.p + off_z[h][0]; jb.Z1 = ks.in.p + off_z[h][1];
+      for (int d = 0; d < MAXD; ++d) { jb.zc0[d] = zc[h][0][d]; jb.zc1[d] = zc[h][1][d]; }
+      double* L = lat(h);
+      jb.U = L + KF_LAT_U; jb.S2 = L + KF_LAT_S2; jb.T0 = L + KF_LAT_T0; jb.T1 = L + KF_LAT_T1; jb.Al = L + KF_LAT_AL; jb.s = ks.in.p + off_s[h];
+      jb.work = L + KF_LAT_WORK;
+      jb.krow0 = res(h) + KF_RES_KROW0; jb.krow1 = res(h) + KF_RES_KROW1; jb.gu = res(h) + KF_RES_GU; jb.gs = res(h) + KF_RES_GS;
+    }
+    fa.jitter = jitter; fa.with_kl = include_kl ? 1 : 0;
+    hipLaunchKernelGGL(k_kf_finish, dim3(nlat), dim3(1024), 0, c->stream, fa);
+    ZIGP_HIP(c, hipGetLastError());
+  }
+  double* hres = nullptr;
+  ZIGP_TRY(download(c, ks.res.p, n_res, &hres));
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+  ZIGP_TRY(info_result(c, hinfo, "a Kronecker factor of Kuu"));
+  const double* hacc = hres + (size_t)2 * KF_RES_SIZE;
+  double s_ve = 0, s_dn = 0, s_gv[2] = {0, 0};
+  for (int b = 0; b < pw_blocks; ++b) { s_ve += hacc[4 * b]; s_dn += hacc[4 * b + 1]; s_gv[0] += hacc[4 * b + 2]; s_gv[1] += hacc[4 * b + 3]; }
+  if (elbo_data) *elbo_data = s_ve;
+  if (nlat == 1) { if (d_offset) *d_offset = s_gv[1]; s_gv[1] = 0.0; }   // acc[3] of the head kernel is sum gm = d ve / d f_mu
+  double klsum = 0.0;
+  if (include_kl) {
+    for (int h = 0; h < nlat; ++h) {
+      const double* v = hres + (size_t)h * KF_RES_SIZE + KF_RES_KLV;
+      const int M0 = hl[h].M[0], M1 = hl[h].M[1];
+      klsum += 0.5 * (v[0] - (double)M0 * M1 - v[1] + v[2] + (double)M1 * v[3] + (double)M0 * v[4]);
+    }
+  }
+  if (kl) *kl = klsum;
+  if (need_grad) {
+    double* gZ[2][2] = {{grads->Z0f, grads->Z1f}, {grads->Z0g, grads->Z1g}};
+    double* gl[2][2] = {{grads->ell0f, grads->ell1f}, {grads->ell0g, grads->ell1g}};
+    double gvar[2][2] = {{0, 0}, {0, 0}};
+    double* gu[2] = {grads->u_fm, grads->u_gm};
+    double* gs[2] = {grads->u_fs_sqrt, grads->u_gs_sqrt};
+    for (int h = 0; h < nlat; ++h) {
+      const double* R = hres + (size_t)h * KF_RES_SIZE;
+      for (int q = 0; q < 2; ++q) {
+        const int D = q == 0 ? D0 : D1, W = 2 + 2 * D, M = hl[h].M[q];
+        const double* krow = R + (q == 0 ? KF_RES_KROW0 : KF_RES_KROW1);
+        const double* ell = hl[h].ell[q];
+        double dv = 0.0;
+        std::vector<double> dl(D, 0.0);
+        for (int m = 0; m < M; ++m) {
+          const double* r = &krow[(size_t)m * W];
+          dv += r[0];
+          for (int d = 0; d < D; ++d) {
+            if (gZ[h][q]) gZ[h][q][m * D + d] = r[1 + d] / (ell[d] * ell[d]);
+            dl[d] += r[1 + D + d];
+          }
+        }
+        for (int d = 0; d < D; ++d)
+          if (gl[h][q]) gl[h][q][d] = dl[d] / (ell[d] * ell[d] * ell[d]);
+        gvar[h][q] = dv / hl[h].var[q] + s_gv[h] * hl[h].var[1 - q];   // Knn = var0 * var1 enters var_n directly (scripts/onoff.py:196-200)
+      }
+      const size_t ng = (size_t)hl[h].M[0] * hl[h].M[1];
+      if (gu[h]) memcpy(gu[h], R + KF_RES_GU, sizeof(double) * ng);
+      if (gs[h]) memcpy(gs[h], R + KF_RES_GS, sizeof(double) * ng);
+    }
+    grads->var0f = gvar[0][0]; grads->var1f = gvar[0][1];
+    grads->var0g = nlat == 2 ? gvar[1][0] : 0.0; grads->var1g = nlat == 2 ? gvar[1][1] : 0.0;
+    grads->noise = s_dn;
+  }
+  return 0;
+}
+
 }  // namespace zigp
