@@ -116,29 +116,46 @@ __device__ __forceinline__ double kf_colsum(double v) {
 }
 
 constexpr int KF_Q = 4 * KF_NBMAX;   // registers per [16 nb][16] tile quantity
+constexpr int KF_MQ_ = 16 * KF_NBMAX;
 
 struct KfFwdTile { double K0[KF_Q], K1[KF_Q], A0[KF_Q], A1[KF_Q], B0[KF_Q], C0[KF_Q]; };
 
+// The workgroup's copy of the fragment images in LDS (8 KB each at 32 x 32): every wave re-reads them for every tile, and an LDS
+// read returns in ~100 cycles where an L2 hit takes 500+ (one wave per SIMD has nothing else to hide that behind).
+constexpr int KF_FRAG = KF_MQ_ * KF_MQ_;
+struct KfFrags { const double *P0, *P1, *Al, *S2, *AlT, *S2T; };
+__device__ __forceinline__ void kf_stage_frag(double* dst, const double* __restrict__ src, int n) {
+  for (int idx = threadIdx.x; idx < n; idx += blockDim.x) dst[idx] = src[idx];
+}
 // forward pieces of one tile: A_p = P_p K_p, B0 = Alpha K1, C0 = S2 A1^2
-__device__ __forceinline__ void kf_forward_tile(KfFwdTile& t, const KfLat& L, const double* __restrict__ xrow, bool valid, int g, int slot) {
+__device__ __forceinline__ void kf_forward_tile(KfFwdTile& t, const KfLat& L, const KfFrags& F, const double* __restrict__ xrow, bool valid, int g,
+                                                int slot) {
   const KfFac &f0 = L.f[0], &f1 = L.f[1];
   kf_ktile<KF_Q>(t.K0, f0, xrow, valid, g);
   kf_ktile<KF_Q>(t.K1, f1, xrow, valid, g);
 #pragma unroll
   for (int q = 0; q < KF_Q; ++q) { t.A0[q] = 0.0; t.A1[q] = 0.0; t.B0[q] = 0.0; t.C0[q] = 0.0; }
-  kf_frag_mm<KF_NBMAX, KF_Q>(t.A0, f0.PF, f0.nb, 4 * f0.nb, t.K0, slot);
-  kf_frag_mm<KF_NBMAX, KF_Q>(t.A1, f1.PF, f1.nb, 4 * f1.nb, t.K1, slot);
-  kf_frag_mm<KF_NBMAX, KF_Q>(t.B0, L.AlF, f0.nb, 4 * f1.nb, t.K1, slot);
+  kf_frag_mm<KF_NBMAX, KF_Q>(t.A0, F.P0, f0.nb, 4 * f0.nb, t.K0, slot);
+  kf_frag_mm<KF_NBMAX, KF_Q>(t.A1, F.P1, f1.nb, 4 * f1.nb, t.K1, slot);
+  kf_frag_mm<KF_NBMAX, KF_Q>(t.B0, F.Al, f0.nb, 4 * f1.nb, t.K1, slot);
   double sq[KF_Q];
 #pragma unroll
   for (int q = 0; q < KF_Q; ++q) sq[q] = t.A1[q] * t.A1[q];
-  kf_frag_mm<KF_NBMAX, KF_Q>(t.C0, L.S2F, f0.nb, 4 * f1.nb, sq, slot);
+  kf_frag_mm<KF_NBMAX, KF_Q>(t.C0, F.S2, f0.nb, 4 * f1.nb, sq, slot);
 }
 
 // ---- forward: part[0..3][n] = q0 = k0.a0, q1 = k1.a1, mean = k0^T Alpha k1, st = (a0^2)^T S2 (a1^2) -------------------------
 __global__ void __launch_bounds__(64 * KF_WAVES)
 k_kf_forward(KfArgs a) {
+  __shared__ double sfr[4 * KF_FRAG];
   const KfLat& L = a.lat[blockIdx.y];
+  {
+    const int n0 = L.f[0].nb * L.f[0].nb * 256, n1 = L.f[1].nb * L.f[1].nb * 256, n01 = L.f[0].nb * L.f[1].nb * 256;
+    kf_stage_frag(sfr, L.f[0].PF, n0); kf_stage_frag(sfr + KF_FRAG, L.f[1].PF, n1);
+    kf_stage_frag(sfr + 2 * KF_FRAG, L.AlF, n01); kf_stage_frag(sfr + 3 * KF_FRAG, L.S2F, n01);
+    __syncthreads();
+  }
+  const KfFrags F = {sfr, sfr + KF_FRAG, sfr + 2 * KF_FRAG, sfr + 3 * KF_FRAG, nullptr, nullptr};
   const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
@@ -146,7 +163,7 @@ k_kf_forward(KfArgs a) {
     const int64_t pn = (int64_t)tile * 16 + n;
     const bool valid = pn < a.N;
     KfFwdTile t;
-    kf_forward_tile(t, L, a.X + (valid ? pn : 0) * a.ldx, valid, g, slot);
+    kf_forward_tile(t, L, F, a.X + (valid ? pn : 0) * a.ldx, valid, g, slot);
     double q0 = 0.0, q1 = 0.0, mu = 0.0, st = 0.0;
 #pragma unroll
     for (int q = 0; q < KF_Q; ++q) {
@@ -218,6 +235,15 @@ k_kf_backward(KfArgs a) {
   const int w = blockIdx.x * KF_WAVES + wib;
   constexpr int TILE = 16 * KF_NBMAX * KF_LD;
   double* bK0 = lds + wib * 4 * TILE; double* bK1 = bK0 + TILE; double* c0 = bK1 + TILE; double* c1 = c0 + TILE;
+  double* sfr = lds + KF_WAVES * 4 * TILE;
+  {
+    const int n0 = f0.nb * f0.nb * 256, n1 = f1.nb * f1.nb * 256, n01 = f0.nb * f1.nb * 256;
+    kf_stage_frag(sfr, f0.PF, n0); kf_stage_frag(sfr + KF_FRAG, f1.PF, n1);
+    kf_stage_frag(sfr + 2 * KF_FRAG, L.AlF, n01); kf_stage_frag(sfr + 3 * KF_FRAG, L.S2F, n01);
+    kf_stage_frag(sfr + 4 * KF_FRAG, L.AlTF, n01); kf_stage_frag(sfr + 5 * KF_FRAG, L.S2TF, n01);
+    __syncthreads();
+  }
+  const KfFrags F = {sfr, sfr + KF_FRAG, sfr + 2 * KF_FRAG, sfr + 3 * KF_FRAG, sfr + 4 * KF_FRAG, sfr + 5 * KF_FRAG};
   double accAl[KF_NBMAX * KF_NBMAX][4], accS2[KF_NBMAX * KF_NBMAX][4], accP0[KF_NBMAX * KF_NBMAX][4], accP1[KF_NBMAX * KF_NBMAX][4];
   double accK0[KF_NBMAX][4], accK1[KF_NBMAX][4];
 #pragma unroll
@@ -236,13 +262,13 @@ k_kf_backward(KfArgs a) {
     const bool valid = pn < a.N;
     const double* xrow = a.X + (valid ? pn : 0) * a.ldx;
     KfFwdTile t;
-    kf_forward_tile(t, L, xrow, valid, g, slot);
+    kf_forward_tile(t, L, F, xrow, valid, g, slot);
     const double gmn = L.gm[pn], gvn = L.gv[pn], dq0n = L.dq0[pn], dq1n = L.dq1[pn];   // zero for padding points (scale 0 in the point-wise kernel)
     double B1[KF_Q], C1[KF_Q], sq[KF_Q];
 #pragma unroll
     for (int q = 0; q < KF_Q; ++q) { B1[q] = 0.0; C1[q] = 0.0; sq[q] = t.A0[q] * t.A0[q]; }
-    kf_frag_mm<KF_NBMAX, KF_Q>(B1, L.AlTF, f1.nb, 4 * f0.nb, t.K0, slot);
-    kf_frag_mm<KF_NBMAX, KF_Q>(C1, L.S2TF, f1.nb, 4 * f0.nb, sq, slot);
+    kf_frag_mm<KF_NBMAX, KF_Q>(B1, F.AlT, f1.nb, 4 * f0.nb, t.K0, slot);
+    kf_frag_mm<KF_NBMAX, KF_Q>(C1, F.S2T, f1.nb, 4 * f0.nb, sq, slot);
     double dA0[KF_Q], dA1[KF_Q], PdA0[KF_Q], PdA1[KF_Q];
 #pragma unroll
     for (int q = 0; q < KF_Q; ++q) {
@@ -250,8 +276,8 @@ k_kf_backward(KfArgs a) {
       dA1[q] = 2.0 * gvn * t.A1[q] * C1[q];
       PdA0[q] = 0.0; PdA1[q] = 0.0;
     }
-    kf_frag_mm<KF_NBMAX, KF_Q>(PdA0, f0.PF, f0.nb, 4 * f0.nb, dA0, slot);
-    kf_frag_mm<KF_NBMAX, KF_Q>(PdA1, f1.PF, f1.nb, 4 * f1.nb, dA1, slot);
+    kf_frag_mm<KF_NBMAX, KF_Q>(PdA0, F.P0, f0.nb, 4 * f0.nb, dA0, slot);
+    kf_frag_mm<KF_NBMAX, KF_Q>(PdA1, F.P1, f1.nb, 4 * f1.nb, dA1, slot);
     // ---- LDS images for the sums over points (k index = point): K tiles, E tiles
     kf_store_tile(bK0, t.K0, f0.nb, g, n);
     kf_store_tile(bK1, t.K1, f1.nb, g, n);
@@ -408,8 +434,9 @@ k_kf_factor(KfFactorArgs a) {
   __shared__ double red[16];
   const KfFactorJob& jb = a.job[blockIdx.x];
   const int t = threadIdx.x, M = jb.M, Mq = jb.Mq, D = jb.D;
-  for (int idx = t; idx < PB * PB; idx += 1024) {
-    const int i = idx >> 7, j = idx & 127;
+  const int nreal = ((M + PNB - 1) / PNB) * PNB;   // the factorisation touches the 32-column panels that hold real rows only
+  for (int idx = t; idx < nreal * nreal; idx += 1024) {
+    const int i = idx / nreal, j = idx - i * nreal;
     double v;
     if (i < M && j < M) {
       double r2 = 0.0;
@@ -418,7 +445,7 @@ k_kf_factor(KfFactorArgs a) {
     } else {
       v = (i == j) ? 1.0 : 0.0;
     }
-    jb.K[idx] = v;
+    jb.K[i * PB + j] = v;
     S[i * PBLD + j] = (j <= i) ? v : 0.0;
   }
   __syncthreads();
@@ -446,15 +473,33 @@ k_kf_factor(KfFactorArgs a) {
   kf_write_frag(jb.PF, Mq / 16, Mq / 4, t, 1024, jb.P, Mq, false);
 }
 
-// C (m x n) = op(A) (m x k) * op(B) (k x n), row-major operands in global memory (L1-resident sizes), all threads of the workgroup
+// ---- small dense algebra of the M x M stages: every operand lives in LDS with row stride KF_SLD (odd: column walks are conflict free)
+constexpr int KF_SLD = KF_MQ + 1;
+constexpr int KF_SMAT = KF_MQ * KF_SLD;
+// C (m x n) = op(A) (m x k) * op(B) (k x n) [+ C], all threads of the workgroup; caller synchronises
 template <bool TA, bool TB, bool ACC>
-__device__ __forceinline__ void kf_small_mm(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B,
-                                            int ldb, int m, int n, int k, double alpha = 1.0) {
+__device__ __forceinline__ void kf_lds_mm(double* C, const double* A, const double* B, int m, int n, int k) {
   for (int idx = threadIdx.x; idx < m * n; idx += blockDim.x) {
     const int i = idx / n, j = idx - i * n;
     double v = 0.0;
-    for (int q = 0; q < k; ++q) v = fma(TA ? A[q * lda + i] : A[i * lda + q], TB ? B[j * ldb + q] : B[q * ldb + j], v);
-    if (ACC) C[i * ldc + j] += alpha * v; else C[i * ldc + j] = alpha * v;
+#pragma unroll 4
+    for (int q = 0; q < k; ++q) v = fma(TA ? A[q * KF_SLD + i] : A[i * KF_SLD + q], TB ? B[j * KF_SLD + q] : B[q * KF_SLD + j], v);
+    if (ACC) C[i * KF_SLD + j] += v; else C[i * KF_SLD + j] = v;
+  }
+}
+__device__ __forceinline__ void kf_lds_load(double* dst, const double* __restrict__ src, int rows, int cols, int ld) {
+  for (int idx = threadIdx.x; idx < rows * cols; idx += blockDim.x) { const int i = idx / cols, j = idx - i * cols; dst[i * KF_SLD + j] = src[(int64_t)i * ld + j]; }
+}
+__device__ __forceinline__ void kf_lds_store(double* __restrict__ dst, const double* src, int rows, int cols, int ld) {
+  for (int idx = threadIdx.x; idx < rows * cols; idx += blockDim.x) { const int i = idx / cols, j = idx - i * cols; dst[(int64_t)i * ld + j] = src[i * KF_SLD + j]; }
+}
+// fragment image of an LDS matrix (see kf_write_frag)
+__device__ __forceinline__ void kf_lds_frag(double* __restrict__ F, int nbr, int ksn, const double* A, bool transposed) {
+  const int total = nbr * ksn * 64;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int r = idx & 3, slot = (idx >> 2) & 15, blk = idx >> 6, ks = blk % ksn, rb = blk / ksn;
+    const int row = 16 * rb + 4 * r + (slot & 3), k = 4 * ks + (slot >> 2);
+    F[idx] = transposed ? A[k * KF_SLD + row] : A[row * KF_SLD + k];
   }
 }
 
@@ -470,33 +515,41 @@ struct KfLatentArgs { KfLatentJob job[2]; };
 
 __global__ void __launch_bounds__(1024)
 k_kf_latent(KfLatentArgs a) {
+  __shared__ double sm[6 * KF_SMAT];
   __shared__ double sh[16];
+  double *sP0 = sm, *sP1 = sm + KF_SMAT, *sU = sm + 2 * KF_SMAT, *sS2 = sm + 3 * KF_SMAT, *sT = sm + 4 * KF_SMAT, *sAl = sm + 5 * KF_SMAT;
   const KfLatentJob& jb = a.job[blockIdx.x];
   const int t = threadIdx.x, M0 = jb.M0, M1 = jb.M1, Mq0 = jb.Mq0, Mq1 = jb.Mq1;
+  kf_lds_load(sP0, jb.P0, Mq0, Mq0, Mq0);
+  kf_lds_load(sP1, jb.P1, Mq1, Mq1, Mq1);
   for (int idx = t; idx < Mq0 * Mq1; idx += 1024) {
     const int i = idx / Mq1, j = idx - i * Mq1;
     const bool in = i < M0 && j < M1;
-    const double sv = in ? jb.s[i * M1 + j] : 0.0;
-    jb.U[idx] = in ? jb.u[i * M1 + j] : 0.0;
-    jb.S2[idx] = sv * sv;
+    const double sv = in ? jb.s[i * M1 + j] : 0.0, uv = in ? jb.u[i * M1 + j] : 0.0;
+    sU[i * KF_SLD + j] = uv; sS2[i * KF_SLD + j] = sv * sv;
+    jb.U[idx] = uv; jb.S2[idx] = sv * sv;
   }
   __syncthreads();
-  kf_small_mm<false, false, false>(jb.T0, Mq1, jb.U, Mq1, jb.P1, Mq1, Mq0, Mq1, Mq1);      // T0 = U P1
-  kf_small_mm<false, false, false>(jb.T1, Mq1, jb.P0, Mq0, jb.U, Mq1, Mq0, Mq1, Mq0);      // T1 = P0 U
+  kf_lds_mm<false, false, false>(sT, sP0, sU, Mq0, Mq1, Mq0);       // T1 = P0 U
   __syncthreads();
-  kf_small_mm<false, false, false>(jb.Al, Mq1, jb.P0, Mq0, jb.T0, Mq1, Mq0, Mq1, Mq0);     // Alpha = P0 (U P1)   (= __kron_mv, :193)
+  kf_lds_store(jb.T1, sT, Mq0, Mq1, Mq1);
   __syncthreads();
-  kf_write_frag(jb.AlF, Mq0 / 16, Mq1 / 4, t, 1024, jb.Al, Mq1, false);
-  kf_write_frag(jb.S2F, Mq0 / 16, Mq1 / 4, t, 1024, jb.S2, Mq1, false);
-  kf_write_frag(jb.AlTF, Mq1 / 16, Mq0 / 4, t, 1024, jb.Al, Mq1, true);
-  kf_write_frag(jb.S2TF, Mq1 / 16, Mq0 / 4, t, 1024, jb.S2, Mq1, true);
+  kf_lds_mm<false, false, false>(sT, sU, sP1, Mq0, Mq1, Mq1);       // T0 = U P1
+  __syncthreads();
+  kf_lds_store(jb.T0, sT, Mq0, Mq1, Mq1);
+  kf_lds_mm<false, false, false>(sAl, sP0, sT, Mq0, Mq1, Mq0);      // Alpha = P0 (U P1)   (= __kron_mv, scripts/onoff.py:193)
+  __syncthreads();
+  kf_lds_store(jb.Al, sAl, Mq0, Mq1, Mq1);
+  kf_lds_frag(jb.AlF, Mq0 / 16, Mq1 / 4, sAl, false);
+  kf_lds_frag(jb.S2F, Mq0 / 16, Mq1 / 4, sS2, false);
+  kf_lds_frag(jb.AlTF, Mq1 / 16, Mq0 / 4, sAl, true);
+  kf_lds_frag(jb.S2TF, Mq1 / 16, Mq0 / 4, sS2, true);
   // KL scalars (GaussKLkron, onofftf/main.py:350-387, factored): fixed-order sums
   double av = 0.0, bv = 0.0, cv = 0.0;
   for (int idx = t; idx < M0 * M1; idx += 1024) {
     const int i = idx / M1, j = idx - i * M1;
-    const int64_t o = (int64_t)i * Mq1 + j;
     const double sv = jb.s[idx];
-    av = fma(jb.U[o], jb.Al[o], av);
+    av = fma(sU[i * KF_SLD + j], sAl[i * KF_SLD + j], av);
     bv += log(sv * sv);
     cv = fma(jb.dvec0[i] * jb.dvec1[j], sv * sv, cv);
   }
@@ -522,117 +575,119 @@ struct KfFinishJob {
   const double *P0, *P1, *dvec0, *dvec1, *K0, *K1, *Z0, *Z1;
   double zc0[MAXD], zc1[MAXD];
   const double *U, *S2, *T0, *T1, *Al, *s;
-  double* work;        // KF_W_TOTAL summed accumulators, then scratch: X0, X1, Q (3 x [KF_MQ][KF_MQ]) behind it
+  const double* work;  // KF_W_TOTAL summed accumulators
   double *krow0, *krow1, *gu, *gs;     // outputs: [M0][2 + 2 D0], [M1][2 + 2 D1], [M0*M1], [M0*M1]
 };
 struct KfFinishArgs { KfFinishJob job[2]; double jitter; int with_kl; };
-
-__device__ __forceinline__ void kf_factor_backward(const KfFinishJob& jb, int p, double* dP, const double* Kr, double* X, double* G, double jitter,
-                                                   bool with_kl) {
-  const int t = threadIdx.x;
-  const int M = p == 0 ? jb.M0 : jb.M1, Mq = p == 0 ? jb.Mq0 : jb.Mq1, Mo = p == 0 ? jb.M1 : jb.M0, D = p == 0 ? jb.D0 : jb.D1;
-  const double* P = p == 0 ? jb.P0 : jb.P1;
-  const double* Kuu = p == 0 ? jb.K0 : jb.K1;
-  const double* Z = p == 0 ? jb.Z0 : jb.Z1;
-  const double* zc = p == 0 ? jb.zc0 : jb.zc1;
-  double* krow = p == 0 ? jb.krow0 : jb.krow1;
-  // X = sym(dP) P ; G = -P X - coef P
-  for (int idx = t; idx < Mq * Mq; idx += blockDim.x) {
-    const int i = idx / Mq, j = idx - i * Mq;
-    double v = 0.0;
-    for (int q = 0; q < Mq; ++q) v = fma(0.5 * (dP[i * KF_MQ + q] + dP[q * KF_MQ + i]), P[q * Mq + j], v);
-    X[i * KF_MQ + j] = v;
-  }
-  __syncthreads();
-  const double coef = with_kl ? 0.5 * (double)Mo : 0.0;
-  for (int idx = t; idx < Mq * Mq; idx += blockDim.x) {
-    const int i = idx / Mq, j = idx - i * Mq;
-    double v = 0.0;
-    for (int q = 0; q < Mq; ++q) v = fma(P[i * Mq + q], X[q * KF_MQ + j], v);
-    G[i * KF_MQ + j] = -v - coef * P[i * Mq + j];
-  }
-  __syncthreads();
-  // krow[m][c]: Kuu part (as k_kuu_grad, Kz = K_p - jitter I) + data moments rebuilt around z_m
-  const int W = 2 + 2 * D;
-  for (int idx = t; idx < M * W; idx += blockDim.x) {
-    const int m = idx / W, c = idx - m * W;
-    double v = 0.0;
-    if (c <= 2 * D) {
-      const int d = (c == 0) ? 0 : (c - 1) % D;
-      const double zm = Z[m * D + d];
-      for (int j = 0; j < M; ++j) {
-        const double kz = Kuu[m * PB + j] - ((m == j) ? jitter : 0.0);
-        const double tt = G[m * KF_MQ + j] * kz;
-        const double df = Z[j * D + d] - zm;
-        v += (c == 0) ? tt : ((c <= D) ? 2.0 * tt * df : tt * df * df);
-      }
-      const double s0 = Kr[m * 16];
-      if (c == 0) v += s0;
-      else {
-        const double dz = zm - zc[d], s1 = Kr[m * 16 + 1 + d];
-        if (c <= D) v += s1 - dz * s0;
-        else v += Kr[m * 16 + 1 + D + d] - 2.0 * dz * s1 + dz * dz * s0;
-      }
-    }
-    krow[idx] = v;
-  }
-}
+constexpr size_t KF_FIN_LDS = sizeof(double) * 12 * KF_SMAT;
 
 __global__ void __launch_bounds__(1024)
 k_kf_finish(KfFinishArgs a) {
+  extern __shared__ double sm[];
+  double *sP0 = sm, *sP1 = sm + KF_SMAT, *sdAl = sm + 2 * KF_SMAT, *sdP0 = sm + 3 * KF_SMAT, *sdP1 = sm + 4 * KF_SMAT, *sT0 = sm + 5 * KF_SMAT,
+         *sT1 = sm + 6 * KF_SMAT, *sU = sm + 7 * KF_SMAT, *sX = sm + 8 * KF_SMAT, *sG = sm + 9 * KF_SMAT, *sQ = sm + 10 * KF_SMAT, *sK = sm + 11 * KF_SMAT;
   const KfFinishJob& jb = a.job[blockIdx.x];
   const int t = threadIdx.x, M0 = jb.M0, M1 = jb.M1, Mq0 = jb.Mq0, Mq1 = jb.Mq1;
   const bool kl = a.with_kl != 0;
-  double* dAl = jb.work + KF_W_AL; double* dS2 = jb.work + KF_W_S2; double* dP0 = jb.work + KF_W_P0; double* dP1 = jb.work + KF_W_P1;
-  const double* Kr0 = jb.work + KF_W_K0; const double* Kr1 = jb.work + KF_W_K1;
-  double* X = jb.work + KF_W_TOTAL; double* G = X + KF_MQ * KF_MQ; double* Q = G + KF_MQ * KF_MQ; double* dU = Q + KF_MQ * KF_MQ;
-  // X = dAl P1 ; dU = P0 X
-  kf_small_mm<false, false, false>(X, KF_MQ, dAl, KF_MQ, jb.P1, Mq1, Mq0, Mq1, Mq1);
-  // dP0 += dAl T0^T ; dP1 += T1^T dAl
-  kf_small_mm<false, true, true>(dP0, KF_MQ, dAl, KF_MQ, jb.T0, Mq1, Mq0, Mq0, Mq1);
-  kf_small_mm<true, false, true>(dP1, KF_MQ, jb.T1, Mq1, dAl, KF_MQ, Mq1, Mq1, Mq0);
+  kf_lds_load(sP0, jb.P0, Mq0, Mq0, Mq0);
+  kf_lds_load(sP1, jb.P1, Mq1, Mq1, Mq1);
+  kf_lds_load(sdAl, jb.work + KF_W_AL, Mq0, Mq1, KF_MQ);
+  kf_lds_load(sdP0, jb.work + KF_W_P0, Mq0, Mq0, KF_MQ);
+  kf_lds_load(sdP1, jb.work + KF_W_P1, Mq1, Mq1, KF_MQ);
+  kf_lds_load(sT0, jb.T0, Mq0, Mq1, Mq1);
+  kf_lds_load(sT1, jb.T1, Mq0, Mq1, Mq1);
+  kf_lds_load(sU, jb.U, Mq0, Mq1, Mq1);
   __syncthreads();
-  kf_small_mm<false, false, false>(dU, KF_MQ, jb.P0, Mq0, X, KF_MQ, Mq0, Mq1, Mq0);
+  kf_lds_mm<false, false, false>(sX, sdAl, sP1, Mq0, Mq1, Mq1);       // X = dAl P1
+  kf_lds_mm<false, true, true>(sdP0, sdAl, sT0, Mq0, Mq0, Mq1);       // dP0 += dAl T0^T
+  kf_lds_mm<true, false, true>(sdP1, sT1, sdAl, Mq1, Mq1, Mq0);       // dP1 += T1^T dAl
   __syncthreads();
-  // u / s gradients
+  kf_lds_mm<false, false, false>(sG, sP0, sX, Mq0, Mq1, Mq0);         // dU = P0 X
+  __syncthreads();
   for (int idx = t; idx < M0 * M1; idx += 1024) {
     const int i = idx / M1, j = idx - i * M1;
     const double sv = jb.s[idx];
-    double gu = dU[i * KF_MQ + j], gs = 2.0 * sv * dS2[i * KF_MQ + j];
+    double gu = sG[i * KF_SLD + j], gs = 2.0 * sv * jb.work[KF_W_S2 + i * KF_MQ + j];
     if (kl) { gu -= jb.Al[i * Mq1 + j]; gs -= (-1.0 / sv + jb.dvec0[i] * jb.dvec1[j] * sv); }
     jb.gu[idx] = gu; jb.gs[idx] = gs;
   }
-  // KL pieces on dP_p, then the factor reverse passes
   for (int p = 0; p < 2; ++p) {
-    const int Mq = p == 0 ? Mq0 : Mq1;
-    double* dP = p == 0 ? dP0 : dP1;
+    const int M = p == 0 ? M0 : M1, Mq = p == 0 ? Mq0 : Mq1, Mo = p == 0 ? M1 : M0, D = p == 0 ? jb.D0 : jb.D1;
+    double* dP = p == 0 ? sdP0 : sdP1;
+    const double* P = p == 0 ? sP0 : sP1;
+    const double* Z = p == 0 ? jb.Z0 : jb.Z1;
+    const double* zc = p == 0 ? jb.zc0 : jb.zc1;
+    const double* Kr = jb.work + (p == 0 ? KF_W_K0 : KF_W_K1);
+    double* krow = p == 0 ? jb.krow0 : jb.krow1;
     __syncthreads();
+    kf_lds_load(sK, p == 0 ? jb.K0 : jb.K1, M, M, PB);
     if (kl) {
-      if (p == 0) kf_small_mm<false, true, false>(Q, KF_MQ, jb.T0, Mq1, jb.U, Mq1, Mq0, Mq0, Mq1);     // Q0 = T0 U^T
-      else kf_small_mm<true, false, false>(Q, KF_MQ, jb.U, Mq1, jb.T1, Mq1, Mq1, Mq1, Mq0);           // Q1 = U^T T1
-      __syncthreads();
-      for (int idx = t; idx < Mq * Mq; idx += 1024) {
-        const int i = idx / Mq, j = idx - i * Mq;
-        if (j > i) continue;
-        double v = 0.5 * (dP[i * KF_MQ + j] + dP[j * KF_MQ + i]) - 0.25 * (Q[i * KF_MQ + j] + Q[j * KF_MQ + i]);
+      if (p == 0) kf_lds_mm<false, true, false>(sQ, sT0, sU, Mq0, Mq0, Mq1);     // Q0 = T0 U^T
+      else kf_lds_mm<true, false, false>(sQ, sU, sT1, Mq1, Mq1, Mq0);            // Q1 = U^T T1
+    }
+    __syncthreads();
+    // sX = sym(dP) [- kl pieces]
+    for (int idx = t; idx < Mq * Mq; idx += 1024) {
+      const int i = idx / Mq, j = idx - i * Mq;
+      double v = 0.5 * (dP[i * KF_SLD + j] + dP[j * KF_SLD + i]);
+      if (kl) {
+        v -= 0.25 * (sQ[i * KF_SLD + j] + sQ[j * KF_SLD + i]);
         if (i == j) {
           double w = 0.0;
           if (p == 0) { for (int o = 0; o < M1; ++o) w = fma(jb.dvec1[o], jb.S2[i * Mq1 + o], w); }
           else { for (int o = 0; o < M0; ++o) w = fma(jb.dvec0[o], jb.S2[o * Mq1 + i], w); }
           v -= 0.5 * w;
         }
-        dP[i * KF_MQ + j] = v; dP[j * KF_MQ + i] = v;
       }
-      __syncthreads();
+      sX[i * KF_SLD + j] = v;
     }
-    kf_factor_backward(jb, p, dP, p == 0 ? Kr0 : Kr1, X, G, a.jitter, kl);
+    __syncthreads();
+    kf_lds_mm<false, false, false>(sQ, sX, P, Mq, Mq, Mq);      // Q = sym(dP) P
+    __syncthreads();
+    const double coef = kl ? 0.5 * (double)Mo : 0.0;
+    for (int idx = t; idx < Mq * Mq; idx += 1024) {              // G = -P Q - coef P
+      const int i = idx / Mq, j = idx - i * Mq;
+      double v = 0.0;
+#pragma unroll 4
+      for (int q = 0; q < Mq; ++q) v = fma(P[i * KF_SLD + q], sQ[q * KF_SLD + j], v);
+      sG[i * KF_SLD + j] = -v - coef * P[i * KF_SLD + j];
+    }
+    __syncthreads();
+    // krow[m][c]: Kuu part (as k_kuu_grad, Kz = K_p - jitter I) + data moments rebuilt around z_m
+    const int W = 2 + 2 * D;
+    for (int idx = t; idx < M * W; idx += 1024) {
+      const int m = idx / W, c = idx - m * W;
+      double v = 0.0;
+      if (c <= 2 * D) {
+        const int d = (c == 0) ? 0 : (c - 1) % D;
+        const double zm = Z[m * D + d];
+        for (int j = 0; j < M; ++j) {
+          const double kz = sK[m * KF_SLD + j] - ((m == j) ? a.jitter : 0.0);
+          const double tt = sG[m * KF_SLD + j] * kz;
+          const double df = Z[j * D + d] - zm;
+          v += (c == 0) ? tt : ((c <= D) ? 2.0 * tt * df : tt * df * df);
+        }
+        const double s0 = Kr[m * 16];
+        if (c == 0) v += s0;
+        else {
+          const double dz = zm - zc[d], s1 = Kr[m * 16 + 1 + d];
+          if (c <= D) v += s1 - dz * s0;
+          else v += Kr[m * 16 + 1 + D + d] - 2.0 * dz * s1 + dz * dz * s0;
+        }
+      }
+      krow[idx] = v;
+    }
   }
 }
 
+}  // namespace zigp
+
+namespace zigp {
 
 // =============================================================================================================================
 // host orchestration
 // =============================================================================================================================
+constexpr size_t KF_BWD_LDS = sizeof(double) * (KF_WAVES * 4 * 16 * KF_NBMAX * KF_LD + 6 * KF_FRAG);
 struct KfState {
   DevBuf in, mat, pts, acc, res, out;
 };
@@ -718,7 +773,8 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   if (!attr_set) {
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * PB * PBLD)));
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_backward), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(double) * KF_WAVES * 4 * 16 * KF_NBMAX * KF_LD)));
+                                    (int)KF_BWD_LDS));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KF_FIN_LDS));
     attr_set = true;
   }
   int Mq[2][2];
@@ -821,7 +877,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     const int nwg = (nw + KF_WAVES - 1) / KF_WAVES, nw_alloc = nwg * KF_WAVES;
     ZIGP_ENSURE(c, ks.acc, (size_t)2 * nw_alloc * KF_ACC_DOUBLES);
     for (int h = 0; h < nlat; ++h) ka.lat[h].acc = ks.acc.p + (size_t)h * nw_alloc * KF_ACC_DOUBLES;
-    hipLaunchKernelGGL(k_kf_backward, dim3(nwg, nlat), dim3(64 * KF_WAVES), sizeof(double) * KF_WAVES * 4 * 16 * KF_NBMAX * KF_LD, c->stream, ka);
+    hipLaunchKernelGGL(k_kf_backward, dim3(nwg, nlat), dim3(64 * KF_WAVES), KF_BWD_LDS, c->stream, ka);
     ZIGP_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(k_kf_reduce, dim3(KF_ACC_DOUBLES / 16, nlat), dim3(256), 0, c->stream, ka.lat[0].acc, ka.lat[gl_].acc, nw_alloc,
                        lat(0) + KF_LAT_WORK, lat(gl_) + KF_LAT_WORK);
@@ -840,7 +896,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       jb.krow0 = res(h) + KF_RES_KROW0; jb.krow1 = res(h) + KF_RES_KROW1; jb.gu = res(h) + KF_RES_GU; jb.gs = res(h) + KF_RES_GS;
     }
     fa.jitter = jitter; fa.with_kl = include_kl ? 1 : 0;
-    hipLaunchKernelGGL(k_kf_finish, dim3(nlat), dim3(1024), 0, c->stream, fa);
+    hipLaunchKernelGGL(k_kf_finish, dim3(nlat), dim3(1024), KF_FIN_LDS, c->stream, fa);
     ZIGP_HIP(c, hipGetLastError());
   }
   double* hres = nullptr;
