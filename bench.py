@@ -127,10 +127,13 @@ def other_configs(eng, X3, Y3, p3, jitter):
         np.random.seed(0)
         pk = engine_params(init_params(Xtr, (32, 32), (32, 32), kmeans_seed=1))
         n5 = Xtr.shape[0]
-        t = timeit(lambda: eng.kron_elbo(pk, Xtr, Ytr, jitter=1e-5), 5, 2)
+        eng.set_data(Xtr, Ytr)
+        t = timeit(lambda: eng.kron_elbo(pk, rows=(0, n5), jitter=1e-5), 20, 3)
         # algorithmic bytes: X 24 B + Y 8 B per point read per pass; two passes (value, gradient)
-        out['cfg5_full'] = dict(workload='pptr N=%d, 32x32, value+gradient, host minibatch in' % n5, ms_per_step=t * 1e3,
+        out['cfg5_full'] = dict(workload='pptr N=%d, 32x32, value+gradient, data resident in HBM' % n5, ms_per_step=t * 1e3,
                                 rows_per_s=n5 / t, algorithmic_GBps=2 * 32.0 * n5 / t / 1e9, frac_hbm=2 * 32.0 * n5 / t / PEAK_HBM)
+        t = timeit(lambda: eng.kron_elbo(pk, Xtr, Ytr, jitter=1e-5), 10, 2)
+        out['cfg5_full']['ms_per_step_host_minibatch_in'] = t * 1e3      # PCIe-inclusive: X, Y (3.4 MB) staged and copied every step
         xb, yb = Xtr[:1000], Ytr[:1000]
         t = timeit(lambda: eng.kron_elbo(pk, xb, yb, jitter=1e-5, scale=n5 / 1000.0), 50, 5)
         out['cfg5_mb1000'] = dict(workload='pptr minibatch 1000 (scripts/onoff.py:55), 32x32', ms_per_step=t * 1e3, steps_per_s=1 / t)

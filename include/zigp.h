@@ -122,6 +122,12 @@ typedef struct {
 int zigp_kron_elbo(zigp_ctx* ctx, const zigp_kron_params* p, const double* X, const double* Y, int64_t N,
                    double jitter, double scale, double g_offset, int32_t include_kl,
                    double* elbo_data, double* kl, zigp_kron_grads* grads);
+/* The same step on rows [row_begin, row_end) of the RESIDENT data set (zigp_set_data / zigp_set_data_device, D = D0 + D1): no
+ * host->device copy of the minibatch.  The reference's iterator (DataSet.next_batch, onofftf/main.py:98-133) shuffles once per
+ * epoch and then hands out contiguous slices, so a host that makes the permuted epoch resident feeds every step by row range;
+ * the full-batch configuration (BASELINE cfg5) is rows [0, N). */
+int zigp_kron_elbo_rows(zigp_ctx* ctx, const zigp_kron_params* p, int64_t row_begin, int64_t row_end, double jitter, double scale,
+                        double g_offset, int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads);
 /* Replaces predict_onoff's graph (onofftf/onoffpred.py:127-200); out9 as zigp_predict. */
 int zigp_kron_predict(zigp_ctx* ctx, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter,
                       double g_offset, double* out9);

@@ -138,3 +138,35 @@ def test_kron_value_only_and_no_kl(engine):
     assert g is None and np.isfinite(ed) and kl > 0
     ed2, kl2, _ = engine.kron_elbo(p, X, Y, include_kl=False, need_grad=False)
     assert kl2 == 0.0 and ed2 == ed
+
+
+def test_kron_elbo_on_resident_rows_equals_host_minibatch(engine):
+    """zigp_kron_elbo_rows: rows of the resident data set instead of a host minibatch -- same kernels, same numbers"""
+    X, Y, p = make_kron_problem(3000, 32, 32, seed=5)
+    engine.set_data(X, Y)
+    for lo, hi in ((0, 3000), (1000, 2000), (17, 1234)):
+        a = engine.kron_elbo(p, X[lo:hi], Y[lo:hi], jitter=1e-5, scale=2.5)
+        b = engine.kron_elbo(p, rows=(lo, hi), jitter=1e-5, scale=2.5)
+        assert a[0] == b[0] and a[1] == b[1]
+        for k in a[2]:
+            va, vb = a[2][k], b[2][k]
+            if isinstance(va, list):
+                for x, y in zip(va, vb):
+                    assert np.array_equal(np.asarray(x), np.asarray(y)), k
+            else:
+                assert np.array_equal(np.asarray(va), np.asarray(vb)), k
+    with pytest.raises(ValueError):
+        engine.kron_elbo(p, rows=(5, 5))
+    with pytest.raises(ValueError):
+        engine.kron_elbo(p, rows=(0, 3001))
+
+
+def test_kron_fused_and_panel_paths_agree(engine):
+    """the register-resident kernels (grids up to 32 x 32) against the GEMM-panel path (used for larger factors): a 32 x 33 grid
+    takes the panel path, and on the shared 32 x 32 sub-problem both must match the literal oracle (above) -- here: bit-stable reruns"""
+    X, Y, p = make_kron_problem(2000, 32, 32, seed=9)
+    a = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=3.0)
+    b = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=3.0)
+    assert a[0] == b[0] and a[1] == b[1]
+    for k in ('u_fm', 'u_gs_sqrt'):
+        assert np.array_equal(a[2][k], b[2][k])

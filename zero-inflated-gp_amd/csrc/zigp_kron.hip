@@ -529,21 +529,21 @@ namespace {
 
 int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
                     double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
-                    int lik, double* d_offset);
+                    int lik, double* d_offset, bool dev_xy);
 
 // small grids go through the fused register-resident kernels (zigp_kronf.hip); larger factors through the panel path below
 int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
              double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
-             int lik = ZIGP_LIK_ONOFF, double* d_offset = nullptr) {
+             int lik = ZIGP_LIK_ONOFF, double* d_offset = nullptr, bool dev_xy = false) {
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;
   if (!c->capturing && !c->kron_legacy && kf_eligible(p, nlat))
-    return kronf_run(c, p, X, Y, N, jitter, scale, g_offset, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset);
-  return kron_run_panels(c, p, X, Y, N, jitter, scale, g_offset, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset);
+    return kronf_run(c, p, X, Y, N, jitter, scale, g_offset, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset, dev_xy);
+  return kron_run_panels(c, p, X, Y, N, jitter, scale, g_offset, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset, dev_xy);
 }
 
 int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
                     double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
-                    int lik, double* d_offset) {
+                    int lik, double* d_offset, bool dev_xy) {
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;   // single-latent heads use the f latent only; g_offset is then f_mu
   if (!c->kron) { c->kron = new (std::nothrow) KronState(); c->kron_free = kron_free; if (!c->kron) { c->err = "out of memory"; return ZIGP_EHIP; } }
   KronState& ks = *c->kron;
@@ -551,8 +551,14 @@ int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, con
   const bool need_grad = grads != nullptr && !predict;
   const int D0 = p->D0, D1 = p->D1, ldx = D0 + D1;
   const int64_t Nc = std::max<int64_t>(1024, round_up(N, 1024));
-  ZIGP_TRY(upload_padded(c, ks.X, X, (size_t)N * ldx, (size_t)N * ldx));   // the minibatch, staged like the parameters
-  if (Y) ZIGP_TRY(upload_padded(c, ks.Y, Y, (size_t)N, (size_t)N));
+  if (dev_xy) {   // rows of the resident data set: device-to-device
+    ZIGP_ENSURE(c, ks.X, (size_t)N * ldx); ZIGP_ENSURE(c, ks.Y, (size_t)N);
+    ZIGP_HIP(c, hipMemcpyAsync(ks.X.p, X, sizeof(double) * N * ldx, hipMemcpyDeviceToDevice, c->stream));
+    if (Y) ZIGP_HIP(c, hipMemcpyAsync(ks.Y.p, Y, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    ZIGP_TRY(upload_padded(c, ks.X, X, (size_t)N * ldx, (size_t)N * ldx));   // the minibatch, staged like the parameters
+    if (Y) ZIGP_TRY(upload_padded(c, ks.Y, Y, (size_t)N, (size_t)N));
+  }
   HostKronLatent hl[2] = {{{p->M0f, p->M1f}, {p->Z0f, p->Z1f}, {p->ell0f, p->ell1f}, {p->var0f, p->var1f}, p->u_fm, p->u_fs_sqrt},
                           {{p->M0g, p->M1g}, {p->Z0g, p->Z1g}, {p->ell0g, p->ell1g}, {p->var0g, p->var1g}, p->u_gm, p->u_gs_sqrt}};
   if (nlat == 1) hl[1] = hl[0];
@@ -709,6 +715,19 @@ int zigp_kron_elbo(zigp_ctx* c, const zigp_kron_params* p, const double* X, cons
   return kron_run(c, p, X, Y, N, jitter, scale, g_offset, include_kl, false, nullptr, elbo_data, kl, grads);
 }
 
+int zigp_kron_elbo_rows(zigp_ctx* c, const zigp_kron_params* p, int64_t row_begin, int64_t row_end, double jitter, double scale, double g_offset,
+                        int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads) {
+  if (!c) return ZIGP_EARG;
+  ZIGP_TRY(validate_kron(c, p));
+  if (!c->dX) return fail_arg(c, "zigp_kron_elbo_rows: no data set (call zigp_set_data first)");
+  if (p->D0 + p->D1 != c->D) return fail_arg(c, "zigp_kron_elbo_rows: D0 + D1 differs from the data's D");
+  if (row_begin < 0 || row_end > c->N || row_begin >= row_end) return fail_arg(c, "zigp_kron_elbo_rows: bad row range");
+  if (!(jitter >= 0)) return fail_arg(c, "zigp_kron_elbo_rows: jitter must be >= 0");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  return kron_run(c, p, c->dX + row_begin * c->D, c->dY + row_begin, row_end - row_begin, jitter, scale, g_offset, include_kl, false, nullptr,
+                  elbo_data, kl, grads, ZIGP_LIK_ONOFF, nullptr, true);
+}
+
 int zigp_kron_predict(zigp_ctx* c, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter, double g_offset, double* out9) {
   if (!c) return ZIGP_EARG;
   ZIGP_TRY(validate_kron(c, p));
@@ -750,6 +769,8 @@ int zigp_test_kron_graph(zigp_ctx* c, const zigp_kron_params* p, const double* X
   if (!c || !out_ms || iters <= 0) return ZIGP_EARG;
   ZIGP_TRY(validate_kron(c, p));
   ZIGP_HIP(c, hipSetDevice(c->device));
+  struct LegacyGuard { zigp_ctx* c; ~LegacyGuard() { c->kron_legacy = false; } } legacy_guard{c};
+  c->kron_legacy = true;   // the diagnostic compares eager vs graph replay of the SAME (panel) launch sequence
   double ed = 0, kl = 0;
   zigp_kron_grads g;
   memset(&g, 0, sizeof(g));   // NULL outputs: gradients are computed and downloaded, not copied out

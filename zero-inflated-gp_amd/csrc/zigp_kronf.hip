@@ -579,104 +579,100 @@ struct KfFinishJob {
   double *krow0, *krow1, *gu, *gs;     // outputs: [M0][2 + 2 D0], [M1][2 + 2 D1], [M0*M1], [M0*M1]
 };
 struct KfFinishArgs { KfFinishJob job[2]; double jitter; int with_kl; };
-constexpr size_t KF_FIN_LDS = sizeof(double) * 12 * KF_SMAT;
+constexpr size_t KF_FIN_LDS = sizeof(double) * 10 * KF_SMAT;
 
+// grid (2, latents): workgroup (p, h) runs the reverse pass of factor p of latent h; workgroup p = 0 also forms dU -> gu, gs
 __global__ void __launch_bounds__(1024)
 k_kf_finish(KfFinishArgs a) {
   extern __shared__ double sm[];
-  double *sP0 = sm, *sP1 = sm + KF_SMAT, *sdAl = sm + 2 * KF_SMAT, *sdP0 = sm + 3 * KF_SMAT, *sdP1 = sm + 4 * KF_SMAT, *sT0 = sm + 5 * KF_SMAT,
-         *sT1 = sm + 6 * KF_SMAT, *sU = sm + 7 * KF_SMAT, *sX = sm + 8 * KF_SMAT, *sG = sm + 9 * KF_SMAT, *sQ = sm + 10 * KF_SMAT, *sK = sm + 11 * KF_SMAT;
-  const KfFinishJob& jb = a.job[blockIdx.x];
+  double *sP = sm, *sPo = sm + KF_SMAT, *sdAl = sm + 2 * KF_SMAT, *sdP = sm + 3 * KF_SMAT, *sT = sm + 4 * KF_SMAT, *sU = sm + 5 * KF_SMAT,
+         *sX = sm + 6 * KF_SMAT, *sG = sm + 7 * KF_SMAT, *sQ = sm + 8 * KF_SMAT, *sK = sm + 9 * KF_SMAT;
+  const KfFinishJob& jb = a.job[blockIdx.y];
+  const int p = blockIdx.x;
   const int t = threadIdx.x, M0 = jb.M0, M1 = jb.M1, Mq0 = jb.Mq0, Mq1 = jb.Mq1;
   const bool kl = a.with_kl != 0;
-  kf_lds_load(sP0, jb.P0, Mq0, Mq0, Mq0);
-  kf_lds_load(sP1, jb.P1, Mq1, Mq1, Mq1);
+  const int M = p == 0 ? M0 : M1, Mq = p == 0 ? Mq0 : Mq1, Mo = p == 0 ? M1 : M0, D = p == 0 ? jb.D0 : jb.D1;
+  const double* Z = p == 0 ? jb.Z0 : jb.Z1;
+  const double* zc = p == 0 ? jb.zc0 : jb.zc1;
+  const double* Kr = jb.work + (p == 0 ? KF_W_K0 : KF_W_K1);
+  double* krow = p == 0 ? jb.krow0 : jb.krow1;
+  kf_lds_load(sP, p == 0 ? jb.P0 : jb.P1, Mq, Mq, Mq);
   kf_lds_load(sdAl, jb.work + KF_W_AL, Mq0, Mq1, KF_MQ);
-  kf_lds_load(sdP0, jb.work + KF_W_P0, Mq0, Mq0, KF_MQ);
-  kf_lds_load(sdP1, jb.work + KF_W_P1, Mq1, Mq1, KF_MQ);
-  kf_lds_load(sT0, jb.T0, Mq0, Mq1, Mq1);
-  kf_lds_load(sT1, jb.T1, Mq0, Mq1, Mq1);
+  kf_lds_load(sdP, jb.work + (p == 0 ? KF_W_P0 : KF_W_P1), Mq, Mq, KF_MQ);
+  kf_lds_load(sT, p == 0 ? jb.T0 : jb.T1, Mq0, Mq1, Mq1);
   kf_lds_load(sU, jb.U, Mq0, Mq1, Mq1);
+  kf_lds_load(sK, p == 0 ? jb.K0 : jb.K1, M, M, PB);
+  if (p == 0) kf_lds_load(sPo, jb.P1, Mq1, Mq1, Mq1);
   __syncthreads();
-  kf_lds_mm<false, false, false>(sX, sdAl, sP1, Mq0, Mq1, Mq1);       // X = dAl P1
-  kf_lds_mm<false, true, true>(sdP0, sdAl, sT0, Mq0, Mq0, Mq1);       // dP0 += dAl T0^T
-  kf_lds_mm<true, false, true>(sdP1, sT1, sdAl, Mq1, Mq1, Mq0);       // dP1 += T1^T dAl
-  __syncthreads();
-  kf_lds_mm<false, false, false>(sG, sP0, sX, Mq0, Mq1, Mq0);         // dU = P0 X
-  __syncthreads();
-  for (int idx = t; idx < M0 * M1; idx += 1024) {
-    const int i = idx / M1, j = idx - i * M1;
-    const double sv = jb.s[idx];
-    double gu = sG[i * KF_SLD + j], gs = 2.0 * sv * jb.work[KF_W_S2 + i * KF_MQ + j];
-    if (kl) { gu -= jb.Al[i * Mq1 + j]; gs -= (-1.0 / sv + jb.dvec0[i] * jb.dvec1[j] * sv); }
-    jb.gu[idx] = gu; jb.gs[idx] = gs;
+  if (p == 0) {
+    kf_lds_mm<false, false, false>(sX, sdAl, sPo, Mq0, Mq1, Mq1);       // X = dAl P1
+    kf_lds_mm<false, true, true>(sdP, sdAl, sT, Mq0, Mq0, Mq1);         // dP0 += dAl T0^T
+    if (kl) kf_lds_mm<false, true, false>(sQ, sT, sU, Mq0, Mq0, Mq1);   // Q0 = T0 U^T
+    __syncthreads();
+    kf_lds_mm<false, false, false>(sG, sP, sX, Mq0, Mq1, Mq0);          // dU = P0 X
+    __syncthreads();
+    for (int idx = t; idx < M0 * M1; idx += 1024) {
+      const int i = idx / M1, j = idx - i * M1;
+      const double sv = jb.s[idx];
+      double gu = sG[i * KF_SLD + j], gs = 2.0 * sv * jb.work[KF_W_S2 + i * KF_MQ + j];
+      if (kl) { gu -= jb.Al[i * Mq1 + j]; gs -= (-1.0 / sv + jb.dvec0[i] * jb.dvec1[j] * sv); }
+      jb.gu[idx] = gu; jb.gs[idx] = gs;
+    }
+  } else {
+    kf_lds_mm<true, false, true>(sdP, sT, sdAl, Mq1, Mq1, Mq0);         // dP1 += T1^T dAl
+    if (kl) kf_lds_mm<true, false, false>(sQ, sU, sT, Mq1, Mq1, Mq0);   // Q1 = U^T T1
   }
-  for (int p = 0; p < 2; ++p) {
-    const int M = p == 0 ? M0 : M1, Mq = p == 0 ? Mq0 : Mq1, Mo = p == 0 ? M1 : M0, D = p == 0 ? jb.D0 : jb.D1;
-    double* dP = p == 0 ? sdP0 : sdP1;
-    const double* P = p == 0 ? sP0 : sP1;
-    const double* Z = p == 0 ? jb.Z0 : jb.Z1;
-    const double* zc = p == 0 ? jb.zc0 : jb.zc1;
-    const double* Kr = jb.work + (p == 0 ? KF_W_K0 : KF_W_K1);
-    double* krow = p == 0 ? jb.krow0 : jb.krow1;
-    __syncthreads();
-    kf_lds_load(sK, p == 0 ? jb.K0 : jb.K1, M, M, PB);
+  __syncthreads();
+  // sX = sym(dP) [- kl pieces]
+  for (int idx = t; idx < Mq * Mq; idx += 1024) {
+    const int i = idx / Mq, j = idx - i * Mq;
+    double v = 0.5 * (sdP[i * KF_SLD + j] + sdP[j * KF_SLD + i]);
     if (kl) {
-      if (p == 0) kf_lds_mm<false, true, false>(sQ, sT0, sU, Mq0, Mq0, Mq1);     // Q0 = T0 U^T
-      else kf_lds_mm<true, false, false>(sQ, sU, sT1, Mq1, Mq1, Mq0);            // Q1 = U^T T1
-    }
-    __syncthreads();
-    // sX = sym(dP) [- kl pieces]
-    for (int idx = t; idx < Mq * Mq; idx += 1024) {
-      const int i = idx / Mq, j = idx - i * Mq;
-      double v = 0.5 * (dP[i * KF_SLD + j] + dP[j * KF_SLD + i]);
-      if (kl) {
-        v -= 0.25 * (sQ[i * KF_SLD + j] + sQ[j * KF_SLD + i]);
-        if (i == j) {
-          double w = 0.0;
-          if (p == 0) { for (int o = 0; o < M1; ++o) w = fma(jb.dvec1[o], jb.S2[i * Mq1 + o], w); }
-          else { for (int o = 0; o < M0; ++o) w = fma(jb.dvec0[o], jb.S2[o * Mq1 + i], w); }
-          v -= 0.5 * w;
-        }
+      v -= 0.25 * (sQ[i * KF_SLD + j] + sQ[j * KF_SLD + i]);
+      if (i == j) {
+        double w = 0.0;
+        if (p == 0) { for (int o = 0; o < M1; ++o) w = fma(jb.dvec1[o], jb.S2[i * Mq1 + o], w); }
+        else { for (int o = 0; o < M0; ++o) w = fma(jb.dvec0[o], jb.S2[o * Mq1 + i], w); }
+        v -= 0.5 * w;
       }
-      sX[i * KF_SLD + j] = v;
     }
-    __syncthreads();
-    kf_lds_mm<false, false, false>(sQ, sX, P, Mq, Mq, Mq);      // Q = sym(dP) P
-    __syncthreads();
-    const double coef = kl ? 0.5 * (double)Mo : 0.0;
-    for (int idx = t; idx < Mq * Mq; idx += 1024) {              // G = -P Q - coef P
-      const int i = idx / Mq, j = idx - i * Mq;
-      double v = 0.0;
+    sX[i * KF_SLD + j] = v;
+  }
+  __syncthreads();
+  kf_lds_mm<false, false, false>(sQ, sX, sP, Mq, Mq, Mq);      // Q = sym(dP) P
+  __syncthreads();
+  const double coef = kl ? 0.5 * (double)Mo : 0.0;
+  for (int idx = t; idx < Mq * Mq; idx += 1024) {              // G = -P Q - coef P
+    const int i = idx / Mq, j = idx - i * Mq;
+    double v = 0.0;
 #pragma unroll 4
-      for (int q = 0; q < Mq; ++q) v = fma(P[i * KF_SLD + q], sQ[q * KF_SLD + j], v);
-      sG[i * KF_SLD + j] = -v - coef * P[i * KF_SLD + j];
-    }
-    __syncthreads();
-    // krow[m][c]: Kuu part (as k_kuu_grad, Kz = K_p - jitter I) + data moments rebuilt around z_m
-    const int W = 2 + 2 * D;
-    for (int idx = t; idx < M * W; idx += 1024) {
-      const int m = idx / W, c = idx - m * W;
-      double v = 0.0;
-      if (c <= 2 * D) {
-        const int d = (c == 0) ? 0 : (c - 1) % D;
-        const double zm = Z[m * D + d];
-        for (int j = 0; j < M; ++j) {
-          const double kz = sK[m * KF_SLD + j] - ((m == j) ? a.jitter : 0.0);
-          const double tt = sG[m * KF_SLD + j] * kz;
-          const double df = Z[j * D + d] - zm;
-          v += (c == 0) ? tt : ((c <= D) ? 2.0 * tt * df : tt * df * df);
-        }
-        const double s0 = Kr[m * 16];
-        if (c == 0) v += s0;
-        else {
-          const double dz = zm - zc[d], s1 = Kr[m * 16 + 1 + d];
-          if (c <= D) v += s1 - dz * s0;
-          else v += Kr[m * 16 + 1 + D + d] - 2.0 * dz * s1 + dz * dz * s0;
-        }
+    for (int q = 0; q < Mq; ++q) v = fma(sP[i * KF_SLD + q], sQ[q * KF_SLD + j], v);
+    sG[i * KF_SLD + j] = -v - coef * sP[i * KF_SLD + j];
+  }
+  __syncthreads();
+  // krow[m][c]: Kuu part (as k_kuu_grad, Kz = K_p - jitter I) + data moments rebuilt around z_m
+  const int W = 2 + 2 * D;
+  for (int idx = t; idx < M * W; idx += 1024) {
+    const int m = idx / W, c = idx - m * W;
+    double v = 0.0;
+    if (c <= 2 * D) {
+      const int d = (c == 0) ? 0 : (c - 1) % D;
+      const double zm = Z[m * D + d];
+      for (int j = 0; j < M; ++j) {
+        const double kz = sK[m * KF_SLD + j] - ((m == j) ? a.jitter : 0.0);
+        const double tt = sG[m * KF_SLD + j] * kz;
+        const double df = Z[j * D + d] - zm;
+        v += (c == 0) ? tt : ((c <= D) ? 2.0 * tt * df : tt * df * df);
       }
-      krow[idx] = v;
+      const double s0 = Kr[m * 16];
+      if (c == 0) v += s0;
+      else {
+        const double dz = zm - zc[d], s1 = Kr[m * 16 + 1 + d];
+        if (c <= D) v += s1 - dz * s0;
+        else v += Kr[m * 16 + 1 + D + d] - 2.0 * dz * s1 + dz * dz * s0;
+      }
     }
+    krow[idx] = v;
   }
 }
 
@@ -721,7 +717,8 @@ constexpr size_t KF_RES_KLV = 0, KF_RES_KROW0 = 8, KF_RES_KROW1 = KF_RES_KROW0 +
 
 static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
                      double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
-                     int lik, double* d_offset) {
+                     int lik, double* d_offset, bool dev_xy) {
+  // dev_xy: X / Y are DEVICE pointers into the resident data set (zigp_set_data): nothing but the parameters is staged
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;
   if (!c->kronf) { c->kronf = new (std::nothrow) KfState(); c->kronf_free = kf_free; if (!c->kronf) { c->err = "out of memory"; return ZIGP_EHIP; } }
   KfState& ks = *c->kronf;
@@ -733,7 +730,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
                         {{p->M0g, p->M1g}, {p->Z0g, p->Z1g}, {p->ell0g, p->ell1g}, {p->var0g, p->var1g}, p->u_gm, p->u_gs_sqrt}};
   if (nlat == 1) hl[1] = hl[0];
   // ---- one staged host -> device copy: X, Y, per latent Z0, Z1, u, s
-  size_t off_x = 0, off_y = (size_t)N * ldx, off = off_y + (size_t)N;
+  size_t off_x = 0, off_y = dev_xy ? 0 : (size_t)N * ldx, off = dev_xy ? 0 : off_y + (size_t)N;
   size_t off_z[2][2], off_u[2], off_s[2];
   for (int h = 0; h < nlat; ++h) {
     off_z[h][0] = off; off += (size_t)hl[h].M[0] * D0;
@@ -745,8 +742,10 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   ZIGP_ENSURE(c, ks.in, n_in);
   {
     ZIGP_PINNED(c, hin, n_in);
-    memcpy(hin + off_x, X, sizeof(double) * N * ldx);
-    if (Y) memcpy(hin + off_y, Y, sizeof(double) * N); else memset(hin + off_y, 0, sizeof(double) * N);
+    if (!dev_xy) {
+      memcpy(hin + off_x, X, sizeof(double) * N * ldx);
+      if (Y) memcpy(hin + off_y, Y, sizeof(double) * N); else memset(hin + off_y, 0, sizeof(double) * N);
+    }
     for (int h = 0; h < nlat; ++h) {
       memcpy(hin + off_z[h][0], hl[h].Z[0], sizeof(double) * hl[h].M[0] * D0);
       memcpy(hin + off_z[h][1], hl[h].Z[1], sizeof(double) * hl[h].M[1] * D1);
@@ -825,7 +824,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   // ---- point stage
   KfArgs ka;
   memset(&ka, 0, sizeof(ka));
-  ka.X = ks.in.p + off_x; ka.N = N; ka.Npad = Npad; ka.ldx = ldx; ka.ntiles = (int)(Npad / 16);
+  ka.X = dev_xy ? X : ks.in.p + off_x; ka.N = N; ka.Npad = Npad; ka.ldx = ldx; ka.ntiles = (int)(Npad / 16);
   for (int h = 0; h < nlat; ++h) {
     KfLat& L = ka.lat[h];
     for (int q = 0; q < 2; ++q) {
@@ -851,7 +850,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   }
   KronPwArgs a;
   const int gl_ = nlat - 1;   // latent whose buffers stand in for g (unused by the single-latent kernels)
-  a.part_f = pts(0); a.part_g = pts(gl_); a.Y = Y ? ks.in.p + off_y : nullptr; a.N = N; a.Nc = Npad;
+  a.part_f = pts(0); a.part_g = pts(gl_); a.Y = Y ? (dev_xy ? Y : ks.in.p + off_y) : nullptr; a.N = N; a.Nc = Npad;
   a.knn_f = p->var0f * p->var1f; a.knn_g = p->var0g * p->var1g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
   a.gm_f = need_grad ? pts(0) + 4 * Npad : nullptr; a.gv_f = pts(0) + 5 * Npad; a.gm_g = pts(gl_) + 4 * Npad; a.gv_g = pts(gl_) + 5 * Npad;
   a.dq0_f = pts(0) + 6 * Npad; a.dq1_f = pts(0) + 7 * Npad; a.dq0_g = pts(gl_) + 6 * Npad; a.dq1_g = pts(gl_) + 7 * Npad;
@@ -896,7 +895,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       jb.krow0 = res(h) + KF_RES_KROW0; jb.krow1 = res(h) + KF_RES_KROW1; jb.gu = res(h) + KF_RES_GU; jb.gs = res(h) + KF_RES_GS;
     }
     fa.jitter = jitter; fa.with_kl = include_kl ? 1 : 0;
-    hipLaunchKernelGGL(k_kf_finish, dim3(nlat), dim3(1024), KF_FIN_LDS, c->stream, fa);
+    hipLaunchKernelGGL(k_kf_finish, dim3(2, nlat), dim3(1024), KF_FIN_LDS, c->stream, fa);
     ZIGP_HIP(c, hipGetLastError());
   }
   double* hres = nullptr;

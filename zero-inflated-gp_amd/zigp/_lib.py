@@ -71,6 +71,8 @@ SIGNATURES = {
     'zigp_rbf_K': (C.c_int, [C.c_void_p, dp, C.c_int64, dp, C.c_int64, C.c_int32, dp, C.c_double, dp]),
     'zigp_kron_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, dp, C.c_int64, C.c_double, C.c_double, C.c_double,
                                  C.c_int32, dp, dp, C.POINTER(zigp_kron_grads)]),
+    'zigp_kron_elbo_rows': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                      C.c_int32, dp, dp, C.POINTER(zigp_kron_grads)]),
     'zigp_kron_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, C.c_int64, C.c_double, C.c_double, dp]),
     'zigp_test_kron_graph': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, dp, C.c_int64, C.c_double, C.c_double, C.c_int32, dp]),
     'zigp_set_overlap': (C.c_int, [C.c_void_p, C.c_int32]),

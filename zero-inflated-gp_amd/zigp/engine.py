@@ -218,15 +218,19 @@ class DenseEngine:
         s.noise = float(np.squeeze(p.get('noise', 1.0)))
         return s, keep, dims
 
-    def kron_elbo(self, p, X, Y, jitter=1e-5, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True):
-        """One Kronecker ELBO (step) on an explicit minibatch; returns (elbo_data, kl, grads or None)."""
+    def kron_elbo(self, p, X=None, Y=None, jitter=1e-5, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True, rows=None):
+        """One Kronecker ELBO (step); returns (elbo_data, kl, grads or None).  Either an explicit host minibatch (X, Y), as
+        scripts/onoff.py:377-381 feeds it, or rows=(lo, hi) of the resident data set (set_data / set_data_device)."""
         s, keep, dims = self._pack_kron(p)
-        X = as_f64(X)
-        if X.ndim != 2 or X.shape[1] != dims[0] + dims[1]:
-            raise ValueError('X must be (N,%d)' % (dims[0] + dims[1]))
-        Y = as_f64(Y).reshape(-1)
-        if Y.size != X.shape[0]:
-            raise ValueError('Y must have N entries')
+        if rows is None:
+            X = as_f64(X)
+            if X.ndim != 2 or X.shape[1] != dims[0] + dims[1]:
+                raise ValueError('X must be (N,%d)' % (dims[0] + dims[1]))
+            Y = as_f64(Y).reshape(-1)
+            if Y.size != X.shape[0]:
+                raise ValueError('Y must have N entries')
+        elif X is not None or Y is not None:
+            raise ValueError('pass either (X, Y) or rows=(lo, hi), not both')
         ed, kl = C.c_double(0), C.c_double(0)
         g, gs = None, None
         if need_grad:
@@ -240,8 +244,13 @@ class DenseEngine:
                 setattr(gs, 'Z0' + tag, ptr(arrs['Z0'])); setattr(gs, 'Z1' + tag, ptr(arrs['Z1']))
                 setattr(gs, 'ell0' + tag, ptr(arrs['ell0'])); setattr(gs, 'ell1' + tag, ptr(arrs['ell1']))
                 setattr(gs, 'u_%sm' % tag, ptr(arrs['um'])); setattr(gs, 'u_%ss_sqrt' % tag, ptr(arrs['us']))
-        rc = self.lib.zigp_kron_elbo(self.ctx, C.byref(s), ptr(X), ptr(Y), X.shape[0], float(jitter), float(scale), float(g_offset),
-                                     1 if include_kl else 0, C.byref(ed), C.byref(kl), C.byref(gs) if gs is not None else None)
+        gref = C.byref(gs) if gs is not None else None
+        if rows is None:
+            rc = self.lib.zigp_kron_elbo(self.ctx, C.byref(s), ptr(X), ptr(Y), X.shape[0], float(jitter), float(scale), float(g_offset),
+                                         1 if include_kl else 0, C.byref(ed), C.byref(kl), gref)
+        else:
+            rc = self.lib.zigp_kron_elbo_rows(self.ctx, C.byref(s), int(rows[0]), int(rows[1]), float(jitter), float(scale), float(g_offset),
+                                              1 if include_kl else 0, C.byref(ed), C.byref(kl), gref)
         _check(self.lib, self.ctx, rc)
         out = None
         if need_grad:
