@@ -59,11 +59,45 @@ def test_toy_fit_reaches_notebook_band(tmp_path):
     e1 = m.compute_log_likelihood()
     print('toy ELBO: init %.3f -> %.6f after %d its (%d evals); notebook 488.713' % (e0, e1, res.nit, res.nfev))
     assert e1 > e0
-    assert 400.0 < e1 < 560.0
+    assert 0.95 * 488.713 < e1 < 1.05 * 488.713          # +-5 % of the notebook's number (seed 0: 480.5; see the 8-seed test)
     # checkpoint round trip (savemodel, OnOffSVGP.py:154-158)
     f = m.savemodel(str(tmp_path / 'm.pickle'))
     m2 = pickle.load(open(f, 'rb'))
     assert abs(m2.compute_log_likelihood() - e1) < 1e-9 * abs(e1)
+
+
+def test_toy_fit_eight_seeds_bracket_the_notebook_number():
+    """The notebook's 488.7130771963765 (zero-inflated-gpflow.ipynb:146) is ONE draw of an unseeded init (OnOffSVGP.py:56-57) read
+    off after 8000 L-BFGS-B iterations -- BEFORE convergence: every seed is still climbing at 8000 (scipy stops on the iteration
+    limit) and plateaus 20-50 units higher (tools/toy_long.py: 478 ... 509).  Evidence that the recipe reproduces it: the values at
+    8000 iterations from 8 seeds reach to within 1 % below it, none is further than 8 % away, and the best seed continued to
+    convergence passes it -- the notebook number is bracketed by [value at 8000 its, converged value] of the same recipe.
+    The distribution goes to gpurun_out/toy_seeds.json (quoted in DESIGN.md)."""
+    import json
+    NOTEBOOK = 488.7130771963765
+    runs, models = [], []
+    for seed in range(8):
+        m, X, Y = _toy_model(seed=seed)
+        res = m.optimize(maxiter=8000)
+        runs.append(dict(seed=seed, elbo=float(m.compute_log_likelihood()), nit=int(res.nit), nfev=int(res.nfev)))
+        models.append(m)
+        print('toy seed %d: ELBO %.6f after %d its (%d evals)' % (seed, runs[-1]['elbo'], res.nit, res.nfev))
+    e = np.array([r['elbo'] for r in runs])
+    print('toy ELBO over 8 seeds at 8000 its: min %.4f median %.4f max %.4f (notebook 488.7131)' % (e.min(), np.median(e), e.max()))
+    best = int(np.argmax(e))
+    res = models[best].optimize(maxiter=40000)
+    conv = float(models[best].compute_log_likelihood())
+    print('best seed %d continued: ELBO %.6f after %d more its' % (best, conv, res.nit))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        json.dump(dict(notebook=NOTEBOOK, runs=runs, best_seed=best, best_seed_converged=conv, extra_its=int(res.nit)),
+                  open(os.path.join(out, 'toy_seeds.json'), 'w'), indent=1)
+    except OSError:
+        pass
+    assert e.max() >= 0.99 * NOTEBOOK                      # within 1 % at the notebook's own iteration count
+    assert np.all(e >= 0.92 * NOTEBOOK) and np.all(e <= 1.05 * NOTEBOOK)
+    assert e.max() <= NOTEBOOK + 25.0 and conv >= NOTEBOOK  # [value at 8000 its, converged value] brackets the notebook number
 
 
 def test_minibatch_scale_and_adam():
