@@ -189,3 +189,35 @@ def test_kron_oracle_frozen_against_g4():
         assert abs(e - float(g[lik + '_elbo'])) <= 1e-11 * abs(float(g[lik + '_elbo'])) and abs(kl - float(g[lik + '_kl'])) <= 1e-11 * abs(kl)
         pr = np.stack([np.asarray(q).reshape(-1) for q in o.kron_head_predict(X, ph, lik, 1e-6, 0.2)])
         assert np.max(np.abs(pr - g[lik + '_pred'])) <= 1e-10 * np.max(np.abs(g[lik + '_pred']))
+
+
+def test_factored_kronecker_algebra_differs_from_literal_order_even_with_the_oracles_own_inverse():
+    """VERDICT r1 item 7 asked for an LU-equivalent inverse so that the engine matches the (LU-based) oracle to 1e-6 on
+    ill-conditioned Kronecker factors.  This test records why no such mode can: evaluate the FACTORED identities (what the engine
+    computes) on the CPU with the oracle's own np.linalg.inv -- the result is as far from the literal dense order
+    (scripts/onoff.py:206-211) as with a Cholesky-based inverse.  The gap is cond(K_p) * eps through a different op order."""
+    import sys
+    import zigp_oracle as o
+    from scipy.linalg import cholesky, solve_triangular
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_kron import make_kron_problem, ELL_T_HARD
+    X, Y, p = make_kron_problem(700, 32, 32, seed=700, ell_t=ELL_T_HARD)
+    ref = o.kron_build_predict(X, p, 1e-5, 0.0)
+
+    def chol_inv(A):
+        W = solve_triangular(cholesky(A, lower=True), np.eye(A.shape[0]), lower=True)
+        return W.T @ W
+
+    def factored(inv, tag):
+        Z, ell, var = p['Z' + tag], p['ell_' + tag], [float(np.squeeze(v)) for v in p['var_' + tag]]
+        P = [inv(o.rbf_K(Z[q], None, ell[q], var[q]) + 1e-5 * np.eye(Z[q].shape[0])) for q in range(2)]
+        k0, k1 = o.rbf_K(Z[0], X[:, :2], ell[0], var[0]), o.rbf_K(Z[1], X[:, 2:], ell[1], var[1])
+        U = p['u_%sm' % tag].reshape(32, 32)
+        return np.einsum('in,ij,jn->n', k0, P[0] @ U @ P[1], k1)
+
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    e_lu = rel(factored(np.linalg.inv, 'f'), ref[3].reshape(-1))
+    e_ch = rel(factored(chol_inv, 'f'), ref[3].reshape(-1))
+    print('factored fmean vs literal oracle: with np.linalg.inv %.2e, with Cholesky %.2e' % (e_lu, e_ch))
+    assert e_lu > 1e-6               # the oracle's own inverse does not reach 1e-6 in factored order either
+    assert e_ch < 3.0 * e_lu         # and Cholesky is in the same accuracy class

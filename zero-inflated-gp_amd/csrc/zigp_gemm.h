@@ -191,12 +191,19 @@ __device__ __forceinline__ void glds_lane_offsets(uint32_t (&off)[16 / WAVES], i
     }
   }
 }
-template <int LAY, int WAVES>
+// BPAD: a k-contiguous B image gets 2 doubles (16 B) of padding in front of every 16-row block.  The four B fragments of a k-step
+// (tn = 0..3) then sit 2064 B apart -- beyond the 2040-B reach of ds_read2_b64 and not a multiple of 512 B (ds_read2st64_b64) --
+// so the compiler must issue them as single ds_read_b64, which take the conflict-free 64-bank path (the paired form reads two
+// 16-lane groups per cycle on a 32-bank mapping: 49 % of the LDS cycles of the rank-N update were bank conflicts).
+#ifndef ZIGP_BPAD
+#define ZIGP_BPAD 1
+#endif
+template <int LAY, int WAVES, bool PAD = false>
 __device__ __forceinline__ void glds_tile(double* tile, const char* __restrict__ base, const uint32_t (&off)[16 / WAVES], int wave) {
 #pragma unroll
   for (int p = 0; p < 16 / WAVES; ++p) {
     const int c = WAVES * p + wave;
-    double* dst = tile + ((LAY == LAY_KCONTIG) ? c * 128 : c * LDMN);
+    double* dst = tile + ((LAY == LAY_KCONTIG) ? c * 128 + (PAD ? (c >> 1) * 2 : 0) : c * LDMN);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (uint64_t)off[p]),
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
@@ -229,6 +236,8 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   constexpr int RW = Shape<WAVES>::RW, TMW = Shape<WAVES>::TMW;
   // the 4-base A map costs 3 VGPRs more: used where the B tile is m/n-contiguous (1 base register), not in the K/K kernels
   constexpr bool A_NEWMAP = (BLAY == LAY_MNCONTIG);
+  constexpr bool B_PAD = (ZIGP_BPAD != 0) && (BLAY == LAY_KCONTIG);
+  static_assert(TILE_DOUBLES >= 128 * 16 + 16, "padded B image must fit the stage");
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS destinations and wave-level skips stay on the SALU
@@ -258,7 +267,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   int b_base[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
-    b_base[ks] = (BLAY == LAY_KCONTIG) ? ((wn * WTN + b_j) * 16 + 2 * (((2 * ks) | (kq >> 1)) ^ kswz<false>(b_j)) + (kq & 1))
+    b_base[ks] = (BLAY == LAY_KCONTIG) ? ((wn * WTN + b_j) * 16 + (B_PAD ? wn * (WTN / 16) * 2 : 0) + 2 * (((2 * ks) | (kq >> 1)) ^ kswz<false>(b_j)) + (kq & 1))
                                        : (kq * LDMN + wn * WTN + b_j + ks * 4 * LDMN);
 
   double acc[TMW][TNW][4];
@@ -286,7 +295,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   auto issue = [&](int it) {
     double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
     glds_tile<ALAY, WAVES>(st, baseA + it * strideA, offA, wave);
-    glds_tile<BLAY, WAVES>(st + TILE_DOUBLES, baseB + it * strideB, offB, wave);
+    glds_tile<BLAY, WAVES, B_PAD>(st + TILE_DOUBLES, baseB + it * strideB, offB, wave);
     if (KSCALE) {   // 16 doubles of the scale vector; every wave issues the same 128 B (uniform vmcnt accounting)
       if (ln < 8)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + kd * it * (BK * 8) + (int64_t)(16 * ln)),
@@ -320,7 +329,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
         const int k = ks * 4 + kq;
         double bf[TNW];
 #pragma unroll
-        for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * 256 : tn * 16)];
+        for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * (B_PAD ? 258 : 256) : tn * 16)];
         if (KSCALE) {
           const double sc = As[2 * TILE_DOUBLES + k];
 #pragma unroll
