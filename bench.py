@@ -53,7 +53,7 @@ def synth(N, M, D, rank=0):
 def csrc_hash():
     """hash of the kernel sources: counter summaries under profiles/ are only quoted when they were collected on this code"""
     from zigp import build as zb
-    return zb.source_hash()
+    return zb.source_hash(zb.DENSE_FILES)
 
 
 def cpu_baseline(X, Y, p, jitter, sample_rows, threads, repeats=3):

@@ -29,7 +29,7 @@ def run_meta():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, 'zero-inflated-gp_amd'))
     from zigp import build as zb
-    return {'csrc_hash': zb.source_hash(), 'M': int(os.environ.get('PMC_M', 1024)), 'chunk': int(os.environ.get('PMC_CHUNK', 32768)),
+    return {'csrc_hash': zb.source_hash(zb.DENSE_FILES), 'M': int(os.environ.get('PMC_M', 1024)), 'chunk': int(os.environ.get('PMC_CHUNK', 32768)),
             'D': int(os.environ.get('PMC_D', 3)), 'rows': int(os.environ.get('ROWS', 262144)),
             'command': 'bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs --profile-steps 0 --no-overlap --rows $ROWS'}
 

@@ -1,0 +1,385 @@
+// Larger Kronecker grids on the fused path: capacity <NB0, NB1> 16-row blocks per factor with NB0 + NB1 <= 8 (the reference's
+// [10, 100] grid, scripts/onoff.py:52-53, is <1, 7>).  Same wave-per-16-points design as the small-grid kernels of zigp_kronf.hip,
+// but a wave cannot keep the 72 accumulator blocks of that grid in registers, so the backward kernel SPILLS its eight per-tile
+// operands (K_p, E_p, A_p, t_p) to a point-major image in global memory (4 KB per point; L2-resident for a minibatch) and
+// k_kfl_accum forms the sums over points, one wave per 16 x 16 output block and point split.
+// Included inside namespace zigp by zigp_kronf.hip.
+
+template <int NB0, int NB1> struct KflTile { double K0[4 * NB0], K1[4 * NB1], A0[4 * NB0], A1[4 * NB1], B0[4 * NB0], C0[4 * NB0]; };
+
+// LDS layout of the fragment images: P0 | P1 | Al | S2 | AlT | S2T, packed by the ACTUAL block counts
+__device__ __forceinline__ KfFrags kfl_stage_frags(double* lds, const KfLat& L, bool with_transposes) {
+  const int nb0 = L.f[0].nb, nb1 = L.f[1].nb;
+  const int n0 = nb0 * nb0 * 256, n1 = nb1 * nb1 * 256, n01 = nb0 * nb1 * 256;
+  double* p = lds;
+  KfFrags F;
+  F.P0 = p; kf_stage_frag(p, L.f[0].PF, n0); p += n0;
+  F.P1 = p; kf_stage_frag(p, L.f[1].PF, n1); p += n1;
+  F.Al = p; kf_stage_frag(p, L.AlF, n01); p += n01;
+  F.S2 = p; kf_stage_frag(p, L.S2F, n01); p += n01;
+  F.AlT = nullptr; F.S2T = nullptr;
+  if (with_transposes) {
+    F.AlT = p; kf_stage_frag(p, L.AlTF, n01); p += n01;
+    F.S2T = p; kf_stage_frag(p, L.S2TF, n01);
+  }
+  __syncthreads();
+  return F;
+}
+
+template <int NB0, int NB1>
+__device__ __forceinline__ void kfl_forward_tile(KflTile<NB0, NB1>& t, const KfLat& L, const KfFrags& F, const double* __restrict__ xrow, bool valid,
+                                                 int g, int slot) {
+  const KfFac &f0 = L.f[0], &f1 = L.f[1];
+  kf_ktile<4 * NB0>(t.K0, f0, xrow, valid, g);
+  kf_ktile<4 * NB1>(t.K1, f1, xrow, valid, g);
+#pragma unroll
+  for (int q = 0; q < 4 * NB0; ++q) { t.A0[q] = 0.0; t.B0[q] = 0.0; t.C0[q] = 0.0; }
+#pragma unroll
+  for (int q = 0; q < 4 * NB1; ++q) t.A1[q] = 0.0;
+  kf_frag_mm<NB0, 4 * NB0>(t.A0, F.P0, f0.nb, 4 * f0.nb, t.K0, slot);
+  kf_frag_mm<NB1, 4 * NB1>(t.A1, F.P1, f1.nb, 4 * f1.nb, t.K1, slot);
+  kf_frag_mm<NB0, 4 * NB1>(t.B0, F.Al, f0.nb, 4 * f1.nb, t.K1, slot);
+  double sq[4 * NB1];
+#pragma unroll
+  for (int q = 0; q < 4 * NB1; ++q) sq[q] = t.A1[q] * t.A1[q];
+  kf_frag_mm<NB0, 4 * NB1>(t.C0, F.S2, f0.nb, 4 * f1.nb, sq, slot);
+}
+
+template <int NB0, int NB1>
+__global__ void __launch_bounds__(64 * KF_WAVES, 1)
+k_kfl_forward(KfArgs a) {
+  extern __shared__ double lds[];
+  const KfLat& L = a.lat[blockIdx.y];
+  const KfFrags F = kfl_stage_frags(lds, L, false);
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
+  const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
+  const int t1 = min((w + 1) * a.tpw, a.ntiles);
+  for (int tile = w * a.tpw; tile < t1; ++tile) {
+    const int64_t pn = (int64_t)tile * 16 + n;
+    const bool valid = pn < a.N;
+    KflTile<NB0, NB1> t;
+    kfl_forward_tile<NB0, NB1>(t, L, F, a.X + (valid ? pn : 0) * a.ldx, valid, g, slot);
+    double q0 = 0.0, q1 = 0.0, mu = 0.0, st = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4 * NB0; ++q) {
+      q0 = fma(t.K0[q], t.A0[q], q0);
+      mu = fma(t.K0[q], t.B0[q], mu);
+      st = fma(t.A0[q] * t.A0[q], t.C0[q], st);
+    }
+#pragma unroll
+    for (int q = 0; q < 4 * NB1; ++q) q1 = fma(t.K1[q], t.A1[q], q1);
+    q0 = kf_colsum(q0); q1 = kf_colsum(q1); mu = kf_colsum(mu); st = kf_colsum(st);
+    if (g == 0) { L.part[pn] = q0; L.part[a.Npad + pn] = q1; L.part[2 * a.Npad + pn] = mu; L.part[3 * a.Npad + pn] = st; }
+  }
+}
+
+// Spill image of one tile quantity V (rows x 16 points), point-major with the rows of every 16-block permuted so that both operand
+// roles of k_kfl_accum read it coalesced:  element (row = 16 rb + 4 r + a, point n)  ->  base[n * Mq + 16 rb + 4 a + r]
+//   A role (lane (a, kk), fragments r = 0..3): ONE 32-byte load at [(4 ks + kk) * Mq + 16 rb + 4 a]
+//   B role (lane (kk, j)):                     [(4 ks + kk) * Mq + 16 cb + 4 (j % 4) + j / 4]
+template <int NB>
+__device__ __forceinline__ void kfl_spill(double* __restrict__ base, const double (&V)[4 * NB], int nb, int Mq, int g, int n) {
+#pragma unroll
+  for (int rb = 0; rb < NB; ++rb)
+    if (rb < nb) *reinterpret_cast<double4*>(base + n * Mq + 16 * rb + 4 * g) = make_double4(V[4 * rb], V[4 * rb + 1], V[4 * rb + 2], V[4 * rb + 3]);
+}
+
+// backward for the larger grids: the per-point reverse pass of k_kf_backward, operands of the sums over points spilled per tile:
+// record = K0 | E0 | A0 | t0 (16 Mq0 doubles each) | K1 | E1 | A1 | t1 (16 Mq1 each)
+template <int NB0, int NB1>
+__global__ void __launch_bounds__(64 * KF_WAVES, 1)
+k_kfl_backward(KfArgs a) {
+  extern __shared__ double lds[];
+  const KfLat& L = a.lat[blockIdx.y];
+  const KfFac &f0 = L.f[0], &f1 = L.f[1];
+  const KfFrags F = kfl_stage_frags(lds, L, true);
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
+  const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
+  const int Mq0 = 16 * f0.nb, Mq1 = 16 * f1.nb;
+  const int64_t rec = 64 * (int64_t)(Mq0 + Mq1);
+  const int t1 = min((w + 1) * a.tpw, a.ntiles);
+  for (int tile = w * a.tpw; tile < t1; ++tile) {
+    const int64_t pn = (int64_t)tile * 16 + n;
+    const bool valid = pn < a.N;
+    const double* xrow = a.X + (valid ? pn : 0) * a.ldx;
+    KflTile<NB0, NB1> t;
+    kfl_forward_tile<NB0, NB1>(t, L, F, xrow, valid, g, slot);
+    const double gmn = L.gm[pn], gvn = L.gv[pn], dq0n = L.dq0[pn], dq1n = L.dq1[pn];
+    double* R = L.spill + (int64_t)tile * rec;
+    double* R1 = R + 64 * Mq0;
+    kfl_spill<NB0>(R, t.K0, f0.nb, Mq0, g, n);
+    kfl_spill<NB1>(R1, t.K1, f1.nb, Mq1, g, n);
+    kfl_spill<NB0>(R + 32 * Mq0, t.A0, f0.nb, Mq0, g, n);
+    kfl_spill<NB1>(R1 + 32 * Mq1, t.A1, f1.nb, Mq1, g, n);
+    {   // factor 0: B0, C0 are part of the forward tile
+      double dA[4 * NB0], PdA[4 * NB0], E[4 * NB0];
+#pragma unroll
+      for (int q = 0; q < 4 * NB0; ++q) { dA[q] = 2.0 * gvn * t.A0[q] * t.C0[q]; PdA[q] = 0.0; E[q] = fma(dq0n, t.K0[q], dA[q]); }
+      kfl_spill<NB0>(R + 16 * Mq0, E, f0.nb, Mq0, g, n);
+      kf_frag_mm<NB0, 4 * NB0>(PdA, F.P0, f0.nb, 4 * f0.nb, dA, slot);
+#pragma unroll
+      for (int q = 0; q < 4 * NB0; ++q) E[q] = fma(gmn, t.B0[q], fma(2.0 * dq0n, t.A0[q], PdA[q])) * t.K0[q];
+      kfl_spill<NB0>(R + 48 * Mq0, E, f0.nb, Mq0, g, n);
+    }
+    {   // factor 1: B1 = Alpha^T K0, C1 = S2^T A0^2
+      double B1[4 * NB1], C1[4 * NB1], sq[4 * NB0];
+#pragma unroll
+      for (int q = 0; q < 4 * NB1; ++q) { B1[q] = 0.0; C1[q] = 0.0; }
+#pragma unroll
+      for (int q = 0; q < 4 * NB0; ++q) sq[q] = t.A0[q] * t.A0[q];
+      kf_frag_mm<NB1, 4 * NB0>(B1, F.AlT, f1.nb, 4 * f0.nb, t.K0, slot);
+      kf_frag_mm<NB1, 4 * NB0>(C1, F.S2T, f1.nb, 4 * f0.nb, sq, slot);
+      double PdA[4 * NB1];
+#pragma unroll
+      for (int q = 0; q < 4 * NB1; ++q) { C1[q] = 2.0 * gvn * t.A1[q] * C1[q]; PdA[q] = 0.0; }       // C1 <- dA1
+      kf_frag_mm<NB1, 4 * NB1>(PdA, F.P1, f1.nb, 4 * f1.nb, C1, slot);
+#pragma unroll
+      for (int q = 0; q < 4 * NB1; ++q) {
+        PdA[q] = fma(gmn, B1[q], fma(2.0 * dq1n, t.A1[q], PdA[q])) * t.K1[q];                          // PdA <- t1
+        C1[q] = fma(dq1n, t.K1[q], C1[q]);                                                             // C1 <- E1
+      }
+      kfl_spill<NB1>(R1 + 16 * Mq1, C1, f1.nb, Mq1, g, n);
+      kfl_spill<NB1>(R1 + 48 * Mq1, PdA, f1.nb, Mq1, g, n);
+    }
+  }
+}
+
+// block numbering shared by the accumulators of every variant (capacities nb0c, nb1c): Al | S2 (nb0c x nb1c each) | P0 | P1 | K0 | K1
+struct KfBlock { int kind, rb, cb; };   // kind 0 Al, 1 S2, 2 P0, 3 P1, 4 moments of factor 0, 5 of factor 1
+__device__ __forceinline__ KfBlock kf_block_decode(int blk, int nb0c, int nb1c) {
+  KfBlock b;
+  const int n01 = nb0c * nb1c;
+  if (blk < n01) { b.kind = 0; b.rb = blk / nb1c; b.cb = blk % nb1c; return b; }
+  blk -= n01;
+  if (blk < n01) { b.kind = 1; b.rb = blk / nb1c; b.cb = blk % nb1c; return b; }
+  blk -= n01;
+  if (blk < nb0c * nb0c) { b.kind = 2; b.rb = blk / nb0c; b.cb = blk % nb0c; return b; }
+  blk -= nb0c * nb0c;
+  if (blk < nb1c * nb1c) { b.kind = 3; b.rb = blk / nb1c; b.cb = blk % nb1c; return b; }
+  blk -= nb1c * nb1c;
+  if (blk < nb0c) { b.kind = 4; b.rb = blk; b.cb = 0; return b; }
+  b.kind = 5; b.rb = blk - nb0c; b.cb = 0;
+  return b;
+}
+__host__ __device__ inline int kf_nblocks(int nb0c, int nb1c) { return 2 * nb0c * nb1c + nb0c * nb0c + nb1c * nb1c + nb0c + nb1c; }
+
+struct KflAccLat { const double* spill; const double *gm, *gv; double* acc; int nb0, nb1, D0, D1; double zc0[MAXD], zc1[MAXD]; };
+struct KflAccArgs { KflAccLat lat[2]; const double* X; int64_t N; int ldx, ntiles, tps, nb0c, nb1c; };
+
+// sums over points for the larger grids: wave = one 16 x 16 output block over the tiles of one split
+//   dAlpha += K0 diag(gm) K1^T ; dS2 += A0^2 diag(gv) (A1^2)^T ; dP_p += E_p K_p^T ; moments_p += t_p Psi_p
+__global__ void __launch_bounds__(256)
+k_kfl_accum(KflAccArgs a) {
+  const KflAccLat& L = a.lat[blockIdx.z];
+  const int lane = threadIdx.x & 63, ai = lane & 3, kk = lane >> 4, bj = lane & 15;
+  const int nblk = kf_nblocks(a.nb0c, a.nb1c);
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= nblk) return;
+  const KfBlock b = kf_block_decode(blk, a.nb0c, a.nb1c);
+  const int Mq0 = 16 * L.nb0, Mq1 = 16 * L.nb1;
+  const int64_t rec = 64 * (int64_t)(Mq0 + Mq1);
+  // operand images inside a tile record, and the block counts that bound (rb, cb)
+  int offA, MqA, offB, MqB, nbr, nbc;
+  switch (b.kind) {
+    case 0: offA = 0; MqA = Mq0; offB = 64 * Mq0; MqB = Mq1; nbr = L.nb0; nbc = L.nb1; break;                         // K0 , K1 gm
+    case 1: offA = 32 * Mq0; MqA = Mq0; offB = 64 * Mq0 + 32 * Mq1; MqB = Mq1; nbr = L.nb0; nbc = L.nb1; break;       // A0^2 , A1^2 gv
+    case 2: offA = 16 * Mq0; MqA = Mq0; offB = 0; MqB = Mq0; nbr = L.nb0; nbc = L.nb0; break;                         // E0 , K0
+    case 3: offA = 64 * Mq0 + 16 * Mq1; MqA = Mq1; offB = 64 * Mq0; MqB = Mq1; nbr = L.nb1; nbc = L.nb1; break;       // E1 , K1
+    case 4: offA = 48 * Mq0; MqA = Mq0; offB = 0; MqB = 0; nbr = L.nb0; nbc = 1; break;                               // t0 , Psi_0
+    default: offA = 64 * Mq0 + 48 * Mq1; MqA = Mq1; offB = 0; MqB = 0; nbr = L.nb1; nbc = 1; break;                   // t1 , Psi_1
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (b.rb < nbr && b.cb < nbc) {
+    const int D = b.kind == 4 ? L.D0 : L.D1, col0 = b.kind == 4 ? 0 : L.D0;
+    const double* zc = b.kind == 4 ? L.zc0 : L.zc1;
+    const int psi_d = (bj == 0) ? -1 : ((bj <= D) ? bj - 1 : ((bj <= 2 * D) ? bj - 1 - D : -2));   // -1: constant 1, -2: 0
+    const int t0 = blockIdx.y * a.tps, t1 = min(t0 + a.tps, a.ntiles);
+    const int oa = 16 * b.rb + 4 * ai, ob = 16 * b.cb + 4 * (bj & 3) + (bj >> 2);
+#pragma unroll 2
+    for (int tile = t0; tile < t1; ++tile) {
+      const double* R = L.spill + (int64_t)tile * rec;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int pt = 4 * ks + kk;
+        const int64_t pn = (int64_t)tile * 16 + pt;
+        double4 av = *reinterpret_cast<const double4*>(R + offA + pt * MqA + oa);
+        double bv;
+        if (b.kind <= 3) {
+          bv = R[offB + pt * MqB + ob];
+          if (b.kind == 0) bv *= L.gm[pn];
+          if (b.kind == 1) { bv = bv * bv * L.gv[pn]; av.x *= av.x; av.y *= av.y; av.z *= av.z; av.w *= av.w; }
+        } else {
+          bv = 0.0;
+          if (pn < a.N) {
+            if (psi_d == -1) bv = 1.0;
+            else if (psi_d >= 0) { const double xv = a.X[pn * a.ldx + col0 + psi_d] - zc[psi_d]; bv = (bj <= D) ? xv : xv * xv; }
+          }
+        }
+        acc[0] = kf_mfma(av.x, bv, acc[0]); acc[1] = kf_mfma(av.y, bv, acc[1]);
+        acc[2] = kf_mfma(av.z, bv, acc[2]); acc[3] = kf_mfma(av.w, bv, acc[3]);
+      }
+    }
+  }
+  double* out = L.acc + ((int64_t)blockIdx.y * nblk + blk) * 256;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[r * 64 + lane] = acc[r];
+}
+
+// ---- M x M stages with operands in global memory (L2 resident): the LDS-resident kernels of zigp_kronf.hip hold 32 x 32 matrices ----
+// C (m x n) [+]= op(A) (m x k) op(B) (k x n); m, k multiples of 4.  A thread owns a 4 x 1 micro-tile (rows i0..i0+3, column j) and
+// unrolls k by 4: 20 independent loads per step keep the memory pipe busy (the naive loop is one L2 round trip per FMA).
+template <bool TA, bool TB, bool ACC>
+__device__ __forceinline__ void kf_gmm(double* C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, int m, int n,
+                                       int k) {
+  const int mt = m >> 2;
+  for (int idx = threadIdx.x; idx < mt * n; idx += blockDim.x) {
+    const int it = idx / n, j = idx - it * n, i0 = 4 * it;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int q0 = 0; q0 < k; q0 += 4) {
+      double av[4][4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u;
+        bv[u] = TB ? B[j * ldb + q] : B[q * ldb + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r][u] = TA ? A[q * lda + i0 + r] : A[(i0 + r) * lda + q];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fma(av[r][u], bv[u], v[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { double* c = C + (i0 + r) * ldc + j; *c = ACC ? *c + v[r] : v[r]; }
+  }
+}
+
+// global-operand twin of k_kf_latent (same job structure)
+__global__ void __launch_bounds__(1024)
+k_kfl_latent(KfLatentArgs a) {
+  __shared__ double sh[16];
+  const KfLatentJob& jb = a.job[blockIdx.x];
+  const int t = threadIdx.x, M0 = jb.M0, M1 = jb.M1, Mq0 = jb.Mq0, Mq1 = jb.Mq1;
+  for (int idx = t; idx < Mq0 * Mq1; idx += 1024) {
+    const int i = idx / Mq1, j = idx - i * Mq1;
+    const bool in = i < M0 && j < M1;
+    const double sv = in ? jb.s[i * M1 + j] : 0.0;
+    jb.U[idx] = in ? jb.u[i * M1 + j] : 0.0;
+    jb.S2[idx] = sv * sv;
+  }
+  __syncthreads();
+  kf_gmm<false, false, false>(jb.T0, Mq1, jb.U, Mq1, jb.P1, Mq1, Mq0, Mq1, Mq1);      // T0 = U P1
+  kf_gmm<false, false, false>(jb.T1, Mq1, jb.P0, Mq0, jb.U, Mq1, Mq0, Mq1, Mq0);      // T1 = P0 U
+  __syncthreads();
+  kf_gmm<false, false, false>(jb.Al, Mq1, jb.P0, Mq0, jb.T0, Mq1, Mq0, Mq1, Mq0);     // Alpha = P0 (U P1)
+  __syncthreads();
+  kf_write_frag(jb.AlF, Mq0 / 16, Mq1 / 4, t, 1024, jb.Al, Mq1, false);
+  kf_write_frag(jb.S2F, Mq0 / 16, Mq1 / 4, t, 1024, jb.S2, Mq1, false);
+  kf_write_frag(jb.AlTF, Mq1 / 16, Mq0 / 4, t, 1024, jb.Al, Mq1, true);
+  kf_write_frag(jb.S2TF, Mq1 / 16, Mq0 / 4, t, 1024, jb.S2, Mq1, true);
+  double av = 0.0, bv = 0.0, cv = 0.0;
+  for (int idx = t; idx < M0 * M1; idx += 1024) {
+    const int i = idx / M1, j = idx - i * M1;
+    const int64_t o = (int64_t)i * Mq1 + j;
+    const double sv = jb.s[idx];
+    av = fma(jb.U[o], jb.Al[o], av);
+    bv += log(sv * sv);
+    cv = fma(jb.dvec0[i] * jb.dvec1[j], sv * sv, cv);
+  }
+  double vals[3] = {av, bv, cv};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    double v = wave_sum(vals[q]);
+    __syncthreads();
+    if ((t & 63) == 0) sh[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) { double r = 0.0; for (int w = 0; w < 16; ++w) r += sh[w]; jb.klv[q] = r; }
+  }
+  if (t == 0) { jb.klv[3] = jb.dvec0[Mq0]; jb.klv[4] = jb.dvec1[Mq1]; }
+}
+
+// global-operand twin of k_kf_finish: grid (2, latents); work matrices have leading dimension ldw, scratch behind them
+struct KflFinishArgs { KfFinishJob job[2]; double jitter; int with_kl; int ldw, wS2, wP0, wP1, wK0, wK1; int64_t scratch_off, scratch_set; };
+
+__global__ void __launch_bounds__(1024)
+k_kfl_finish(KflFinishArgs a) {
+  const KfFinishJob& jb = a.job[blockIdx.y];
+  const int p = blockIdx.x;
+  const int t = threadIdx.x, M0 = jb.M0, M1 = jb.M1, Mq0 = jb.Mq0, Mq1 = jb.Mq1, ldw = a.ldw;
+  const bool kl = a.with_kl != 0;
+  const int M = p == 0 ? M0 : M1, Mq = p == 0 ? Mq0 : Mq1, Mo = p == 0 ? M1 : M0, D = p == 0 ? jb.D0 : jb.D1;
+  const double* Z = p == 0 ? jb.Z0 : jb.Z1;
+  const double* zc = p == 0 ? jb.zc0 : jb.zc1;
+  const double* P = p == 0 ? jb.P0 : jb.P1;
+  const double* Kuu = p == 0 ? jb.K0 : jb.K1;
+  double* work = const_cast<double*>(jb.work);
+  const double* dAl = work;
+  double* dP = work + (p == 0 ? a.wP0 : a.wP1);
+  const double* Kr = work + (p == 0 ? a.wK0 : a.wK1);
+  double* krow = p == 0 ? jb.krow0 : jb.krow1;
+  double* X = work + a.scratch_off + (int64_t)p * a.scratch_set;     // this workgroup's scratch: X, G, Q (ldw x ldw each), dU
+  double* G = X + (int64_t)ldw * ldw; double* Q = G + (int64_t)ldw * ldw; double* dU = Q + (int64_t)ldw * ldw;
+  if (p == 0) {
+    kf_gmm<false, false, false>(X, ldw, dAl, ldw, jb.P1, Mq1, Mq0, Mq1, Mq1);        // X = dAl P1
+    kf_gmm<false, true, true>(dP, ldw, dAl, ldw, jb.T0, Mq1, Mq0, Mq0, Mq1);         // dP0 += dAl T0^T
+    if (kl) kf_gmm<false, true, false>(Q, ldw, jb.T0, Mq1, jb.U, Mq1, Mq0, Mq0, Mq1);   // Q0 = T0 U^T
+    __syncthreads();
+    kf_gmm<false, false, false>(dU, ldw, jb.P0, Mq0, X, ldw, Mq0, Mq1, Mq0);         // dU = P0 X
+    __syncthreads();
+    for (int idx = t; idx < M0 * M1; idx += 1024) {
+      const int i = idx / M1, j = idx - i * M1;
+      const double sv = jb.s[idx];
+      double gu = dU[i * ldw + j], gs = 2.0 * sv * work[a.wS2 + i * ldw + j];
+      if (kl) { gu -= jb.Al[i * Mq1 + j]; gs -= (-1.0 / sv + jb.dvec0[i] * jb.dvec1[j] * sv); }
+      jb.gu[idx] = gu; jb.gs[idx] = gs;
+    }
+  } else {
+    kf_gmm<true, false, true>(dP, ldw, jb.T1, Mq1, dAl, ldw, Mq1, Mq1, Mq0);         // dP1 += T1^T dAl
+    if (kl) kf_gmm<true, false, false>(Q, ldw, jb.U, Mq1, jb.T1, Mq1, Mq1, Mq1, Mq0);   // Q1 = U^T T1
+  }
+  __syncthreads();
+  for (int idx = t; idx < Mq * Mq; idx += 1024) {       // X = sym(dP) [- kl pieces]
+    const int i = idx / Mq, j = idx - i * Mq;
+    double v = 0.5 * (dP[i * ldw + j] + dP[j * ldw + i]);
+    if (kl) {
+      v -= 0.25 * (Q[i * ldw + j] + Q[j * ldw + i]);
+      if (i == j) {
+        double w = 0.0;
+        if (p == 0) { for (int o = 0; o < M1; ++o) w = fma(jb.dvec1[o], jb.S2[i * Mq1 + o], w); }
+        else { for (int o = 0; o < M0; ++o) w = fma(jb.dvec0[o], jb.S2[o * Mq1 + i], w); }
+        v -= 0.5 * w;
+      }
+    }
+    X[i * ldw + j] = v;
+  }
+  __syncthreads();
+  kf_gmm<false, false, false>(Q, ldw, X, ldw, P, Mq, Mq, Mq, Mq);                    // Q = sym(dP) P
+  __syncthreads();
+  kf_gmm<false, false, false>(G, ldw, P, Mq, Q, ldw, Mq, Mq, Mq);                    // G = P Q   (sign and KL term below)
+  __syncthreads();
+  const double coef = kl ? 0.5 * (double)Mo : 0.0;
+  const int W = 2 + 2 * D;
+  for (int idx = t; idx < M * W; idx += 1024) {
+    const int m = idx / W, c = idx - m * W;
+    double v = 0.0;
+    if (c <= 2 * D) {
+      const int d = (c == 0) ? 0 : (c - 1) % D;
+      const double zm = Z[m * D + d];
+#pragma unroll 4
+      for (int j = 0; j < M; ++j) {
+        const double kz = Kuu[m * PB + j] - ((m == j) ? a.jitter : 0.0);
+        const double tt = (-G[m * ldw + j] - coef * P[m * Mq + j]) * kz;
+        const double df = Z[j * D + d] - zm;
+        v += (c == 0) ? tt : ((c <= D) ? 2.0 * tt * df : tt * df * df);
+      }
+      const double s0 = Kr[m * 16];
+      if (c == 0) v += s0;
+      else {
+        const double dz = zm - zc[d], s1 = Kr[m * 16 + 1 + d];
+        if (c <= D) v += s1 - dz * s0;
+        else v += Kr[m * 16 + 1 + D + d] - 2.0 * dz * s1 + dz * dz * s0;
+      }
+    }
+    krow[idx] = v;
+  }
+}

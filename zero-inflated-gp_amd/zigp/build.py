@@ -14,11 +14,15 @@ HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(('.h', '.hip')) and f
 HASHFILE = LIB + '.srchash'
 
 
-def source_hash():
-    """sha256 over every file the library is built from (file mtimes do not survive a snapshot copy; contents do)"""
+DENSE_FILES = ['zigp_gemm.h', 'zigp_kernels.h', 'zigp_host.h', 'zigp_ctx.h', 'zigp_dense.hip']   # what the cfg3 step's kernels are built from
+
+
+def source_hash(files=None):
+    """sha256 over every file the library is built from (file mtimes do not survive a snapshot copy; contents do);
+    files=DENSE_FILES: the dense path only (provenance of the counter summaries under profiles/)"""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(SOURCES + HEADERS):
+    for f in sorted(files if files is not None else SOURCES + HEADERS):
         p = os.path.join(CSRC, f)
         if os.path.exists(p):
             h.update(f.encode())
