@@ -8,7 +8,7 @@ from test_gpu_kron import make_kron_problem
 
 pytestmark = pytest.mark.gpu
 
-CASES = [(200, 6, 5), (1000, 10, 12), (700, 32, 32)]
+CASES = [(200, 6, 5), (1000, 10, 12), (700, 32, 32), (600, 10, 100)]   # the last one: the reference's [10, 100] grid (larger-grid kernels)
 
 
 def _head_problem(N, M0, M1, lik, seed):

@@ -128,7 +128,7 @@ def test_kron_predict_matches_literal_oracle(engine, N, M0, M1, M0g, M1g, HARD):
                 assert e_gpu < max(1e-6, 10 * e_orc), (tag, nm, e_gpu, e_orc)
 
 
-@pytest.mark.parametrize('N,M0,M1,M0g,M1g', CASES[:3])
+@pytest.mark.parametrize('N,M0,M1,M0g,M1g', CASES[:3] + [(600, 10, 100, None, None), (500, 16, 112, 9, 50)])
 def test_kron_elbo_and_gradient_match_literal_oracle(engine, N, M0, M1, M0g, M1g):
     import zigp_oracle_torch as ot
     X, Y, p = make_kron_problem(N, M0, M1, seed=N + 1, M0g=M0g, M1g=M1g)

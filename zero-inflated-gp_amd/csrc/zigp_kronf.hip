@@ -38,6 +38,7 @@ struct KfLat {
   double* part;                 // [4][Npad]: q0, q1, mean, S-term
   const double *gm, *gv, *dq0, *dq1;   // [Npad] cotangents from the point-wise kernel
   double* acc;                  // [waves][KF_ACC_BLOCKS][4][64] per-wave partial sums
+  double* spill;                // larger grids: per-tile operand records of the sums over points (zigp_kronl.h)
   double knn;
 };
 struct KfArgs {
@@ -365,22 +366,52 @@ k_kf_backward(KfArgs a) {
     }
 }
 
-// ---- fixed-order sum of the per-wave partials; un-permutes the accumulator layout into row-major matrices ---------------------
-// work layout per latent (doubles): dAl [32][32], dS2 [32][32], dP0 [32][32], dP1 [32][32], Kr0 [32][16], Kr1 [32][16]   (32 = 16 KF_NBMAX)
+// ---- fixed-order sum of the partial accumulators; un-permutes the accumulator layout into row-major matrices ------------------
+// block numbering shared by the accumulators of every variant (capacities nb0c, nb1c): Al | S2 (nb0c x nb1c each) | P0 | P1 | K0 | K1
+struct KfBlock { int kind, rb, cb; };   // kind 0 Al, 1 S2, 2 P0, 3 P1, 4 moments of factor 0, 5 of factor 1
+__device__ __forceinline__ KfBlock kf_block_decode(int blk, int nb0c, int nb1c) {
+  KfBlock b;
+  const int n01 = nb0c * nb1c;
+  if (blk < n01) { b.kind = 0; b.rb = blk / nb1c; b.cb = blk % nb1c; return b; }
+  blk -= n01;
+  if (blk < n01) { b.kind = 1; b.rb = blk / nb1c; b.cb = blk % nb1c; return b; }
+  blk -= n01;
+  if (blk < nb0c * nb0c) { b.kind = 2; b.rb = blk / nb0c; b.cb = blk % nb0c; return b; }
+  blk -= nb0c * nb0c;
+  if (blk < nb1c * nb1c) { b.kind = 3; b.rb = blk / nb1c; b.cb = blk % nb1c; return b; }
+  blk -= nb1c * nb1c;
+  if (blk < nb0c) { b.kind = 4; b.rb = blk; b.cb = 0; return b; }
+  b.kind = 5; b.rb = blk - nb0c; b.cb = 0;
+  return b;
+}
+__host__ __device__ inline int kf_nblocks(int nb0c, int nb1c) { return 2 * nb0c * nb1c + nb0c * nb0c + nb1c * nb1c + nb0c + nb1c; }
+
+// work layout per latent (doubles), R_p = 16 nb_p capacity rows, ldw = max(R0, R1):
+//   dAl [R0][ldw] | dS2 [R0][ldw] | dP0 [R0][ldw] | dP1 [R1][ldw] | Kr0 [R0][16] | Kr1 [R1][16]
+struct KfWork { int ldw, S2, P0, P1, K0, K1, total; };
+__host__ __device__ inline KfWork kf_work_layout(int nb0c, int nb1c) {
+  KfWork w;
+  const int R0 = 16 * nb0c, R1 = 16 * nb1c;
+  w.ldw = R0 > R1 ? R0 : R1;
+  w.S2 = R0 * w.ldw; w.P0 = 2 * R0 * w.ldw; w.P1 = 3 * R0 * w.ldw; w.K0 = w.P1 + R1 * w.ldw; w.K1 = w.K0 + R0 * 16; w.total = w.K1 + R1 * 16;
+  return w;
+}
 constexpr int KF_MQ = 16 * KF_NBMAX;
 constexpr int KF_W_AL = 0, KF_W_S2 = KF_MQ * KF_MQ, KF_W_P0 = 2 * KF_MQ * KF_MQ, KF_W_P1 = 3 * KF_MQ * KF_MQ, KF_W_K0 = 4 * KF_MQ * KF_MQ,
-              KF_W_K1 = KF_W_K0 + KF_MQ * 16, KF_W_TOTAL = KF_W_K1 + KF_MQ * 16;
+              KF_W_K1 = KF_W_K0 + KF_MQ * 16, KF_W_TOTAL = KF_W_K1 + KF_MQ * 16;   // = kf_work_layout(KF_NBMAX, KF_NBMAX)
 constexpr int KF_RED_GROUPS = 16;
 __global__ void __launch_bounds__(256)
-k_kf_reduce(const double* __restrict__ acc0, const double* __restrict__ acc1, int nwaves, double* __restrict__ work0, double* __restrict__ work1) {
+k_kf_reduce(const double* __restrict__ acc0, const double* __restrict__ acc1, int nparts, double* __restrict__ work0, double* __restrict__ work1,
+            int nb0c, int nb1c) {
   __shared__ double sh[KF_RED_GROUPS][16];
   const double* acc = blockIdx.y == 0 ? acc0 : acc1;
   double* work = blockIdx.y == 0 ? work0 : work1;
+  const int64_t accd = (int64_t)kf_nblocks(nb0c, nb1c) * 256;
   const int e = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
-  const int per = (nwaves + KF_RED_GROUPS - 1) / KF_RED_GROUPS;
-  const int w0 = grp * per, w1 = min(w0 + per, nwaves);
+  const int per = (nparts + KF_RED_GROUPS - 1) / KF_RED_GROUPS;
+  const int w0 = grp * per, w1 = min(w0 + per, nparts);
   double s = 0.0;
-  for (int w = w0; w < w1; ++w) s += acc[(int64_t)w * KF_ACC_DOUBLES + e];
+  for (int w = w0; w < w1; ++w) s += acc[(int64_t)w * accd + e];
   sh[grp][threadIdx.x & 15] = s;
   __syncthreads();
   if (grp != 0) return;
@@ -390,15 +421,11 @@ k_kf_reduce(const double* __restrict__ acc0, const double* __restrict__ acc1, in
   // e = (block * 4 + r) * 64 + lane  ->  element (16 rb + 4 r + lane / 16, 16 cb + lane % 16) of its matrix
   const int lane = e & 63, r = (e >> 6) & 3, blk = e >> 8;
   const int ri = 4 * r + (lane >> 4), cj = lane & 15;
-  int base, rb, cb, ld;
-  if (blk < KF_B_K0) {
-    const int which = blk / (KF_NBMAX * KF_NBMAX), b = blk % (KF_NBMAX * KF_NBMAX);
-    base = which * KF_MQ * KF_MQ; rb = b / KF_NBMAX; cb = b % KF_NBMAX; ld = KF_MQ;
-  } else {
-    const int b = blk - KF_B_K0;
-    base = (b < KF_NBMAX) ? KF_W_K0 : KF_W_K1; rb = b % KF_NBMAX; cb = 0; ld = 16;
-  }
-  work[base + (16 * rb + ri) * ld + 16 * cb + cj] = tot;
+  const KfBlock b = kf_block_decode(blk, nb0c, nb1c);
+  const KfWork w = kf_work_layout(nb0c, nb1c);
+  const int base = b.kind == 0 ? 0 : b.kind == 1 ? w.S2 : b.kind == 2 ? w.P0 : b.kind == 3 ? w.P1 : b.kind == 4 ? w.K0 : w.K1;
+  const int ld = b.kind <= 3 ? w.ldw : 16;
+  work[base + (16 * b.rb + ri) * ld + 16 * b.cb + cj] = tot;
 }
 
 // =============================================================================================================================
@@ -680,46 +707,45 @@ k_kf_finish(KfFinishArgs a) {
 
 namespace zigp {
 
+#include "zigp_kronl.h"
+
 // =============================================================================================================================
 // host orchestration
 // =============================================================================================================================
 constexpr size_t KF_BWD_LDS = sizeof(double) * (KF_WAVES * 4 * 16 * KF_NBMAX * KF_LD + 6 * KF_FRAG);
 struct KfState {
-  DevBuf in, mat, pts, acc, res, out;
+  DevBuf in, mat, pts, acc, res, out, spill;
 };
 static void kf_free(KfState* k) {
-  DevBuf* bs[] = {&k->in, &k->mat, &k->pts, &k->acc, &k->res, &k->out};
+  DevBuf* bs[] = {&k->in, &k->mat, &k->pts, &k->acc, &k->res, &k->out, &k->spill};
   for (DevBuf* b : bs) b->release();
   delete k;
 }
 
-// the register-resident kernels cover factors of up to 16 KF_NBMAX inducing points and 7 input columns (1 + 2 D moment columns <= 16)
-static bool kf_eligible(const zigp_kron_params* p, int nlat) {
-  const int lim = 16 * KF_NBMAX;
-  if (p->D0 > 7 || p->D1 > 7) return false;
-  if (p->M0f > lim || p->M1f > lim) return false;
-  if (nlat == 2 && (p->M0g > lim || p->M1g > lim)) return false;
-  return true;
+// Variants of the point-stage kernels by capacity (16-row blocks per factor):
+//   small  <2, 2>  accumulators in registers (grids up to 32 x 32: BASELINE cfg5)
+//   large  <1, 7>  operands spilled per tile, k_kfl_accum (the reference's [10, 100] grid, scripts/onoff.py:52-53)
+// anything else (and more than 7 input columns per factor: 1 + 2 D moment columns <= 16) takes the GEMM-panel path of zigp_kron.hip.
+struct KfPlan { bool ok, large; int nb0c, nb1c; };
+static KfPlan kf_plan(const zigp_kron_params* p, int nlat) {
+  KfPlan pl = {false, false, 0, 0};
+  if (p->D0 > 7 || p->D1 > 7) return pl;
+  const int m0 = std::max(p->M0f, nlat == 2 ? p->M0g : 0), m1 = std::max(p->M1f, nlat == 2 ? p->M1g : 0);
+  if (m0 <= 16 * KF_NBMAX && m1 <= 16 * KF_NBMAX) { pl.ok = true; pl.nb0c = KF_NBMAX; pl.nb1c = KF_NBMAX; return pl; }
+  if (m0 <= 16 && m1 <= 112) { pl.ok = true; pl.large = true; pl.nb0c = 1; pl.nb1c = 7; return pl; }
+  return pl;
 }
+static bool kf_eligible(const zigp_kron_params* p, int nlat) { return kf_plan(p, nlat).ok; }
 
 struct KfHostLatent { int M[2]; const double* Z[2]; const double* ell[2]; double var[2]; const double* u; const double* s; };
-
-// per-factor / per-latent regions of KfState::mat (doubles)
-constexpr size_t KF_FAC_K = 0, KF_FAC_P = (size_t)PB * PB, KF_FAC_PF = KF_FAC_P + KF_MQ * KF_MQ, KF_FAC_DV = KF_FAC_PF + KF_MQ * KF_MQ,
-                 KF_FAC_SIZE = KF_FAC_DV + KF_MQ + 8;
-constexpr size_t KF_LAT_U = 0, KF_LAT_S2 = 1 * KF_MQ * KF_MQ, KF_LAT_T0 = 2 * KF_MQ * KF_MQ, KF_LAT_T1 = 3 * KF_MQ * KF_MQ, KF_LAT_AL = 4 * KF_MQ * KF_MQ,
-                 KF_LAT_ALF = 5 * KF_MQ * KF_MQ, KF_LAT_S2F = 6 * KF_MQ * KF_MQ, KF_LAT_ALTF = 7 * KF_MQ * KF_MQ, KF_LAT_S2TF = 8 * KF_MQ * KF_MQ,
-                 KF_LAT_KLV = 9 * KF_MQ * KF_MQ, KF_LAT_WORK = KF_LAT_KLV + 8, KF_LAT_SIZE = KF_LAT_WORK + KF_W_TOTAL + 4 * KF_MQ * KF_MQ;
-// per-latent region of KfState::res
 constexpr int KF_KROW_W = 2 + 2 * MAXD;
-constexpr size_t KF_RES_KLV = 0, KF_RES_KROW0 = 8, KF_RES_KROW1 = KF_RES_KROW0 + KF_MQ * KF_KROW_W, KF_RES_GU = KF_RES_KROW1 + KF_MQ * KF_KROW_W,
-                 KF_RES_GS = KF_RES_GU + KF_MQ * KF_MQ, KF_RES_SIZE = KF_RES_GS + KF_MQ * KF_MQ;
 
 static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
                      double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
                      int lik, double* d_offset, bool dev_xy) {
   // dev_xy: X / Y are DEVICE pointers into the resident data set (zigp_set_data): nothing but the parameters is staged
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;
+  const KfPlan pl = kf_plan(p, nlat);
   if (!c->kronf) { c->kronf = new (std::nothrow) KfState(); c->kronf_free = kf_free; if (!c->kronf) { c->err = "out of memory"; return ZIGP_EHIP; } }
   KfState& ks = *c->kronf;
   ZIGP_TRY(begin_staged_call(c));
@@ -729,6 +755,18 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   KfHostLatent hl[2] = {{{p->M0f, p->M1f}, {p->Z0f, p->Z1f}, {p->ell0f, p->ell1f}, {p->var0f, p->var1f}, p->u_fm, p->u_fs_sqrt},
                         {{p->M0g, p->M1g}, {p->Z0g, p->Z1g}, {p->ell0g, p->ell1g}, {p->var0g, p->var1g}, p->u_gm, p->u_gs_sqrt}};
   if (nlat == 1) hl[1] = hl[0];
+  // ---- sizes of this variant
+  const int R0 = 16 * pl.nb0c, R1 = 16 * pl.nb1c;
+  const KfWork wl = kf_work_layout(pl.nb0c, pl.nb1c);
+  const int nblk = kf_nblocks(pl.nb0c, pl.nb1c);
+  const size_t r01 = (size_t)R0 * R1;
+  // per-factor region of KfState::mat: K [128][128] | P | PF | dvec ; per-latent: U S2 T0 T1 Al | AlF S2F AlTF S2TF | work | scratch
+  const size_t rmax = (size_t)wl.ldw * wl.ldw;
+  const size_t FAC_P = (size_t)PB * PB, FAC_PF = FAC_P + rmax, FAC_DV = FAC_PF + rmax, FAC_SIZE = FAC_DV + wl.ldw + 8;
+  const size_t LAT_U = 0, LAT_S2 = r01, LAT_T0 = 2 * r01, LAT_T1 = 3 * r01, LAT_AL = 4 * r01, LAT_ALF = 5 * r01, LAT_S2F = 6 * r01, LAT_ALTF = 7 * r01,
+               LAT_S2TF = 8 * r01, LAT_WORK = 9 * r01, LAT_SCR = LAT_WORK + wl.total, SCR_SET = 3 * rmax + r01, LAT_SIZE = LAT_SCR + 2 * SCR_SET;
+  const size_t RES_KLV = 0, RES_KROW0 = 8, RES_KROW1 = RES_KROW0 + (size_t)R0 * KF_KROW_W, RES_GU = RES_KROW1 + (size_t)R1 * KF_KROW_W,
+               RES_GS = RES_GU + r01, RES_SIZE = RES_GS + r01;
   // ---- one staged host -> device copy: X, Y, per latent Z0, Z1, u, s
   size_t off_x = 0, off_y = dev_xy ? 0 : (size_t)N * ldx, off = dev_xy ? 0 : off_y + (size_t)N;
   size_t off_z[2][2], off_u[2], off_s[2];
@@ -755,28 +793,38 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     ZIGP_HIP(c, hipMemcpyAsync(ks.in.p, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, c->stream));
   }
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
-  ZIGP_ENSURE(c, ks.mat, (size_t)4 * KF_FAC_SIZE + 2 * KF_LAT_SIZE);
+  ZIGP_ENSURE(c, ks.mat, (size_t)4 * FAC_SIZE + 2 * LAT_SIZE);
   const int pw_blocks = (int)(Npad / PW_THREADS);
   const size_t pts_lat = (size_t)8 * Npad;   // part[4], gm, gv, dq0, dq1
   ZIGP_ENSURE(c, ks.pts, 2 * pts_lat);
-  const size_t n_res = (size_t)2 * KF_RES_SIZE + (size_t)pw_blocks * 4;
+  const size_t n_res = (size_t)2 * RES_SIZE + (size_t)pw_blocks * 4;
   ZIGP_ENSURE(c, ks.res, n_res);
-  auto fac = [&](int h, int q) { return ks.mat.p + (size_t)(2 * h + q) * KF_FAC_SIZE; };
-  auto lat = [&](int h) { return ks.mat.p + (size_t)4 * KF_FAC_SIZE + (size_t)h * KF_LAT_SIZE; };
+  auto fac = [&](int h, int q) { return ks.mat.p + (size_t)(2 * h + q) * FAC_SIZE; };
+  auto lat = [&](int h) { return ks.mat.p + (size_t)4 * FAC_SIZE + (size_t)h * LAT_SIZE; };
   auto pts = [&](int h) { return ks.pts.p + (size_t)h * pts_lat; };
-  auto res = [&](int h) { return ks.res.p + (size_t)h * KF_RES_SIZE; };
-  double* d_pwacc = ks.res.p + (size_t)2 * KF_RES_SIZE;
+  auto res = [&](int h) { return ks.res.p + (size_t)h * RES_SIZE; };
+  double* d_pwacc = ks.res.p + (size_t)2 * RES_SIZE;
 
-  // ---- factor stage
+  int Mq[2][2];
+  for (int h = 0; h < nlat; ++h)
+    for (int q = 0; q < 2; ++q) Mq[h][q] = (int)round_up(hl[h].M[q], 16);
+  // LDS of the larger-grid point kernels: fragment images packed by the actual block counts (max over the latents)
+  size_t lds_fwd = 0, lds_bwd = 0;
+  for (int h = 0; h < nlat; ++h) {
+    const size_t b0 = Mq[h][0] / 16, b1 = Mq[h][1] / 16;
+    lds_fwd = std::max(lds_fwd, sizeof(double) * 256 * (b0 * b0 + b1 * b1 + 2 * b0 * b1));
+    lds_bwd = std::max(lds_bwd, sizeof(double) * 256 * (b0 * b0 + b1 * b1 + 4 * b0 * b1));
+  }
   static bool attr_set = false;
   if (!attr_set) {
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * PB * PBLD)));
-    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_backward), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)KF_BWD_LDS));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_backward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KF_BWD_LDS));
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KF_FIN_LDS));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_forward<1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_backward<1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  int Mq[2][2];
+  // ---- factor stage
   double zc[2][2][MAXD];
   {
     KfFactorArgs fa;
@@ -785,11 +833,10 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       for (int q = 0; q < 2; ++q) {
         KfFactorJob& jb = fa.job[2 * h + q];
         const int M = hl[h].M[q], D = q == 0 ? D0 : D1;
-        Mq[h][q] = (int)round_up(M, 16);
         jb.Z = ks.in.p + off_z[h][q]; jb.M = M; jb.D = D; jb.Mq = Mq[h][q];
         for (int d = 0; d < MAXD; ++d) jb.inv_ell[d] = d < D ? 1.0 / hl[h].ell[q][d] : 0.0;
         jb.var = hl[h].var[q];
-        jb.K = fac(h, q) + KF_FAC_K; jb.P = fac(h, q) + KF_FAC_P; jb.PF = fac(h, q) + KF_FAC_PF; jb.dvec = fac(h, q) + KF_FAC_DV;
+        jb.K = fac(h, q); jb.P = fac(h, q) + FAC_P; jb.PF = fac(h, q) + FAC_PF; jb.dvec = fac(h, q) + FAC_DV;
         for (int d = 0; d < MAXD; ++d) {
           double lo = 0.0, hi = 0.0;
           if (d < D) {
@@ -811,14 +858,15 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     for (int h = 0; h < nlat; ++h) {
       KfLatentJob& jb = la.job[h];
       jb.M0 = hl[h].M[0]; jb.M1 = hl[h].M[1]; jb.Mq0 = Mq[h][0]; jb.Mq1 = Mq[h][1];
-      jb.P0 = fac(h, 0) + KF_FAC_P; jb.P1 = fac(h, 1) + KF_FAC_P; jb.dvec0 = fac(h, 0) + KF_FAC_DV; jb.dvec1 = fac(h, 1) + KF_FAC_DV;
+      jb.P0 = fac(h, 0) + FAC_P; jb.P1 = fac(h, 1) + FAC_P; jb.dvec0 = fac(h, 0) + FAC_DV; jb.dvec1 = fac(h, 1) + FAC_DV;
       jb.u = ks.in.p + off_u[h]; jb.s = ks.in.p + off_s[h];
       double* L = lat(h);
-      jb.U = L + KF_LAT_U; jb.S2 = L + KF_LAT_S2; jb.T0 = L + KF_LAT_T0; jb.T1 = L + KF_LAT_T1; jb.Al = L + KF_LAT_AL;
-      jb.AlF = L + KF_LAT_ALF; jb.S2F = L + KF_LAT_S2F; jb.AlTF = L + KF_LAT_ALTF; jb.S2TF = L + KF_LAT_S2TF;
-      jb.klv = res(h) + KF_RES_KLV;
+      jb.U = L + LAT_U; jb.S2 = L + LAT_S2; jb.T0 = L + LAT_T0; jb.T1 = L + LAT_T1; jb.Al = L + LAT_AL;
+      jb.AlF = L + LAT_ALF; jb.S2F = L + LAT_S2F; jb.AlTF = L + LAT_ALTF; jb.S2TF = L + LAT_S2TF;
+      jb.klv = res(h) + RES_KLV;
     }
-    hipLaunchKernelGGL(k_kf_latent, dim3(nlat), dim3(1024), 0, c->stream, la);
+    if (pl.large) hipLaunchKernelGGL(k_kfl_latent, dim3(nlat), dim3(1024), 0, c->stream, la);
+    else hipLaunchKernelGGL(k_kf_latent, dim3(nlat), dim3(1024), 0, c->stream, la);
     ZIGP_HIP(c, hipGetLastError());
   }
   // ---- point stage
@@ -833,19 +881,21 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       f.M = hl[h].M[q]; f.nb = Mq[h][q] / 16; f.D = D; f.col0 = q == 0 ? 0 : D0;
       for (int d = 0; d < MAXD; ++d) { f.inv_ell[d] = d < D ? 1.0 / hl[h].ell[q][d] : 0.0; f.zc[d] = zc[h][q][d]; }
       f.var = hl[h].var[q];
-      f.Z = ks.in.p + off_z[h][q]; f.PF = fac(h, q) + KF_FAC_PF;
+      f.Z = ks.in.p + off_z[h][q]; f.PF = fac(h, q) + FAC_PF;
     }
     double* Lm = lat(h);
-    L.AlF = Lm + KF_LAT_ALF; L.S2F = Lm + KF_LAT_S2F; L.AlTF = Lm + KF_LAT_ALTF; L.S2TF = Lm + KF_LAT_S2TF;
+    L.AlF = Lm + LAT_ALF; L.S2F = Lm + LAT_S2F; L.AlTF = Lm + LAT_ALTF; L.S2TF = Lm + LAT_S2TF;
     double* P = pts(h);
     L.part = P; L.gm = P + 4 * Npad; L.gv = P + 5 * Npad; L.dq0 = P + 6 * Npad; L.dq1 = P + 7 * Npad;
     L.knn = hl[h].var[0] * hl[h].var[1];
   }
   {
-    const int waves = std::min(ka.ntiles, 2048);
+    const int waves = std::min(ka.ntiles, pl.large ? 1024 / nlat : 2048);
     ka.tpw = (ka.ntiles + waves - 1) / waves;
     const int nw = (ka.ntiles + ka.tpw - 1) / ka.tpw;
-    hipLaunchKernelGGL(k_kf_forward, dim3((nw + KF_WAVES - 1) / KF_WAVES, nlat), dim3(64 * KF_WAVES), 0, c->stream, ka);
+    const dim3 grid((nw + KF_WAVES - 1) / KF_WAVES, nlat);
+    if (pl.large) hipLaunchKernelGGL((k_kfl_forward<1, 7>), grid, dim3(64 * KF_WAVES), lds_fwd, c->stream, ka);
+    else hipLaunchKernelGGL(k_kf_forward, grid, dim3(64 * KF_WAVES), 0, c->stream, ka);
     ZIGP_HIP(c, hipGetLastError());
   }
   KronPwArgs a;
@@ -870,39 +920,77 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   else hipLaunchKernelGGL(k_kron_head_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
   ZIGP_HIP(c, hipGetLastError());
   if (need_grad) {
-    const int waves = std::min(ka.ntiles, 1024 / nlat);   // one wave per SIMD of the chip: the kernel holds ~400 registers per lane
+    const int waves = std::min(ka.ntiles, 1024 / nlat);   // one wave per SIMD of the chip: the kernels hold ~400-500 registers per lane
     ka.tpw = (ka.ntiles + waves - 1) / waves;
     const int nw = (ka.ntiles + ka.tpw - 1) / ka.tpw;
-    const int nwg = (nw + KF_WAVES - 1) / KF_WAVES, nw_alloc = nwg * KF_WAVES;
-    ZIGP_ENSURE(c, ks.acc, (size_t)2 * nw_alloc * KF_ACC_DOUBLES);
-    for (int h = 0; h < nlat; ++h) ka.lat[h].acc = ks.acc.p + (size_t)h * nw_alloc * KF_ACC_DOUBLES;
-    hipLaunchKernelGGL(k_kf_backward, dim3(nwg, nlat), dim3(64 * KF_WAVES), KF_BWD_LDS, c->stream, ka);
+    const int nwg = (nw + KF_WAVES - 1) / KF_WAVES;
+    int nparts;
+    if (!pl.large) {
+      nparts = nwg * KF_WAVES;
+      ZIGP_ENSURE(c, ks.acc, (size_t)2 * nparts * nblk * 256);
+      for (int h = 0; h < nlat; ++h) ka.lat[h].acc = ks.acc.p + (size_t)h * nparts * nblk * 256;
+      hipLaunchKernelGGL(k_kf_backward, dim3(nwg, nlat), dim3(64 * KF_WAVES), KF_BWD_LDS, c->stream, ka);
+      ZIGP_HIP(c, hipGetLastError());
+    } else {
+      size_t rec[2] = {0, 0}, spill_total = 0;
+      for (int h = 0; h < nlat; ++h) { rec[h] = (size_t)64 * (Mq[h][0] + Mq[h][1]); spill_total += rec[h] * ka.ntiles; }
+      ZIGP_ENSURE(c, ks.spill, spill_total);
+      ka.lat[0].spill = ks.spill.p;
+      if (nlat == 2) ka.lat[1].spill = ks.spill.p + rec[0] * ka.ntiles;
+      hipLaunchKernelGGL((k_kfl_backward<1, 7>), dim3(nwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
+      ZIGP_HIP(c, hipGetLastError());
+      // sums over points: one wave per output block and split of ~16 tiles
+      const int tps = 16;
+      nparts = (ka.ntiles + tps - 1) / tps;
+      ZIGP_ENSURE(c, ks.acc, (size_t)2 * nparts * nblk * 256);
+      KflAccArgs aa;
+      memset(&aa, 0, sizeof(aa));
+      aa.X = ka.X; aa.N = N; aa.ldx = ldx; aa.ntiles = ka.ntiles; aa.tps = tps; aa.nb0c = pl.nb0c; aa.nb1c = pl.nb1c;
+      for (int h = 0; h < nlat; ++h) {
+        KflAccLat& L = aa.lat[h];
+        L.spill = ka.lat[h].spill; L.gm = ka.lat[h].gm; L.gv = ka.lat[h].gv;
+        L.acc = ks.acc.p + (size_t)h * nparts * nblk * 256;
+        ka.lat[h].acc = L.acc;
+        L.nb0 = Mq[h][0] / 16; L.nb1 = Mq[h][1] / 16; L.D0 = D0; L.D1 = D1;
+        for (int d = 0; d < MAXD; ++d) { L.zc0[d] = zc[h][0][d]; L.zc1[d] = zc[h][1][d]; }
+      }
+      hipLaunchKernelGGL(k_kfl_accum, dim3((nblk + 3) / 4, nparts, nlat), dim3(256), 0, c->stream, aa);
+      ZIGP_HIP(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_kf_reduce, dim3(nblk * 256 / 16, nlat), dim3(256), 0, c->stream, ka.lat[0].acc, ka.lat[gl_].acc, nparts,
+                       lat(0) + LAT_WORK, lat(gl_) + LAT_WORK, pl.nb0c, pl.nb1c);
     ZIGP_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_kf_reduce, dim3(KF_ACC_DOUBLES / 16, nlat), dim3(256), 0, c->stream, ka.lat[0].acc, ka.lat[gl_].acc, nw_alloc,
-                       lat(0) + KF_LAT_WORK, lat(gl_) + KF_LAT_WORK);
-    ZIGP_HIP(c, hipGetLastError());
-    KfFinishArgs fa;
+    KflFinishArgs fa;
     memset(&fa, 0, sizeof(fa));
     for (int h = 0; h < nlat; ++h) {
       KfFinishJob& jb = fa.job[h];
       jb.M0 = hl[h].M[0]; jb.M1 = hl[h].M[1]; jb.Mq0 = Mq[h][0]; jb.Mq1 = Mq[h][1]; jb.D0 = D0; jb.D1 = D1;
-      jb.P0 = fac(h, 0) + KF_FAC_P; jb.P1 = fac(h, 1) + KF_FAC_P; jb.dvec0 = fac(h, 0) + KF_FAC_DV; jb.dvec1 = fac(h, 1) + KF_FAC_DV;
-      jb.K0 = fac(h, 0) + KF_FAC_K; jb.K1 = fac(h, 1) + KF_FAC_K; jb.Z0 = ks.in.p + off_z[h][0]; jb.Z1 = ks.in.p + off_z[h][1];
+      jb.P0 = fac(h, 0) + FAC_P; jb.P1 = fac(h, 1) + FAC_P; jb.dvec0 = fac(h, 0) + FAC_DV; jb.dvec1 = fac(h, 1) + FAC_DV;
+      jb.K0 = fac(h, 0); jb.K1 = fac(h, 1); jb.Z0 = ks.in.p + off_z[h][0]; jb.Z1 = ks.in.p + off_z[h][1];
       for (int d = 0; d < MAXD; ++d) { jb.zc0[d] = zc[h][0][d]; jb.zc1[d] = zc[h][1][d]; }
       double* L = lat(h);
-      jb.U = L + KF_LAT_U; jb.S2 = L + KF_LAT_S2; jb.T0 = L + KF_LAT_T0; jb.T1 = L + KF_LAT_T1; jb.Al = L + KF_LAT_AL; jb.s = ks.in.p + off_s[h];
-      jb.work = L + KF_LAT_WORK;
-      jb.krow0 = res(h) + KF_RES_KROW0; jb.krow1 = res(h) + KF_RES_KROW1; jb.gu = res(h) + KF_RES_GU; jb.gs = res(h) + KF_RES_GS;
+      jb.U = L + LAT_U; jb.S2 = L + LAT_S2; jb.T0 = L + LAT_T0; jb.T1 = L + LAT_T1; jb.Al = L + LAT_AL; jb.s = ks.in.p + off_s[h];
+      jb.work = L + LAT_WORK;
+      jb.krow0 = res(h) + RES_KROW0; jb.krow1 = res(h) + RES_KROW1; jb.gu = res(h) + RES_GU; jb.gs = res(h) + RES_GS;
     }
     fa.jitter = jitter; fa.with_kl = include_kl ? 1 : 0;
-    hipLaunchKernelGGL(k_kf_finish, dim3(2, nlat), dim3(1024), KF_FIN_LDS, c->stream, fa);
+    fa.ldw = wl.ldw; fa.wS2 = wl.S2; fa.wP0 = wl.P0; fa.wP1 = wl.P1; fa.wK0 = wl.K0; fa.wK1 = wl.K1;
+    fa.scratch_off = (int64_t)wl.total; fa.scratch_set = (int64_t)SCR_SET;
+    if (pl.large) {
+      hipLaunchKernelGGL(k_kfl_finish, dim3(2, nlat), dim3(1024), 0, c->stream, fa);
+    } else {
+      KfFinishArgs fs;
+      memset(&fs, 0, sizeof(fs));
+      fs.job[0] = fa.job[0]; fs.job[1] = fa.job[1]; fs.jitter = fa.jitter; fs.with_kl = fa.with_kl;
+      hipLaunchKernelGGL(k_kf_finish, dim3(2, nlat), dim3(1024), KF_FIN_LDS, c->stream, fs);
+    }
     ZIGP_HIP(c, hipGetLastError());
   }
   double* hres = nullptr;
   ZIGP_TRY(download(c, ks.res.p, n_res, &hres));
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   ZIGP_TRY(info_result(c, hinfo, "a Kronecker factor of Kuu"));
-  const double* hacc = hres + (size_t)2 * KF_RES_SIZE;
+  const double* hacc = hres + (size_t)2 * RES_SIZE;
   double s_ve = 0, s_dn = 0, s_gv[2] = {0, 0};
   for (int b = 0; b < pw_blocks; ++b) { s_ve += hacc[4 * b]; s_dn += hacc[4 * b + 1]; s_gv[0] += hacc[4 * b + 2]; s_gv[1] += hacc[4 * b + 3]; }
   if (elbo_data) *elbo_data = s_ve;
@@ -910,7 +998,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   double klsum = 0.0;
   if (include_kl) {
     for (int h = 0; h < nlat; ++h) {
-      const double* v = hres + (size_t)h * KF_RES_SIZE + KF_RES_KLV;
+      const double* v = hres + (size_t)h * RES_SIZE + RES_KLV;
       const int M0 = hl[h].M[0], M1 = hl[h].M[1];
       klsum += 0.5 * (v[0] - (double)M0 * M1 - v[1] + v[2] + (double)M1 * v[3] + (double)M0 * v[4]);
     }
@@ -923,10 +1011,10 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     double* gu[2] = {grads->u_fm, grads->u_gm};
     double* gs[2] = {grads->u_fs_sqrt, grads->u_gs_sqrt};
     for (int h = 0; h < nlat; ++h) {
-      const double* R = hres + (size_t)h * KF_RES_SIZE;
+      const double* R = hres + (size_t)h * RES_SIZE;
       for (int q = 0; q < 2; ++q) {
         const int D = q == 0 ? D0 : D1, W = 2 + 2 * D, M = hl[h].M[q];
-        const double* krow = R + (q == 0 ? KF_RES_KROW0 : KF_RES_KROW1);
+        const double* krow = R + (q == 0 ? RES_KROW0 : RES_KROW1);
         const double* ell = hl[h].ell[q];
         double dv = 0.0;
         std::vector<double> dl(D, 0.0);
@@ -943,8 +1031,8 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
         gvar[h][q] = dv / hl[h].var[q] + s_gv[h] * hl[h].var[1 - q];   // Knn = var0 * var1 enters var_n directly (scripts/onoff.py:196-200)
       }
       const size_t ng = (size_t)hl[h].M[0] * hl[h].M[1];
-      if (gu[h]) memcpy(gu[h], R + KF_RES_GU, sizeof(double) * ng);
-      if (gs[h]) memcpy(gs[h], R + KF_RES_GS, sizeof(double) * ng);
+      if (gu[h]) memcpy(gu[h], R + RES_GU, sizeof(double) * ng);
+      if (gs[h]) memcpy(gs[h], R + RES_GS, sizeof(double) * ng);
     }
     grads->var0f = gvar[0][0]; grads->var1f = gvar[0][1];
     grads->var0g = nlat == 2 ? gvar[1][0] : 0.0; grads->var1g = nlat == 2 ? gvar[1][1] : 0.0;

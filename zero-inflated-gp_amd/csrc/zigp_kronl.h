@@ -144,25 +144,6 @@ k_kfl_backward(KfArgs a) {
   }
 }
 
-// block numbering shared by the accumulators of every variant (capacities nb0c, nb1c): Al | S2 (nb0c x nb1c each) | P0 | P1 | K0 | K1
-struct KfBlock { int kind, rb, cb; };   // kind 0 Al, 1 S2, 2 P0, 3 P1, 4 moments of factor 0, 5 of factor 1
-__device__ __forceinline__ KfBlock kf_block_decode(int blk, int nb0c, int nb1c) {
-  KfBlock b;
-  const int n01 = nb0c * nb1c;
-  if (blk < n01) { b.kind = 0; b.rb = blk / nb1c; b.cb = blk % nb1c; return b; }
-  blk -= n01;
-  if (blk < n01) { b.kind = 1; b.rb = blk / nb1c; b.cb = blk % nb1c; return b; }
-  blk -= n01;
-  if (blk < nb0c * nb0c) { b.kind = 2; b.rb = blk / nb0c; b.cb = blk % nb0c; return b; }
-  blk -= nb0c * nb0c;
-  if (blk < nb1c * nb1c) { b.kind = 3; b.rb = blk / nb1c; b.cb = blk % nb1c; return b; }
-  blk -= nb1c * nb1c;
-  if (blk < nb0c) { b.kind = 4; b.rb = blk; b.cb = 0; return b; }
-  b.kind = 5; b.rb = blk - nb0c; b.cb = 0;
-  return b;
-}
-__host__ __device__ inline int kf_nblocks(int nb0c, int nb1c) { return 2 * nb0c * nb1c + nb0c * nb0c + nb1c * nb1c + nb0c + nb1c; }
-
 struct KflAccLat { const double* spill; const double *gm, *gv; double* acc; int nb0, nb1, D0, D1; double zc0[MAXD], zc1[MAXD]; };
 struct KflAccArgs { KflAccLat lat[2]; const double* X; int64_t N; int ldx, ntiles, tps, nb0c, nb1c; };
 
