@@ -125,8 +125,11 @@ struct KfFwdTile { double K0[KF_Q], K1[KF_Q], A0[KF_Q], A1[KF_Q], B0[KF_Q], C0[K
 // read returns in ~100 cycles where an L2 hit takes 500+ (one wave per SIMD has nothing else to hide that behind).
 constexpr int KF_FRAG = KF_MQ_ * KF_MQ_;
 struct KfFrags { const double *P0, *P1, *Al, *S2, *AlT, *S2T; };
-__device__ __forceinline__ void kf_stage_frag(double* dst, const double* __restrict__ src, int n) {
-  for (int idx = threadIdx.x; idx < n; idx += blockDim.x) dst[idx] = src[idx];
+__device__ __forceinline__ void kf_stage_frag(double* dst, const double* __restrict__ src, int n) {   // n is a multiple of 256
+  const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
+  double2* d2 = reinterpret_cast<double2*>(dst);
+#pragma unroll 4
+  for (int idx = threadIdx.x; idx < n / 2; idx += blockDim.x) d2[idx] = s2[idx];
 }
 // forward pieces of one tile: A_p = P_p K_p, B0 = Alpha K1, C0 = S2 A1^2
 __device__ __forceinline__ void kf_forward_tile(KfFwdTile& t, const KfLat& L, const KfFrags& F, const double* __restrict__ xrow, bool valid, int g,
@@ -486,14 +489,19 @@ k_kf_factor(KfFactorArgs a) {
     __syncthreads();
     if (t == 0) { double q = 0.0; for (int w = 0; w < 16; ++w) q += red[w]; jb.dvec[Mq] = q; }
   }
-  // P = W^T W:  P[i][j] = sum_{k >= max(i,j)} W[k][i] W[k][j]
+  // P = W^T W:  P[i][j] = sum_{k >= max(i,j)} W[k][i] W[k][j].  Column i of W (below its diagonal) is ROW i of the LDS image right
+  // of the diagonal, so for i <= j:  P[i][j] = W[j][i] W[j][j] + sum_{k > j} S[i][k] S[j][k]  -- two contiguous rows, no branches
   for (int idx = t; idx < Mq * Mq; idx += 1024) {
     const int i = idx / Mq, j = idx - i * Mq;
+    if (i > j) continue;
     double v = 0.0;
-    if (i < M && j < M) {
-      for (int k = max(i, j); k < M; ++k) v = fma(potrf_wget(S, psh.dinv, k, i), potrf_wget(S, psh.dinv, k, j), v);
+    if (j < M) {
+      v = (i == j) ? psh.dinv[j] * psh.dinv[j] : S[i * PBLD + j] * psh.dinv[j];
+      const double* si = S + i * PBLD; const double* sj = S + j * PBLD;
+#pragma unroll 4
+      for (int k = j + 1; k < M; ++k) v = fma(si[k], sj[k], v);
     }
-    jb.P[idx] = v;
+    jb.P[i * Mq + j] = v; jb.P[j * Mq + i] = v;
     if (i == j) jb.dvec[i] = v;
   }
   __syncthreads();   // P is re-read below by other threads of this workgroup
@@ -533,6 +541,7 @@ __device__ __forceinline__ void kf_lds_frag(double* __restrict__ F, int nbr, int
 struct KfLatentJob {
   int M0, M1, Mq0, Mq1;
   const double *P0, *P1, *dvec0, *dvec1;     // from k_kf_factor
+  const double *PF0, *PF1;                   // their fragment images (larger-grid kernels)
   const double *u, *s;                       // [M0*M1] from the parameter pack
   double *U, *S2, *T0, *T1, *Al;             // [Mq0][Mq1] zero padded: U, s^2, U P1, P0 U, Alpha = P0 U P1
   double *AlF, *S2F, *AlTF, *S2TF;           // fragment images
@@ -600,6 +609,7 @@ k_kf_latent(KfLatentArgs a) {
 struct KfFinishJob {
   int M0, M1, Mq0, Mq1, D0, D1;
   const double *P0, *P1, *dvec0, *dvec1, *K0, *K1, *Z0, *Z1;
+  const double *PF0, *PF1;
   double zc0[MAXD], zc1[MAXD];
   const double *U, *S2, *T0, *T1, *Al, *s;
   const double* work;  // KF_W_TOTAL summed accumulators
@@ -820,8 +830,8 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * PB * PBLD)));
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_backward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KF_BWD_LDS));
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KF_FIN_LDS));
-    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_forward<1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_backward<1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_forward<1, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_backward<1, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   // ---- factor stage
@@ -859,6 +869,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       KfLatentJob& jb = la.job[h];
       jb.M0 = hl[h].M[0]; jb.M1 = hl[h].M[1]; jb.Mq0 = Mq[h][0]; jb.Mq1 = Mq[h][1];
       jb.P0 = fac(h, 0) + FAC_P; jb.P1 = fac(h, 1) + FAC_P; jb.dvec0 = fac(h, 0) + FAC_DV; jb.dvec1 = fac(h, 1) + FAC_DV;
+      jb.PF0 = fac(h, 0) + FAC_PF; jb.PF1 = fac(h, 1) + FAC_PF;
       jb.u = ks.in.p + off_u[h]; jb.s = ks.in.p + off_s[h];
       double* L = lat(h);
       jb.U = L + LAT_U; jb.S2 = L + LAT_S2; jb.T0 = L + LAT_T0; jb.T1 = L + LAT_T1; jb.Al = L + LAT_AL;
@@ -894,7 +905,8 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     ka.tpw = (ka.ntiles + waves - 1) / waves;
     const int nw = (ka.ntiles + ka.tpw - 1) / ka.tpw;
     const dim3 grid((nw + KF_WAVES - 1) / KF_WAVES, nlat);
-    if (pl.large) hipLaunchKernelGGL((k_kfl_forward<1, 7>), grid, dim3(64 * KF_WAVES), lds_fwd, c->stream, ka);
+    if (pl.large && ka.tpw > 0) hipLaunchKernelGGL((k_kfl_forward<1, 7, true>), grid, dim3(64 * KF_WAVES), lds_fwd, c->stream, ka);
+    else if (pl.large) hipLaunchKernelGGL((k_kfl_forward<1, 7, false>), grid, dim3(64 * KF_WAVES), 0, c->stream, ka);
     else hipLaunchKernelGGL(k_kf_forward, grid, dim3(64 * KF_WAVES), 0, c->stream, ka);
     ZIGP_HIP(c, hipGetLastError());
   }
@@ -937,10 +949,11 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       ZIGP_ENSURE(c, ks.spill, spill_total);
       ka.lat[0].spill = ks.spill.p;
       if (nlat == 2) ka.lat[1].spill = ks.spill.p + rec[0] * ka.ntiles;
-      hipLaunchKernelGGL((k_kfl_backward<1, 7>), dim3(nwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
+      if (ka.tpw > 0) hipLaunchKernelGGL((k_kfl_backward<1, 7, true>), dim3(nwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
+      else hipLaunchKernelGGL((k_kfl_backward<1, 7, false>), dim3(nwg, nlat), dim3(64 * KF_WAVES), 0, c->stream, ka);
       ZIGP_HIP(c, hipGetLastError());
-      // sums over points: one wave per output block and split of ~16 tiles
-      const int tps = 16;
+      // sums over points: one wave per output block and split of tps tiles (4 for a minibatch: the chain of dependent loads is short)
+      const int tps = std::max(4, std::min(64, ka.ntiles / 16));
       nparts = (ka.ntiles + tps - 1) / tps;
       ZIGP_ENSURE(c, ks.acc, (size_t)2 * nparts * nblk * 256);
       KflAccArgs aa;
@@ -966,6 +979,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       KfFinishJob& jb = fa.job[h];
       jb.M0 = hl[h].M[0]; jb.M1 = hl[h].M[1]; jb.Mq0 = Mq[h][0]; jb.Mq1 = Mq[h][1]; jb.D0 = D0; jb.D1 = D1;
       jb.P0 = fac(h, 0) + FAC_P; jb.P1 = fac(h, 1) + FAC_P; jb.dvec0 = fac(h, 0) + FAC_DV; jb.dvec1 = fac(h, 1) + FAC_DV;
+      jb.PF0 = fac(h, 0) + FAC_PF; jb.PF1 = fac(h, 1) + FAC_PF;
       jb.K0 = fac(h, 0); jb.K1 = fac(h, 1); jb.Z0 = ks.in.p + off_z[h][0]; jb.Z1 = ks.in.p + off_z[h][1];
       for (int d = 0; d < MAXD; ++d) { jb.zc0[d] = zc[h][0][d]; jb.zc1[d] = zc[h][1][d]; }
       double* L = lat(h);

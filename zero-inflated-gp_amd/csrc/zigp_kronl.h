@@ -8,7 +8,11 @@
 template <int NB0, int NB1> struct KflTile { double K0[4 * NB0], K1[4 * NB1], A0[4 * NB0], A1[4 * NB1], B0[4 * NB0], C0[4 * NB0]; };
 
 // LDS layout of the fragment images: P0 | P1 | Al | S2 | AlT | S2T, packed by the ACTUAL block counts
+// STAGE = false: a wave that owns only a tile or two reads the fragments straight from global memory (L2): staging would move the
+// same bytes once per workgroup and put a barrier in front of the first MFMA
+template <bool STAGE>
 __device__ __forceinline__ KfFrags kfl_stage_frags(double* lds, const KfLat& L, bool with_transposes) {
+  if (!STAGE) { KfFrags G = {L.f[0].PF, L.f[1].PF, L.AlF, L.S2F, L.AlTF, L.S2TF}; return G; }
   const int nb0 = L.f[0].nb, nb1 = L.f[1].nb;
   const int n0 = nb0 * nb0 * 256, n1 = nb1 * nb1 * 256, n01 = nb0 * nb1 * 256;
   double* p = lds;
@@ -45,12 +49,12 @@ __device__ __forceinline__ void kfl_forward_tile(KflTile<NB0, NB1>& t, const KfL
   kf_frag_mm<NB0, 4 * NB1>(t.C0, F.S2, f0.nb, 4 * f1.nb, sq, slot);
 }
 
-template <int NB0, int NB1>
+template <int NB0, int NB1, bool STAGE>
 __global__ void __launch_bounds__(64 * KF_WAVES, 1)
 k_kfl_forward(KfArgs a) {
   extern __shared__ double lds[];
   const KfLat& L = a.lat[blockIdx.y];
-  const KfFrags F = kfl_stage_frags(lds, L, false);
+  const KfFrags F = kfl_stage_frags<STAGE>(lds, L, false);
   const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
@@ -86,13 +90,13 @@ __device__ __forceinline__ void kfl_spill(double* __restrict__ base, const doubl
 
 // backward for the larger grids: the per-point reverse pass of k_kf_backward, operands of the sums over points spilled per tile:
 // record = K0 | E0 | A0 | t0 (16 Mq0 doubles each) | K1 | E1 | A1 | t1 (16 Mq1 each)
-template <int NB0, int NB1>
+template <int NB0, int NB1, bool STAGE>
 __global__ void __launch_bounds__(64 * KF_WAVES, 1)
 k_kfl_backward(KfArgs a) {
   extern __shared__ double lds[];
   const KfLat& L = a.lat[blockIdx.y];
   const KfFac &f0 = L.f[0], &f1 = L.f[1];
-  const KfFrags F = kfl_stage_frags(lds, L, true);
+  const KfFrags F = kfl_stage_frags<STAGE>(lds, L, true);
   const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
   const int Mq0 = 16 * f0.nb, Mq1 = 16 * f1.nb;
@@ -235,6 +239,58 @@ __device__ __forceinline__ void kf_gmm(double* C, int ldc, const double* __restr
   }
 }
 
+// C (16 nbr x 16 ncb) = A . B on the MFMA pipe: A in fragment order (k = 4 ksn; P_p ships that way for the point kernels), B in
+// global memory -- row-major B[k][j], or (TB) the transpose of a row-major matrix, B[k][j] = Bsrc[j][k].  The waves of the workgroup
+// stride over the 16 x 16 output blocks; TC stores the result transposed (C^T row-major).  One 32-byte and one 8-byte load per
+// 16 x 16 x 4 product, independent across k-steps: a 112^3 product takes microseconds where the scalar loop took a hundred.
+template <bool TB, bool TC, int CB>
+__device__ __forceinline__ void kf_frag_gmm_cb(double* __restrict__ C, int ldc, const double* __restrict__ AF, int nbr, int ksn,
+                                               const double* __restrict__ B, int ldb, int ncb) {
+  // a wave owns a block ROW and up to CB column blocks of it: the A fragment of a k-step is loaded once and feeds CB independent
+  // accumulator chains, and 1 + CB independent loads per k-step are in flight (a one-block loop is a chain of L2 round trips)
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const double4* __restrict__ F4 = reinterpret_cast<const double4*>(AF);
+  const int ncg = (ncb + CB - 1) / CB;
+  for (int unit = wave; unit < nbr * ncg; unit += nw) {
+    const int rb = unit / ncg, cb0 = (unit - rb * ncg) * CB;
+    double acc[CB][4];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) { acc[c][0] = 0.0; acc[c][1] = 0.0; acc[c][2] = 0.0; acc[c][3] = 0.0; }
+#pragma unroll (CB == 1 ? 8 : 2)
+    for (int ks = 0; ks < ksn; ++ks) {
+      const double4 av = F4[(rb * ksn + ks) * 16 + slot];
+      double bv[CB];
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const int cb = min(cb0 + c, ncb - 1);      // clamped: the surplus chains of the last group are computed and dropped
+        bv[c] = TB ? B[(16 * cb + n) * ldb + 4 * ks + g] : B[(4 * ks + g) * ldb + 16 * cb + n];
+      }
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        acc[c][0] = kf_mfma(av.x, bv[c], acc[c][0]); acc[c][1] = kf_mfma(av.y, bv[c], acc[c][1]);
+        acc[c][2] = kf_mfma(av.z, bv[c], acc[c][2]); acc[c][3] = kf_mfma(av.w, bv[c], acc[c][3]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+      if (cb0 + c < ncb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * rb + 4 * r + g, col = 16 * (cb0 + c) + n;
+          if (TC) C[col * ldc + row] = acc[c][r]; else C[row * ldc + col] = acc[c][r];
+        }
+      }
+  }
+}
+
+template <bool TB, bool TC>
+__device__ __forceinline__ void kf_frag_gmm(double* __restrict__ C, int ldc, const double* __restrict__ AF, int nbr, int ksn,
+                                            const double* __restrict__ B, int ldb, int ncb) {
+  if (ncb >= 3) kf_frag_gmm_cb<TB, TC, 4>(C, ldc, AF, nbr, ksn, B, ldb, ncb);
+  else kf_frag_gmm_cb<TB, TC, 1>(C, ldc, AF, nbr, ksn, B, ldb, ncb);
+}
+
 // global-operand twin of k_kf_latent (same job structure)
 __global__ void __launch_bounds__(1024)
 k_kfl_latent(KfLatentArgs a) {
@@ -249,10 +305,10 @@ k_kfl_latent(KfLatentArgs a) {
     jb.S2[idx] = sv * sv;
   }
   __syncthreads();
-  kf_gmm<false, false, false>(jb.T0, Mq1, jb.U, Mq1, jb.P1, Mq1, Mq0, Mq1, Mq1);      // T0 = U P1
-  kf_gmm<false, false, false>(jb.T1, Mq1, jb.P0, Mq0, jb.U, Mq1, Mq0, Mq1, Mq0);      // T1 = P0 U
+  kf_frag_gmm<true, true>(jb.T0, Mq1, jb.PF1, Mq1 / 16, Mq1 / 4, jb.U, Mq1, Mq0 / 16);     // T0^T = P1 U^T  (P1 symmetric)
+  kf_frag_gmm<false, false>(jb.T1, Mq1, jb.PF0, Mq0 / 16, Mq0 / 4, jb.U, Mq1, Mq1 / 16);   // T1 = P0 U
   __syncthreads();
-  kf_gmm<false, false, false>(jb.Al, Mq1, jb.P0, Mq0, jb.T0, Mq1, Mq0, Mq1, Mq0);     // Alpha = P0 (U P1)
+  kf_frag_gmm<false, false>(jb.Al, Mq1, jb.PF0, Mq0 / 16, Mq0 / 4, jb.T0, Mq1, Mq1 / 16);  // Alpha = P0 (U P1)
   __syncthreads();
   kf_write_frag(jb.AlF, Mq0 / 16, Mq1 / 4, t, 1024, jb.Al, Mq1, false);
   kf_write_frag(jb.S2F, Mq0 / 16, Mq1 / 4, t, 1024, jb.S2, Mq1, false);
@@ -279,6 +335,21 @@ k_kfl_latent(KfLatentArgs a) {
   if (t == 0) { jb.klv[3] = jb.dvec0[Mq0]; jb.klv[4] = jb.dvec1[Mq1]; }
 }
 
+// C (m x n) [+]= op(A) op(B) for SMALL outputs with a long k: one output element per wave, the lanes split k (coalesced reads of the
+// contiguous operand rows), fixed-order wave sum
+template <bool TA, bool TB, bool ACC>
+__device__ __forceinline__ void kf_gmm_wave(double* C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, int m,
+                                            int n, int k) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int idx = wave; idx < m * n; idx += nw) {
+    const int i = idx / n, j = idx - i * n;
+    double v = 0.0;
+    for (int q = lane; q < k; q += 64) v = fma(TA ? A[q * lda + i] : A[i * lda + q], TB ? B[j * ldb + q] : B[q * ldb + j], v);
+    v = wave_sum(v);
+    if (lane == 0) { double* c = C + i * ldc + j; *c = ACC ? *c + v : v; }
+  }
+}
+
 // global-operand twin of k_kf_finish: grid (2, latents); work matrices have leading dimension ldw, scratch behind them
 struct KflFinishArgs { KfFinishJob job[2]; double jitter; int with_kl; int ldw, wS2, wP0, wP1, wK0, wK1; int64_t scratch_off, scratch_set; };
 
@@ -301,11 +372,11 @@ k_kfl_finish(KflFinishArgs a) {
   double* X = work + a.scratch_off + (int64_t)p * a.scratch_set;     // this workgroup's scratch: X, G, Q (ldw x ldw each), dU
   double* G = X + (int64_t)ldw * ldw; double* Q = G + (int64_t)ldw * ldw; double* dU = Q + (int64_t)ldw * ldw;
   if (p == 0) {
-    kf_gmm<false, false, false>(X, ldw, dAl, ldw, jb.P1, Mq1, Mq0, Mq1, Mq1);        // X = dAl P1
-    kf_gmm<false, true, true>(dP, ldw, dAl, ldw, jb.T0, Mq1, Mq0, Mq0, Mq1);         // dP0 += dAl T0^T
-    if (kl) kf_gmm<false, true, false>(Q, ldw, jb.T0, Mq1, jb.U, Mq1, Mq0, Mq0, Mq1);   // Q0 = T0 U^T
+    kf_frag_gmm<true, true>(X, ldw, jb.PF1, Mq1 / 16, Mq1 / 4, dAl, ldw, Mq0 / 16);  // X^T = P1 dAl^T
+    kf_gmm_wave<false, true, true>(dP, ldw, dAl, ldw, jb.T0, Mq1, Mq0, Mq0, Mq1);    // dP0 += dAl T0^T
+    if (kl) kf_gmm_wave<false, true, false>(Q, ldw, jb.T0, Mq1, jb.U, Mq1, Mq0, Mq0, Mq1);   // Q0 = T0 U^T
     __syncthreads();
-    kf_gmm<false, false, false>(dU, ldw, jb.P0, Mq0, X, ldw, Mq0, Mq1, Mq0);         // dU = P0 X
+    kf_frag_gmm<false, false>(dU, ldw, jb.PF0, Mq0 / 16, Mq0 / 4, X, ldw, Mq1 / 16);   // dU = P0 X
     __syncthreads();
     for (int idx = t; idx < M0 * M1; idx += 1024) {
       const int i = idx / M1, j = idx - i * M1;
@@ -334,33 +405,39 @@ k_kfl_finish(KflFinishArgs a) {
     X[i * ldw + j] = v;
   }
   __syncthreads();
-  kf_gmm<false, false, false>(Q, ldw, X, ldw, P, Mq, Mq, Mq, Mq);                    // Q = sym(dP) P
+  const double* PF = p == 0 ? jb.PF0 : jb.PF1;
+  kf_frag_gmm<false, true>(Q, ldw, PF, Mq / 16, Mq / 4, X, ldw, Mq / 16);            // Q = (P X)^T = X P     (X = sym(dP), P symmetric)
   __syncthreads();
-  kf_gmm<false, false, false>(G, ldw, P, Mq, Q, ldw, Mq, Mq, Mq);                    // G = P Q   (sign and KL term below)
+  kf_frag_gmm<false, false>(G, ldw, PF, Mq / 16, Mq / 4, Q, ldw, Mq / 16);           // G = P X P   (sign and KL term below)
   __syncthreads();
+  // krow[m][c]: Kuu part (as k_kuu_grad, Kz = K_p - jitter I) + data moments rebuilt around z_m.  A wave owns row m, its lanes sweep the
+  // columns j (coalesced rows of G, P, K_p), fixed-order wave sums
   const double coef = kl ? 0.5 * (double)Mo : 0.0;
   const int W = 2 + 2 * D;
-  for (int idx = t; idx < M * W; idx += 1024) {
-    const int m = idx / W, c = idx - m * W;
-    double v = 0.0;
-    if (c <= 2 * D) {
-      const int d = (c == 0) ? 0 : (c - 1) % D;
-      const double zm = Z[m * D + d];
-#pragma unroll 4
-      for (int j = 0; j < M; ++j) {
-        const double kz = Kuu[m * PB + j] - ((m == j) ? a.jitter : 0.0);
-        const double tt = (-G[m * ldw + j] - coef * P[m * Mq + j]) * kz;
-        const double df = Z[j * D + d] - zm;
-        v += (c == 0) ? tt : ((c <= D) ? 2.0 * tt * df : tt * df * df);
-      }
-      const double s0 = Kr[m * 16];
-      if (c == 0) v += s0;
-      else {
-        const double dz = zm - zc[d], s1 = Kr[m * 16 + 1 + d];
-        if (c <= D) v += s1 - dz * s0;
-        else v += Kr[m * 16 + 1 + D + d] - 2.0 * dz * s1 + dz * dz * s0;
+  const int lane = t & 63;
+  for (int m = t >> 6; m < M; m += 16) {
+    double s0 = 0.0, s1[MAXD], s2[MAXD], zm[MAXD];
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) { s1[d] = 0.0; s2[d] = 0.0; zm[d] = d < D ? Z[m * D + d] : 0.0; }
+    for (int j = lane; j < M; j += 64) {
+      const double kz = Kuu[m * PB + j] - ((m == j) ? a.jitter : 0.0);
+      const double tt = (-G[m * ldw + j] - coef * P[m * Mq + j]) * kz;
+      s0 += tt;
+#pragma unroll
+      for (int d = 0; d < MAXD; ++d)
+        if (d < D) { const double df = Z[j * D + d] - zm[d]; s1[d] = fma(2.0 * tt, df, s1[d]); s2[d] = fma(tt * df, df, s2[d]); }
+    }
+    s0 = wave_sum(s0);
+    const double k0 = Kr[m * 16];
+    if (lane == 0) krow[m * W] = s0 + k0;
+    for (int d = 0; d < D; ++d) {
+      const double a1 = wave_sum(s1[d]), a2 = wave_sum(s2[d]);
+      if (lane == 0) {
+        const double dz = zm[d] - zc[d], k1 = Kr[m * 16 + 1 + d];
+        krow[m * W + 1 + d] = a1 + k1 - dz * k0;
+        krow[m * W + 1 + D + d] = a2 + Kr[m * 16 + 1 + D + d] - 2.0 * dz * k1 + dz * dz * k0;
       }
     }
-    krow[idx] = v;
+    if (lane == 0) krow[m * W + 1 + 2 * D] = 0.0;
   }
 }
