@@ -210,3 +210,15 @@ def test_kron_shard_additivity_many_tiles(engine, M0, M1):
             ref = np.asarray(g[k][q])
             assert np.max(np.abs(s_ - ref)) <= 1e-8 * max(np.max(np.abs(ref)), 1e-300), (k, q)
     # and a 3000-row slice against the literal oracle is covered by the parametrised tests above
+
+
+def test_kron_predict_chunks_rows(engine):
+    """prediction sets larger than 131072 rows are processed in chunks (bounded device / pinned memory): same values as per-chunk calls"""
+    X, Y, p = make_kron_problem(140000, 12, 9, seed=2)
+    out = engine.kron_predict(p, X, jitter=1e-6, g_offset=-1.0)
+    a = engine.kron_predict(p, X[:131072], jitter=1e-6, g_offset=-1.0)
+    b = engine.kron_predict(p, X[131072:], jitter=1e-6, g_offset=-1.0)
+    assert out.shape == (9, 140000) and np.array_equal(out[:, :131072], a) and np.array_equal(out[:, 131072:], b)
+    ph = {k: p[k] for k in ('Zf', 'ell_f', 'var_f', 'u_fm', 'u_fs_sqrt', 'noise')}
+    o4 = engine.kron_head_predict(ph, X, 'gaussian', jitter=1e-6)
+    assert o4.shape == (4, 140000) and np.array_equal(o4[:, 131072:], engine.kron_head_predict(ph, X[131072:], 'gaussian', jitter=1e-6))

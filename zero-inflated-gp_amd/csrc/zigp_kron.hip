@@ -703,6 +703,24 @@ int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, con
 
 }  // namespace
 
+namespace {
+// Prediction sets can be much larger than a training minibatch (predict_onoff runs over the full Xtrain / Xtest): rows go through
+// the path in chunks, so device panels and the pinned staging arena stay bounded; the factor stage is recomputed per chunk (microseconds).
+constexpr int64_t KRON_PREDICT_CHUNK = 131072;
+int kron_predict_chunked(zigp_ctx* c, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter, double offset, double* out,
+                         int lik, int rows) {
+  if (N <= KRON_PREDICT_CHUNK) return kron_run(c, p, Xnew, nullptr, N, jitter, 1.0, offset, 0, true, out, nullptr, nullptr, nullptr, lik, nullptr);
+  const int ldx = p->D0 + p->D1;
+  std::vector<double> tmp((size_t)rows * KRON_PREDICT_CHUNK);
+  for (int64_t n0 = 0; n0 < N; n0 += KRON_PREDICT_CHUNK) {
+    const int64_t nc = std::min(KRON_PREDICT_CHUNK, N - n0);
+    ZIGP_TRY(kron_run(c, p, Xnew + n0 * ldx, nullptr, nc, jitter, 1.0, offset, 0, true, tmp.data(), nullptr, nullptr, nullptr, lik, nullptr));
+    for (int r = 0; r < rows; ++r) memcpy(out + (size_t)r * N + n0, tmp.data() + (size_t)r * nc, sizeof(double) * nc);
+  }
+  return ZIGP_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int zigp_kron_elbo(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
@@ -734,7 +752,7 @@ int zigp_kron_predict(zigp_ctx* c, const zigp_kron_params* p, const double* Xnew
   if (N < 0 || (N > 0 && (!Xnew || !out9))) return fail_arg(c, "zigp_kron_predict: bad arguments");
   if (N == 0) return ZIGP_OK;
   ZIGP_HIP(c, hipSetDevice(c->device));
-  return kron_run(c, p, Xnew, nullptr, N, jitter, 1.0, g_offset, 0, true, out9, nullptr, nullptr, nullptr);
+  return kron_predict_chunked(c, p, Xnew, N, jitter, g_offset, out9, ZIGP_LIK_ONOFF, 9);
 }
 
 int zigp_kron_head_elbo(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, const double* X, const double* Y, int64_t N, double jitter,
@@ -756,7 +774,7 @@ int zigp_kron_head_predict(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, 
   if (N < 0 || (N > 0 && (!Xnew || !out4))) return fail_arg(c, "zigp_kron_head_predict: bad arguments");
   if (N == 0) return ZIGP_OK;
   ZIGP_HIP(c, hipSetDevice(c->device));
-  return kron_run(c, p, Xnew, nullptr, N, jitter, 1.0, f_mu, 0, true, out4, nullptr, nullptr, nullptr, lik, nullptr);
+  return kron_predict_chunked(c, p, Xnew, N, jitter, f_mu, out4, lik, 4);
 }
 
 
