@@ -161,7 +161,8 @@ def main():
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
-    ap.add_argument('--no-overlap', action='store_true', help='timed region without the side-stream overlap')
+    ap.add_argument('--no-overlap', action='store_true', help='timed region without stream overlap')
+    ap.add_argument('--overlap-mode', type=int, default=1, help='1: HBM-bound side kernels under the rank-N updates; 2: f and g chunk chains on two streams')
     ap.add_argument('--profile-steps', type=int, default=1, help='steps of the separate profiled pass (0: none)')
     ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL, the default) or 'gloo' to rehearse the multi-rank path on fewer GPUs than ranks")
     ap.add_argument('--cpu-sample-rows', type=int, default=60000)
@@ -223,7 +224,7 @@ def main():
         torch.cuda.synchronize()
 
     eng.profile_enable(False)
-    eng.set_overlap(not args.no_overlap)
+    eng.set_overlap(0 if args.no_overlap else args.overlap_mode)
     for _ in range(args.warmup):
         out = sh.elbo(p, jitter=jitter, scale=scale)
     barrier()
@@ -254,7 +255,7 @@ def main():
         prof = eng.profile_get()
         eng.profile_enable(False)
         eng.profile_sampling(8)
-        eng.set_overlap(not args.no_overlap)
+        eng.set_overlap(0 if args.no_overlap else args.overlap_mode)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -266,7 +267,7 @@ def main():
             'config': {'workload': 'dense zero-inflated GP ELBO step (value+gradient), N=%d rows %s, D=%d, M=%d per latent, full batch'
                                    % (args.rows, 'per GPU' if args.scaling == 'weak' else 'in total', D, M),
                        'rows_this_rank': N, 'rows_total': total_rows, 'M': M, 'D': D, 'chunk_rows': args.chunk, 'jitter': jitter,
-                       'parallelism': 'row-shard x%d, 1 all-reduce/step' % world, 'timed_region': 'event timing off, side-stream overlap %s' % ('off' if args.no_overlap else 'on')},
+                       'parallelism': 'row-shard x%d, 1 all-reduce/step' % world, 'timed_region': 'event timing off, stream overlap %s' % ('off' if args.no_overlap else 'mode %d' % args.overlap_mode)},
             'n_ranks_seen': dist.get_world_size() if dist is not None else 1,
             'backend': (('rccl(nccl)' if args.backend == 'nccl' else args.backend) if dist is not None else 'none'),
             'elbo': elbo_data - kl, 'elbo_data': elbo_data, 'kl': kl,

@@ -169,7 +169,9 @@ int zigp_test_kron_graph(zigp_ctx* ctx, const zigp_kron_params* p, const double*
  * the next chunk's Kuf panels) run on a second HIP stream underneath the chunk's two MFMA-bound rank-N updates.  Results
  * are bit-identical either way and the step is ~0.8 % shorter (tools/overlap_ab.py); it is off by default so that every
  * kernel runs alone on one stream and per-kernel durations (HIP events, rocprofv3 --stats) mean what they say. */
-int zigp_set_overlap(zigp_ctx* ctx, int32_t on);
+int zigp_set_overlap(zigp_ctx* ctx, int32_t on);   /* 0 off; 1 as above; 2: the per-chunk kernel chains of the latents f and g on two
+ * streams (they are independent up to the point-wise stage): measured 1.5 % SLOWER than mode 0 on cfg3 (two full-chip GEMMs in flight
+ * share the LDS / L2 rather than fill each other's tails: tools/overlap_ab.py), kept as an option; bit-identical results; ignored while kernel timing (zigp_profile_enable) is on */
 /* Accumulated HIP-event time (ms), launch count and algorithmic flops per kernel class since the last reset,
  * measured with HIP events on the stream the kernels run on.  Classes (gemm_f64_kernel template arguments are
  * <A layout, B layout, ring stages, k-scale, triangular mode, waves, epilogue>):

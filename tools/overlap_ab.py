@@ -1,14 +1,20 @@
-"""Same-process A/B of the side-stream overlap (zigp_set_overlap) on the cfg3 step, profiling off."""
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/zero-inflated-gp_amd')
-import bench, zigp, torch
-X, Y, p = bench.synth(1000000, 1024, 3)
-e = zigp.DenseEngine(0); e.set_data_device(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
-e.elbo(p)
-for rnd in range(2):
-    for on in (False, True):
-        e.set_overlap(on)
-        e.elbo(p)
+"""Same-process A/B of the stream-overlap modes (zigp_set_overlap 0 / 1 / 2) on the cfg3 step; results must be bit-identical."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'zero-inflated-gp_amd'))
+import numpy as np, torch, bench, zigp
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+X, Y, p = bench.synth(N, 1024, 3)
+e = zigp.DenseEngine(0)
+e.set_data_device(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda())
+ref = None
+for rnd in range(3):
+    for mode in (0, 1, 2):
+        e.set_overlap(mode)
+        out = e.elbo(p)
         t0 = time.time()
-        for _ in range(4): e.elbo(p)
-        print('overlap %-5s %.2f ms/step' % (on, (time.time() - t0) / 4 * 1e3))
+        for _ in range(3): out = e.elbo(p)
+        dt = (time.time() - t0) / 3 * 1e3
+        if ref is None: ref = out
+        same = out[0] == ref[0] and all(np.array_equal(np.asarray(out[2][k]), np.asarray(ref[2][k])) for k in ref[2])
+        print('round %d overlap mode %d: %.2f ms/step  bit-identical %s' % (rnd, mode, dt, same), flush=True)

@@ -94,7 +94,8 @@ struct zigp_ctx {
   zigp::DevBuf pw_part;                 // pointwise block partials
   // mean function of f, m(x) = mean_b + mean_a . x (zigp_set_mean_function), and its gradient from the last zigp_elbo
   bool capturing = false;               // diagnostic (zigp_test_kron_graph): enqueue only, no synchronisation or host post-processing
-  bool overlap = false;                 // zigp_set_overlap: HBM-bound side kernels of a chunk run on stream2 under its SYRKs
+  int overlap = 0;                      // zigp_set_overlap: 1 = HBM-bound side kernels of a chunk on stream2 under its SYRKs; 2 = the chunk chains of f and g on two streams
+  hipEvent_t ev_g = nullptr, ev_pw = nullptr, ev_gdone = nullptr;   // mode 2: g chain done / point-wise done / g's rank-N update done
   bool mean_on = false;
   double mean_a[8] = {0}, mean_b = 0.0, mean_da[8] = {0}, mean_db = 0.0;   // 8 = zigp::MAXD (zigp_kernels.h)
   zigp::DevBuf out9;                    // predict outputs (9,Nc)

@@ -361,7 +361,58 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   };
   struct SideGuard { zigp_ctx* c; ~SideGuard() { c->stream = c->stream_main; c->prof_skip = false; } } side_guard{c};
   bool side_busy = false;
-  if (has_rows) {
+  // ---- mode 2 (zigp_set_overlap(ctx, 2), gradient steps without kernel timing): the chunk chains of the two latents are independent
+  // until the point-wise stage, so f runs on the main stream and g on stream2:
+  //   main:   Kuf_f A1 A2 H J' (f)   [wait g]  point-wise  (ev_pw)  kgrad_f  SYRK_f
+  //   side:   Kuf_g A1 A2 H J' (g)   (ev_g)    [wait pw]            kgrad_g  SYRK_g  (ev_gdone)
+  // The next point-wise kernel (main) rewrites gm_g / gv_g, which SYRK_g of this chunk (side) still reads: it waits for ev_gdone.
+  // Two full-chip GEMMs in flight fill each other's tails; the kernels and every reduction order are unchanged (bit-identical results).
+  bool chains_done = false;
+  if (c->overlap == 2 && need_grad && has_rows && !c->prof_on) {
+    ZIGP_HIP(c, hipEventRecord(c->ev_fork, c->stream_main));              // everything enqueued so far (uploads, MxM forward, memsets)
+    ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    bool g_busy = false;
+    for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc_full) {
+      Nc = chunk_rows(n0);
+      for (int h = 0; h < 2; ++h) {
+        c->stream = h == 0 ? c->stream_main : c->stream2;
+        ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], dX, Nrows, n0, Nc, D, ell_h[h]));
+        ZIGP_TRY(latent_chunk_forward(c, c->lat[h], Nc, true));
+      }
+      ZIGP_HIP(c, hipEventRecord(c->ev_g, c->stream2));
+      c->stream = c->stream_main;
+      ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_g, 0));
+      if (g_busy) ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_gdone, 0));
+      {
+        PwArgs a;
+        a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32;
+        constexpr int RW1 = Shape<WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false>::value>::RW, RW2 = Shape<WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false>::value>::RW;
+        a.np1_f = c->lat[0].Mp / RW1; a.np2_f = c->lat[0].Mp / RW2; a.np1_g = c->lat[1].Mp / RW1; a.np2_g = c->lat[1].Mp / RW2;
+        a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
+        a.var_f = p->var_f; a.var_g = p->var_g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
+        a.gm_f = c->lat[0].gm.p; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
+        a.X = dX; a.D = D; a.mean_on = c->mean_on ? 1 : 0; a.mean_b = c->mean_b;
+        for (int d = 0; d < MAXD; ++d) a.mean_a[d] = (d < D) ? c->mean_a[d] : 0.0;
+        a.acc = c->pw_part.p; a.out9 = nullptr; a.ld9 = row_end - row_begin;
+        hipLaunchKernelGGL(k_pointwise<false>, dim3((unsigned)(Nc / PW_PTS)), dim3(PW_THREADS), 0, c->stream_main, a);
+        ZIGP_HIP(c, hipGetLastError());
+      }
+      ZIGP_HIP(c, hipEventRecord(c->ev_pw, c->stream_main));
+      ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_pw, 0));
+      for (int h = 0; h < 2; ++h) {
+        c->stream = h == 0 ? c->stream_main : c->stream2;
+        ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], dX, Nrows, n0, Nc, D));
+        ZIGP_TRY(latent_chunk_syrk(c, c->lat[h], Nc));
+      }
+      ZIGP_HIP(c, hipEventRecord(c->ev_gdone, c->stream2));
+      g_busy = true;
+      c->stream = c->stream_main;
+    }
+    if (g_busy) ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_gdone, 0));
+    row_begin = row_end;   // the single-stream loop below has nothing left to do
+    chains_done = true;
+  }
+  if (has_rows && !chains_done) {
     c->prof_skip = c->prof_on && !sampled(row_begin);
     for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], dX, Nrows, row_begin, chunk_rows(row_begin), D, ell_h[h]));
   }
@@ -395,7 +446,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
     }
     // side work of this chunk: its kgrads and the next chunk's Kuf panels (gradient mode only: without the SYRKs there is
     // nothing on the main stream to hide them under)
-    const bool kgrad_side = c->overlap && need_grad && !timed;
+    const bool kgrad_side = c->overlap == 1 && need_grad && !timed;
     const bool kuf_side = kgrad_side && has_next && !timed_next;
     if (kgrad_side) {
       ZIGP_HIP(c, hipEventRecord(c->ev_fork, c->stream_main));
@@ -525,7 +576,9 @@ int zigp_create(zigp_ctx** out, int device_id) {
   c->stream_main = c->stream;
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return ZIGP_EHIP; }
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_g, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pw, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_gdone, hipEventDisableTiming) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipMalloc((void**)&c->d_info, sizeof(int)) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(sizeof(double) * PB * PBLD)) != hipSuccess) { delete c; return ZIGP_EHIP; }
@@ -554,6 +607,9 @@ int zigp_destroy(zigp_ctx* c) {
   c->pinned.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_g) (void)hipEventDestroy(c->ev_g);
+  if (c->ev_pw) (void)hipEventDestroy(c->ev_pw);
+  if (c->ev_gdone) (void)hipEventDestroy(c->ev_gdone);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream_main) (void)hipStreamDestroy(c->stream_main);
   delete c;
@@ -565,7 +621,8 @@ int zigp_last_info(zigp_ctx* c) { return c ? c->info : 0; }
 
 int zigp_set_overlap(zigp_ctx* c, int32_t on) {
   if (!c) return ZIGP_EARG;
-  c->overlap = on != 0;
+  if (on < 0 || on > 2) return fail_arg(c, "zigp_set_overlap: mode must be 0, 1 or 2");
+  c->overlap = on;
   return ZIGP_OK;
 }
 
