@@ -48,6 +48,7 @@ struct Latent {
   DevBuf du, dsq, krow;                  // row accumulators: du[Mp], dsq[Mp], krow[Mp][1+2D]
   DevBuf dLpart;                         // [S][Mp*Mp] split-K partials of the rank-N updates
   DevBuf T1, T2, T3, G;                  // MxM scratch
+  DevBuf sk;                             // [S][Mp*Mp] split-K planes of the O(M^3) products of the reverse pass
   DevBuf vec;                            // small vectors: v=W u [Mp], alpha [Mp], dkinv [Mp], scal[8]
 };
 

@@ -201,64 +201,40 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
     // C1 = sym(sum_s planes) -> T1
     hipLaunchKernelGGL(k_sym_from_planes, dim3(gridmm), dim3(256), 0, c->stream, lt.dLpart.p, syr_slices(nb), (int64_t)Mp, lt.T1.p);
     // dsq = diag(A2 G A2^T) = diag(W^T C1 W): Y = C1 W -> T3 ; dsq[m] = sum_k W[k][m] Y[k][m]
-    ZIGP_TRY(get_tiles(c, "bw_y:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
-      for (int bi = 0; bi < nb; ++bi)
-        for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, nb * kb));
-    }, td));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, td, mk_args(lt.T1.p, Mp, lt.W.p, Mp, lt.T3.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm_sk<LAY_KCONTIG, LAY_MNCONTIG>(c, lt.sk, "y", nb, [&](int bi, int bj, int& k0, int& k1) { k0 = bj * kb; k1 = nb * kb; },
+                                                     lt.T1.p, lt.W.p, lt.T3.p, Mp, SK_STORE, 1.0, false)));
     hipLaunchKernelGGL(k_coldot, dim3(Mp / 64), dim3(64, COL_LANES), 0, c->stream, lt.W.p, lt.T3.p, (int64_t)Mp, lt.dsq.p);
     // T = (W diag(s^2)) W^T -> T2   (both factors lower triangular: k <= min(i,j))
-    ZIGP_TRY(get_tiles(c, "bw_tt:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
-      for (int bi = 0; bi < nb; ++bi)
-        for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, 0, (std::min(bi, bj) + 1) * kb));
-    }, ta));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, ta, mk_args(lt.Wp.p, Mp, lt.W.p, Mp, lt.T2.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm_sk<LAY_KCONTIG, LAY_KCONTIG>(c, lt.sk, "tt", nb, [&](int bi, int bj, int& k0, int& k1) { k0 = 0; k1 = (std::min(bi, bj) + 1) * kb; },
+                                                    lt.Wp.p, lt.W.p, lt.T2.p, Mp, SK_STORE, 1.0, false)));
     // U = T C1 -> T3 ; V = U + U^T - C1 -> G
-    ZIGP_TRY(tiles_full(c, nb, nb, nb * kb, tb));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, tb, mk_args(lt.T2.p, Mp, lt.T1.p, Mp, lt.T3.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm_sk<LAY_KCONTIG, LAY_MNCONTIG>(c, lt.sk, "full", nb, [&](int, int, int& k0, int& k1) { k0 = 0; k1 = nb * kb; },
+                                                     lt.T2.p, lt.T1.p, lt.T3.p, Mp, SK_STORE, 1.0, false)));
     hipLaunchKernelGGL(k_uut_minus, dim3(gridmm), dim3(256), 0, c->stream, lt.T3.p, lt.T1.p, (int64_t)Mp, lt.G.p);
     // R = W^T V (lower part) -> T2
-    ZIGP_TRY(get_tiles(c, "bw_r:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
-      for (int bi = 0; bi < nb; ++bi)
-        for (int bj = 0; bj < nb; ++bj) v.push_back(bj <= bi ? mk_tile(bi, bj, bi * kb, nb * kb) : mk_tile(bi, bj, 0, 0));
-    }, tc));
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, tc, mk_args(lt.W.p, Mp, lt.G.p, Mp, lt.T2.p, Mp), EpiStore())));
+    auto lower_up = [&](int bi, int bj, int& k0, int& k1) { if (bj <= bi) { k0 = bi * kb; k1 = nb * kb; } else { k0 = 0; k1 = 0; } };
+    ZIGP_TRY((run_gemm_sk<LAY_MNCONTIG, LAY_MNCONTIG>(c, lt.sk, "r", nb, lower_up, lt.W.p, lt.G.p, lt.T2.p, Mp, SK_STORE, 1.0, true)));
     // dL = -tril(alpha (A1 gm)^T + (A2 gm) v^T + 2 R) -> T1
     hipLaunchKernelGGL(k_dl_assemble, dim3(gridmm), dim3(256), 0, c->stream, lt.T2.p, (int64_t)Mp, lt.vec.p + Mp, lt.a1gm.p, lt.du.p,
                        lt.vec.p, lt.T1.p);
-    TileList t1, t2, t3;
-    // Q = Phi(L^T dL) -> T2  (upper tiles get an empty k range -> zeros)
-    ZIGP_TRY(get_tiles(c, "bw_q:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
-      for (int bi = 0; bi < nb; ++bi)
-        for (int bj = 0; bj < nb; ++bj) v.push_back(bj <= bi ? mk_tile(bi, bj, bi * kb, nb * kb) : mk_tile(bi, bj, 0, 0));
-    }, t1));
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, t1, mk_args(lt.L.p, Mp, lt.T1.p, Mp, lt.T2.p, Mp), EpiPhi())));
+    // Q = Phi(L^T dL) -> T2  (upper tiles are not computed)
+    ZIGP_TRY((run_gemm_sk<LAY_MNCONTIG, LAY_MNCONTIG>(c, lt.sk, "r", nb, lower_up, lt.L.p, lt.T1.p, lt.T2.p, Mp, SK_PHI, 1.0, true)));
     // T = Q W -> T3 (lower)
-    ZIGP_TRY(get_tiles(c, "bw_t:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
-      for (int bi = 0; bi < nb; ++bi)
-        for (int bj = 0; bj < nb; ++bj) v.push_back(bj <= bi ? mk_tile(bi, bj, bj * kb, (bi + 1) * kb) : mk_tile(bi, bj, 0, 0));
-    }, t2));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t2, mk_args(lt.T2.p, Mp, lt.W.p, Mp, lt.T3.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm_sk<LAY_KCONTIG, LAY_MNCONTIG>(c, lt.sk, "t", nb, [&](int bi, int bj, int& k0, int& k1) {
+      if (bj <= bi) { k0 = bj * kb; k1 = (bi + 1) * kb; } else { k0 = 0; k1 = 0; } }, lt.T2.p, lt.W.p, lt.T3.p, Mp, SK_STORE, 1.0, true)));
     // S = W^T T -> T1
-    ZIGP_TRY(get_tiles(c, "bw_s:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
-      for (int bi = 0; bi < nb; ++bi)
-        for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, std::max(bi, bj) * kb, nb * kb));
-    }, t3));
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, t3, mk_args(lt.W.p, Mp, lt.T3.p, Mp, lt.T1.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm_sk<LAY_MNCONTIG, LAY_MNCONTIG>(c, lt.sk, "s", nb, [&](int bi, int bj, int& k0, int& k1) { k0 = std::max(bi, bj) * kb; k1 = nb * kb; },
+                                                      lt.W.p, lt.T3.p, lt.T1.p, Mp, SK_STORE, 1.0, false)));
   }
   double* P = lt.T2.p; double* PSP = lt.G.p;
   if (with_kl) {
-    TileList t3, tf;
-    ZIGP_TRY(get_tiles(c, "bw_s:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
-      for (int bi = 0; bi < nb; ++bi)
-        for (int bj = 0; bj < nb; ++bj) v.push_back(mk_tile(bi, bj, std::max(bi, bj) * kb, nb * kb));
-    }, t3));
     // P = W^T W -> T2
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, t3, mk_args(lt.W.p, Mp, lt.W.p, Mp, lt.T2.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm_sk<LAY_MNCONTIG, LAY_MNCONTIG>(c, lt.sk, "s", nb, [&](int bi, int bj, int& k0, int& k1) { k0 = std::max(bi, bj) * kb; k1 = nb * kb; },
+                                                      lt.W.p, lt.W.p, lt.T2.p, Mp, SK_STORE, 1.0, false)));
     // Ps = diag(s2) P -> T3 ; PSP = P Ps -> G
     hipLaunchKernelGGL(k_rowscale, dim3(gridmm), dim3(256), 0, c->stream, lt.T2.p, lt.s2.p, (int64_t)Mp, lt.T3.p);
-    ZIGP_TRY(tiles_full(c, nb, nb, nb * kb, tf));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, tf, mk_args(lt.T2.p, Mp, lt.T3.p, Mp, lt.G.p, Mp), EpiStore())));
+    ZIGP_TRY((run_gemm_sk<LAY_KCONTIG, LAY_MNCONTIG>(c, lt.sk, "full", nb, [&](int, int, int& k0, int& k1) { k0 = 0; k1 = nb * kb; },
+                                                     lt.T2.p, lt.T3.p, lt.G.p, Mp, SK_STORE, 1.0, false)));
   }
   // G = sym(S) - dKL/dKuu -> T3 (T3 free again)
   hipLaunchKernelGGL(k_sym_combine, dim3(gridmm), dim3(256), 0, c->stream, S, P, PSP, lt.vec.p + Mp, with_data ? 1 : 0, with_kl ? 1 : 0,
@@ -594,7 +570,7 @@ int zigp_destroy(zigp_ctx* c) {
   for (int h = 0; h < 2; ++h) {
     Latent& l = c->lat[h];
     DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.H, &l.Jp, &l.Wp, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
-                    &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec};
+                    &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec, &l.sk};
     for (DevBuf* b : bs) b->release();
   }
   DevBuf* bs[] = {&c->ownX, &c->ownY, &c->pw_part, &c->out9, &c->scratch, &c->scratch2};

@@ -248,6 +248,63 @@ static int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// split-K for the O(M^3) products of the M x M stage.  A 1024^3 product is 64 output tiles of 64 BK steps: 64 workgroups on a
+// 256-CU chip, 105-150 us per launch, and the reverse pass chains nine of them per latent.  Each tile's k range is cut into S slices
+// (S * tiles ~ the 512 resident workgroups), the slices write their partial tile to plane s, and k_sk_finish adds the planes in
+// slice order (fixed order: bit-stable) and applies what used to be the GEMM epilogue.
+// ------------------------------------------------------------------------------------------------
+enum { SK_STORE = 0, SK_ACCUM = 1, SK_PHI = 2 };
+template <int POST>
+__global__ void __launch_bounds__(256)
+k_sk_finish(const double* __restrict__ planes, int S, int64_t Mp, double alpha, int lower_only, double* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Mp * Mp) return;
+  const int64_t i = idx / Mp, j = idx - i * Mp;
+  if (lower_only && (j / BN > i / BM)) return;      // tiles above the diagonal were not computed (and are never read)
+  double v = 0.0;
+  for (int s = 0; s < S; ++s) v += planes[(int64_t)s * Mp * Mp + idx];
+  v *= alpha;
+  if (POST == SK_STORE) out[idx] = v;
+  else if (POST == SK_ACCUM) out[idx] += v;
+  else out[idx] = (j < i) ? v : ((j == i) ? 0.5 * v : 0.0);
+}
+
+// krange(bi, bj, &kbeg, &kend) in units of BK; kend <= kbeg: the tile is not computed
+template <int AL, int BL, class KRange>
+static int run_gemm_sk(zigp_ctx* c, DevBuf& planes, const std::string& key, int nb, KRange krange, const double* A, const double* B, double* C,
+                       int64_t Mp, int post, double alpha, bool lower_only) {
+  int count = 0, minlen = 1 << 30;
+  for (int bi = 0; bi < nb; ++bi)
+    for (int bj = 0; bj < nb; ++bj) {
+      int k0, k1; krange(bi, bj, k0, k1);
+      if (k1 > k0) { ++count; minlen = std::min(minlen, k1 - k0); }
+    }
+  if (count == 0) return 0;
+  const int S = std::max(1, std::min(std::min(8, minlen), 512 / count));
+  TileList tl;
+  ZIGP_TRY(get_tiles(c, "sk:" + key + ":" + std::to_string(nb) + ":" + std::to_string(S), [&](std::vector<GemmTile>& v) {
+    for (int s = 0; s < S; ++s)
+      for (int bi = 0; bi < nb; ++bi)
+        for (int bj = 0; bj < nb; ++bj) {
+          int k0, k1; krange(bi, bj, k0, k1);
+          if (k1 <= k0) continue;
+          const int len = k1 - k0;
+          v.push_back(mk_tile(bi, bj, k0 + (int)((int64_t)len * s / S), k0 + (int)((int64_t)len * (s + 1) / S), s));
+        }
+  }, tl));
+  ZIGP_ENSURE(c, planes, (size_t)S * Mp * Mp);
+  GemmArgs g = mk_args(A, Mp, B, Mp, planes.p, Mp);
+  g.slice_stride = Mp * Mp;
+  ZIGP_TRY((run_gemm<AL, BL, false>(c, tl, g, EpiStore())));
+  const dim3 grid((unsigned)((Mp * Mp + 255) / 256));
+  if (post == SK_STORE) hipLaunchKernelGGL(k_sk_finish<SK_STORE>, grid, dim3(256), 0, c->stream, planes.p, S, Mp, alpha, lower_only ? 1 : 0, C);
+  else if (post == SK_ACCUM) hipLaunchKernelGGL(k_sk_finish<SK_ACCUM>, grid, dim3(256), 0, c->stream, planes.p, S, Mp, alpha, lower_only ? 1 : 0, C);
+  else hipLaunchKernelGGL(k_sk_finish<SK_PHI>, grid, dim3(256), 0, c->stream, planes.p, S, Mp, alpha, lower_only ? 1 : 0, C);
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+
 static inline KernHyp make_hyp(const double* ell, double var, int D) {
   KernHyp h;
   for (int d = 0; d < MAXD; ++d) h.inv_ell[d] = (d < D) ? 1.0 / ell[d] : 0.0;
