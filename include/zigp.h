@@ -194,6 +194,9 @@ int zigp_profile_totals(zigp_ctx* ctx, int64_t* total_launches /*[ZIGP_NCLASS]*/
 int zigp_profile_sampling(zigp_ctx* ctx, int32_t every);
 
 /* ---- diagnostics used by the parity tests (building blocks through the same kernels) ---- */
+/* Kronecker entry points: on != 0 forces the GEMM-panel path (zigp_kron.hip) also for grids the fused register-resident kernels
+ * (zigp_kronf.hip) cover -- two independent implementations of the same factored algebra that the tests check against each other. */
+int zigp_set_kron_panels(zigp_ctx* ctx, int32_t on);
 /* C (m,n) = op(A) * op(B) with the fp64 MFMA GEMM core; transA/transB as BLAS; all dims padded internally. */
 int zigp_test_gemm(zigp_ctx* ctx, int32_t transA, int32_t transB, int64_t m, int64_t n, int64_t k,
                    const double* A, const double* B, double* C);

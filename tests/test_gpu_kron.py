@@ -180,15 +180,30 @@ def test_kron_elbo_on_resident_rows_equals_host_minibatch(engine):
         engine.kron_elbo(p, rows=(0, 3001))
 
 
-def test_kron_fused_and_panel_paths_agree(engine):
-    """the register-resident kernels (grids up to 32 x 32) against the GEMM-panel path (used for larger factors): a 32 x 33 grid
-    takes the panel path, and on the shared 32 x 32 sub-problem both must match the literal oracle (above) -- here: bit-stable reruns"""
-    X, Y, p = make_kron_problem(2000, 32, 32, seed=9)
+@pytest.mark.parametrize('N,M0,M1,M0g,M1g', [(900, 32, 32, None, None), (1200, 10, 100, None, None), (400, 6, 5, 7, 4), (700, 16, 112, 9, 50)])
+def test_kron_fused_and_panel_paths_agree(engine, N, M0, M1, M0g, M1g):
+    """Two independent implementations of the same factored algebra -- the fused register-resident MFMA kernels (zigp_kronf.hip: small
+    grids in registers, the reference's 10 x 100 through spill + accumulate) and the GEMM-panel path (zigp_kron.hip) -- on identical
+    inputs: value, KL, every gradient block and the 9-tuple of predictions.  Also: reruns are bit-identical (fixed-order reductions)."""
+    X, Y, p = make_kron_problem(N, M0, M1, seed=9 + M1, M0g=M0g, M1g=M1g)
     a = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=3.0)
-    b = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=3.0)
-    assert a[0] == b[0] and a[1] == b[1]
-    for k in ('u_fm', 'u_gs_sqrt'):
-        assert np.array_equal(a[2][k], b[2][k])
+    a2 = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=3.0)
+    pa = engine.kron_predict(p, X, jitter=1e-6, g_offset=-1.0)
+    engine.set_kron_panels(True)
+    try:
+        b = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=3.0)
+        pb = engine.kron_predict(p, X, jitter=1e-6, g_offset=-1.0)
+    finally:
+        engine.set_kron_panels(False)
+    assert a[0] == a2[0] and a[1] == a2[1] and np.array_equal(a[2]['u_fm'], a2[2]['u_fm']) and np.array_equal(a[2]['Zg'][1], a2[2]['Zg'][1])
+    assert abs(a[0] - b[0]) <= 1e-10 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-10 * abs(b[1])
+    for k in ('u_fm', 'u_gm', 'u_fs_sqrt', 'u_gs_sqrt', 'noise'):
+        assert relerr(a[2][k], b[2][k]) < 1e-7, k
+    for k in ('Zf', 'Zg', 'ell_f', 'ell_g', 'var_f', 'var_g'):
+        for q in range(2):
+            assert relerr(a[2][k][q], b[2][k][q]) < 1e-7, (k, q)
+    for i in range(9):
+        assert relerr(pa[i], pb[i]) < 1e-8, i
 
 
 @pytest.mark.parametrize('M0,M1', [(32, 32), (10, 100)])

@@ -107,7 +107,8 @@ struct zigp_ctx {
   void (*kron_free)(zigp::KronState*) = nullptr;
   zigp::KfState* kronf = nullptr;
   void (*kronf_free)(zigp::KfState*) = nullptr;
-  bool kron_legacy = false;             // diagnostic: force the panel (GEMM-core) Kronecker path
+  bool kron_legacy = false;             // zigp_test_kron_graph: force the panel (GEMM-core) Kronecker path for its duration
+  bool kron_panels = false;             // zigp_set_kron_panels: the same, set by the caller
   std::map<std::string, zigp::TileList> tiles;
   // profiling
   bool prof_on = false;

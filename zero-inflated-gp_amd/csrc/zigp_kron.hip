@@ -536,7 +536,7 @@ int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const doub
              double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
              int lik = ZIGP_LIK_ONOFF, double* d_offset = nullptr, bool dev_xy = false) {
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;
-  if (!c->capturing && !c->kron_legacy && kf_eligible(p, nlat))
+  if (!c->capturing && !c->kron_legacy && !c->kron_panels && kf_eligible(p, nlat))
     return kronf_run(c, p, X, Y, N, jitter, scale, g_offset, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset, dev_xy);
   return kron_run_panels(c, p, X, Y, N, jitter, scale, g_offset, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset, dev_xy);
 }
@@ -777,6 +777,12 @@ int zigp_kron_head_predict(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, 
   return kron_predict_chunked(c, p, Xnew, N, jitter, f_mu, out4, lik, 4);
 }
 
+
+int zigp_set_kron_panels(zigp_ctx* c, int32_t on) {
+  if (!c) return ZIGP_EARG;
+  c->kron_panels = on != 0;
+  return ZIGP_OK;
+}
 
 // Diagnostic: what replaying the minibatch step as a hipGraph would buy.  Runs the step eagerly (allocations, tile lists and
 // kernel attributes settle), captures the same enqueue sequence from both streams into a graph, and times `iters` replays

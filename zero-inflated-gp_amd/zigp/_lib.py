@@ -76,6 +76,7 @@ SIGNATURES = {
     'zigp_kron_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, C.c_int64, C.c_double, C.c_double, dp]),
     'zigp_test_kron_graph': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, dp, C.c_int64, C.c_double, C.c_double, C.c_int32, dp]),
     'zigp_set_overlap': (C.c_int, [C.c_void_p, C.c_int32]),
+    'zigp_set_kron_panels': (C.c_int, [C.c_void_p, C.c_int32]),
     'zigp_set_mean_function': (C.c_int, [C.c_void_p, dp, C.c_int32, C.c_double]),
     'zigp_get_mean_function_grad': (C.c_int, [C.c_void_p, dp, C.c_int32, dp]),
     'zigp_kron_head_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), C.c_int32, dp, dp, C.c_int64, C.c_double, C.c_double,

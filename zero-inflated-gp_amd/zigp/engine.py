@@ -324,6 +324,10 @@ class DenseEngine:
         2 the chunk chains of f and g on two streams (measured 1.5 % slower on cfg3); results are bit-identical in every mode"""
         _check(self.lib, self.ctx, self.lib.zigp_set_overlap(self.ctx, int(on)))
 
+    def set_kron_panels(self, on=True):
+        """diagnostic: route the Kronecker entry points through the GEMM-panel path also for grids the fused kernels cover"""
+        _check(self.lib, self.ctx, self.lib.zigp_set_kron_panels(self.ctx, 1 if on else 0))
+
     def profile_enable(self, on=True):
         _check(self.lib, self.ctx, self.lib.zigp_profile_enable(self.ctx, 1 if on else 0))
 
