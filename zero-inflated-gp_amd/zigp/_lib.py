@@ -17,7 +17,9 @@ PROF_KERNELS = {'gemm_A1': 'gemm_f64_kernel<0,1,2,false,1,4,EpiStoreColsum> (A1 
                 'gemm_J': 'gemm_f64_kernel<1,1,2,false,2,8,EpiSubLoad> (J\' = W^T H - A2)',
                 'syrk': 'gemm_f64_kernel<0,0,2,true,3,4,EpiAccum> (C1 += A1 G A1^T)'}
 
-dp = C.POINTER(C.c_double)
+# double* everywhere in the C-ABI; typed as void* on the Python side so that a plain address (ndarray.ctypes.data, 1 us) can be passed
+# or stored in a struct field -- ndarray.ctypes.data_as(POINTER(c_double)) costs 2.5 us and a Kronecker step hands over ~30 arrays
+dp = C.c_void_p
 
 
 class ZigpError(RuntimeError):
@@ -119,11 +121,13 @@ def load():
 
 
 def as_f64(a, shape=None):
-    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
     if shape is not None:
         a = a.reshape(shape)
     return a
 
 
 def ptr(a):
-    return a.ctypes.data_as(dp)
+    """address of a float64 C-contiguous array (the caller keeps the array alive for the duration of the call)"""
+    return a.ctypes.data
