@@ -237,3 +237,33 @@ def test_kron_predict_chunks_rows(engine):
     ph = {k: p[k] for k in ('Zf', 'ell_f', 'var_f', 'u_fm', 'u_fs_sqrt', 'noise')}
     o4 = engine.kron_head_predict(ph, X, 'gaussian', jitter=1e-6)
     assert o4.shape == (4, 140000) and np.array_equal(o4[:, 131072:], engine.kron_head_predict(ph, X[131072:], 'gaussian', jitter=1e-6))
+
+
+@pytest.mark.parametrize('M0,M1', [(8, 6), (10, 100), (40, 9)])
+def test_kron_not_positive_definite_factor_raises(engine, M0, M1):
+    """tf.cholesky raises InvalidArgumentError on a non-PD factor (onofftf/main.py:355); the engine returns ZIGP_ENOTPD on every
+    path (fused small grid, larger grid, GEMM panels) and keeps working afterwards.  Duplicate inducing points with jitter 0."""
+    import zigp
+    X, Y, p = make_kron_problem(300, M0, M1, seed=4)
+    bad = dict(p, Zf=[p['Zf'][0].copy(), p['Zf'][1].copy()])
+    bad['Zf'][1][-1] = bad['Zf'][1][0]
+    with pytest.raises(zigp.NotPositiveDefiniteError):
+        engine.kron_elbo(bad, X, Y, jitter=0.0)
+    with pytest.raises(zigp.NotPositiveDefiniteError):
+        engine.kron_predict(bad, X, jitter=0.0)
+    ed, kl, g = engine.kron_elbo(p, X, Y, jitter=1e-5)
+    assert np.isfinite(ed) and np.isfinite(kl)
+
+
+def test_kron_tiny_and_ragged_batches(engine):
+    """fewer rows than one 16-point tile, a ragged tile, one inducing point per factor"""
+    import zigp_oracle as o
+    for N, M0, M1 in ((1, 4, 3), (5, 1, 1), (17, 2, 33), (1000, 32, 1)):
+        X, Y, p = make_kron_problem(N, M0, M1, seed=N)
+        out = engine.kron_predict(p, X, jitter=1e-5)
+        ref = o.kron_build_predict(X, p, 1e-5, 0.0)
+        for i in range(9):
+            assert relerr(out[i], ref[i].reshape(-1)) < 1e-7, (N, M0, M1, i)
+        ed, kl, g = engine.kron_elbo(p, X, Y, jitter=1e-5)
+        e_r, d_r, klf, klg = o.kron_elbo(X, Y, p, 1e-5)
+        assert abs(ed - d_r) <= 1e-8 * max(abs(d_r), 1.0) and abs(kl - (klf + klg)) <= 1e-8 * abs(klf + klg)
