@@ -28,7 +28,7 @@ struct KfFac {
   double inv_ell[MAXD];
   double var;
   double zc[MAXD];          // centre of the moment sums (mid-range of Z_p): sum t (x - z)^k is rebuilt from sum t (x - zc)^k
-  const double* Z;          // [M][D]
+  const double* Zs;         // [16 nb][D] inducing inputs divided by the lengthscales, zero rows beyond M (written by k_kf_factor)
   const double* PF;         // P_p in A-fragment order [nb][4 nb][16][4]
 };
 struct KfLat {
@@ -45,6 +45,7 @@ struct KfArgs {
   KfLat lat[2];
   const double* X; int64_t N, Npad; int ldx;
   int tpw;        // tiles per wave
+  int lat0;       // first latent of this launch (latents with different block counts are launched separately)
   int ntiles;     // Npad / 16
 };
 
@@ -67,43 +68,69 @@ __device__ __forceinline__ void kf_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// out[4 rb + r] += sum_ks F(rb, ks)[r] * in[ks]:   out (16 nba rows) = A (16 nba x 4 ksn) . in (4 ksn rows), A in fragment order
+// out[4 rb + r] += sum_ks F(rb, ks)[r] * in[ks]:   out (16 nba rows) = A (16 nba x 4 ksn) . in (4 ksn rows), A in fragment order.
+// k-steps go in chunks of four, double-buffered by hand: the four fragment loads of chunk c + 1 are issued, a compiler barrier pins
+// them there, then come the 16 MFMAs of chunk c.  Left alone the compiler either waits for every load right before its MFMAs (runtime
+// bounds: one LDS round trip per k-step) or hoists all loads of the tile (compile-time bounds: hundreds of live registers, spills).
 template <int NBA, int QK>
 __device__ __forceinline__ void kf_frag_mm(double (&out)[4 * NBA], const double* __restrict__ F, int nba, int ksn, const double (&in)[QK], int slot) {
+  static_assert(QK % 4 == 0, "k-steps come in multiples of four (16-row blocks)");
   const double4* __restrict__ F4 = reinterpret_cast<const double4*>(F);
 #pragma unroll
   for (int rb = 0; rb < NBA; ++rb) {
     if (rb < nba) {
+      const double4* __restrict__ Fr = F4 + rb * ksn * 16 + slot;
+      double4 cur[4];
 #pragma unroll
-      for (int ks = 0; ks < QK; ++ks) {
-        if (ks < ksn) {
-          const double4 a = F4[(rb * ksn + ks) * 16 + slot];
-          out[4 * rb + 0] = kf_mfma(a.x, in[ks], out[4 * rb + 0]);
-          out[4 * rb + 1] = kf_mfma(a.y, in[ks], out[4 * rb + 1]);
-          out[4 * rb + 2] = kf_mfma(a.z, in[ks], out[4 * rb + 2]);
-          out[4 * rb + 3] = kf_mfma(a.w, in[ks], out[4 * rb + 3]);
+      for (int u = 0; u < 4; ++u) cur[u] = Fr[u * 16];
+#pragma unroll
+      for (int kc = 0; kc < QK / 4; ++kc) {
+        if (4 * kc < ksn) {
+          double4 nxt[4];
+          if (4 * (kc + 1) < ksn && kc + 1 < QK / 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nxt[u] = Fr[(4 * (kc + 1) + u) * 16];
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nxt[u] = cur[u];
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double b = in[4 * kc + u];
+            out[4 * rb + 0] = kf_mfma(cur[u].x, b, out[4 * rb + 0]);
+            out[4 * rb + 1] = kf_mfma(cur[u].y, b, out[4 * rb + 1]);
+            out[4 * rb + 2] = kf_mfma(cur[u].z, b, out[4 * rb + 2]);
+            out[4 * rb + 3] = kf_mfma(cur[u].w, b, out[4 * rb + 3]);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
         }
       }
     }
   }
 }
 
-// K_p tile of this wave: K[q] = k_p(z_{4q+g}, x_n) for the lane's point n, 0 for padding rows / points   (kern.K(Z_p, xnew), :199-201)
+// K_p tile of this wave: K[q] = k_p(z_{4q+g}, x_n) for the lane's point n, 0 for padding rows / points   (kern.K(Z_p, xnew), :199-201).
+// zs = Z_p / ell (LDS copy in the small-grid kernels).  The per-lane conditions (padding row, padding point) are SELECTS, not
+// branches: with a branch around each row the 16 loads of z and the 16 exp calls of a tile ran one after the other, each behind
+// its own memory round trip (in-kernel stamps: 21 k cycles for a forward tile whose MFMAs take 4.4 k).
 template <int Q>
-__device__ __forceinline__ void kf_ktile(double (&K)[Q], const KfFac& f, const double* __restrict__ xrow, bool valid, int g) {
+__device__ __forceinline__ void kf_ktile(double (&K)[Q], const KfFac& f, int nb, const double* zs, const double* __restrict__ xrow, bool valid, int g) {
   double xs[MAXD];
 #pragma unroll
-  for (int d = 0; d < MAXD; ++d) xs[d] = (d < f.D && valid) ? xrow[f.col0 + d] * f.inv_ell[d] : 0.0;
+  for (int d = 0; d < MAXD; ++d) xs[d] = (d < f.D) ? xrow[f.col0 + d] * f.inv_ell[d] : 0.0;
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    const int m = 4 * q + g;
     double v = 0.0;
-    if (q < 4 * f.nb && m < f.M && valid) {
+    if (q < 4 * nb) {                         // wave-uniform (compile-time in the EXACT kernels)
+      const int m = 4 * q + g;
       double r2 = 0.0;
 #pragma unroll
       for (int d = 0; d < MAXD; ++d)
-        if (d < f.D) { const double t = f.Z[m * f.D + d] * f.inv_ell[d] - xs[d]; r2 = fma(t, t, r2); }
-      v = f.var * exp(-0.5 * r2);
+        if (d < f.D) { const double t = zs[m * f.D + d] - xs[d]; r2 = fma(t, t, r2); }
+      const double e = f.var * exp(-0.5 * r2);
+      v = (m < f.M && valid) ? e : 0.0;
     }
     K[q] = v;
   }
@@ -119,107 +146,118 @@ __device__ __forceinline__ double kf_colsum(double v) {
 constexpr int KF_Q = 4 * KF_NBMAX;   // registers per [16 nb][16] tile quantity
 constexpr int KF_MQ_ = 16 * KF_NBMAX;
 
-struct KfFwdTile { double K0[KF_Q], K1[KF_Q], A0[KF_Q], A1[KF_Q], B0[KF_Q], C0[KF_Q]; };
-
 // The workgroup's copy of the fragment images in LDS (8 KB each at 32 x 32): every wave re-reads them for every tile, and an LDS
 // read returns in ~100 cycles where an L2 hit takes 500+ (one wave per SIMD has nothing else to hide that behind).
 constexpr int KF_FRAG = KF_MQ_ * KF_MQ_;
-struct KfFrags { const double *P0, *P1, *Al, *S2, *AlT, *S2T; };
+struct KfFrags { const double *P0, *P1, *Al, *S2, *AlT, *S2T; const double *Z0, *Z1; };   // + the scaled inducing inputs
+__device__ __forceinline__ void kf_stage_z(double* dst, const KfFac& f) {
+  for (int idx = threadIdx.x; idx < 16 * f.nb * f.D; idx += blockDim.x) dst[idx] = f.Zs[idx];
+}
 __device__ __forceinline__ void kf_stage_frag(double* dst, const double* __restrict__ src, int n) {   // n is a multiple of 256
   const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
   double2* d2 = reinterpret_cast<double2*>(dst);
 #pragma unroll 4
   for (int idx = threadIdx.x; idx < n / 2; idx += blockDim.x) d2[idx] = s2[idx];
 }
+
+// Per-tile state of one latent for a grid of NB0 x NB1 16-row blocks.  EXACT kernels are instantiated for the block counts they run
+// with: every loop bound is then a compile-time constant, the guards fold away and the compiler issues the fragment loads of a
+// product ahead of its MFMAs.  With runtime bounds each 16 x 16 x 4 step sat behind its own LDS round trip (in-kernel stamps: 21 k
+// cycles for the 64 products of a forward tile whose MFMAs take 4.4 k).
+template <int NB0, int NB1> struct KfTile { double K0[4 * NB0], K1[4 * NB1], A0[4 * NB0], A1[4 * NB1], B0[4 * NB0], C0[4 * NB0]; };
+
 // forward pieces of one tile: A_p = P_p K_p, B0 = Alpha K1, C0 = S2 A1^2
-__device__ __forceinline__ void kf_forward_tile(KfFwdTile& t, const KfLat& L, const KfFrags& F, const double* __restrict__ xrow, bool valid, int g,
-                                                int slot) {
+template <int NB0, int NB1, bool EXACT>
+__device__ __forceinline__ void kf_forward_tile(KfTile<NB0, NB1>& t, const KfLat& L, const KfFrags& F, const double* __restrict__ xrow, bool valid,
+                                                int g, int slot) {
   const KfFac &f0 = L.f[0], &f1 = L.f[1];
-  kf_ktile<KF_Q>(t.K0, f0, xrow, valid, g);
-  kf_ktile<KF_Q>(t.K1, f1, xrow, valid, g);
+  const int nb0 = EXACT ? NB0 : f0.nb, nb1 = EXACT ? NB1 : f1.nb;
+  kf_ktile<4 * NB0>(t.K0, f0, nb0, F.Z0, xrow, valid, g);
+  kf_ktile<4 * NB1>(t.K1, f1, nb1, F.Z1, xrow, valid, g);
 #pragma unroll
-  for (int q = 0; q < KF_Q; ++q) { t.A0[q] = 0.0; t.A1[q] = 0.0; t.B0[q] = 0.0; t.C0[q] = 0.0; }
-  kf_frag_mm<KF_NBMAX, KF_Q>(t.A0, F.P0, f0.nb, 4 * f0.nb, t.K0, slot);
-  kf_frag_mm<KF_NBMAX, KF_Q>(t.A1, F.P1, f1.nb, 4 * f1.nb, t.K1, slot);
-  kf_frag_mm<KF_NBMAX, KF_Q>(t.B0, F.Al, f0.nb, 4 * f1.nb, t.K1, slot);
-  double sq[KF_Q];
+  for (int q = 0; q < 4 * NB0; ++q) { t.A0[q] = 0.0; t.B0[q] = 0.0; t.C0[q] = 0.0; }
 #pragma unroll
-  for (int q = 0; q < KF_Q; ++q) sq[q] = t.A1[q] * t.A1[q];
-  kf_frag_mm<KF_NBMAX, KF_Q>(t.C0, F.S2, f0.nb, 4 * f1.nb, sq, slot);
+  for (int q = 0; q < 4 * NB1; ++q) t.A1[q] = 0.0;
+  kf_frag_mm<NB0, 4 * NB0>(t.A0, F.P0, nb0, 4 * nb0, t.K0, slot);
+  kf_frag_mm<NB1, 4 * NB1>(t.A1, F.P1, nb1, 4 * nb1, t.K1, slot);
+  kf_frag_mm<NB0, 4 * NB1>(t.B0, F.Al, nb0, 4 * nb1, t.K1, slot);
+  double sq[4 * NB1];
+#pragma unroll
+  for (int q = 0; q < 4 * NB1; ++q) sq[q] = t.A1[q] * t.A1[q];
+  kf_frag_mm<NB0, 4 * NB1>(t.C0, F.S2, nb0, 4 * nb1, sq, slot);
 }
 
 // ---- forward: part[0..3][n] = q0 = k0.a0, q1 = k1.a1, mean = k0^T Alpha k1, st = (a0^2)^T S2 (a1^2) -------------------------
+template <int NB0, int NB1>
 __global__ void __launch_bounds__(64 * KF_WAVES)
 k_kf_forward(KfArgs a) {
   __shared__ double sfr[4 * KF_FRAG];
-  const KfLat& L = a.lat[blockIdx.y];
+  __shared__ double sz[2][KF_MQ_ * MAXD];
+  const KfLat& L = a.lat[a.lat0 + blockIdx.y];
   {
-    const int n0 = L.f[0].nb * L.f[0].nb * 256, n1 = L.f[1].nb * L.f[1].nb * 256, n01 = L.f[0].nb * L.f[1].nb * 256;
+    constexpr int n0 = NB0 * NB0 * 256, n1 = NB1 * NB1 * 256, n01 = NB0 * NB1 * 256;
     kf_stage_frag(sfr, L.f[0].PF, n0); kf_stage_frag(sfr + KF_FRAG, L.f[1].PF, n1);
     kf_stage_frag(sfr + 2 * KF_FRAG, L.AlF, n01); kf_stage_frag(sfr + 3 * KF_FRAG, L.S2F, n01);
+    kf_stage_z(sz[0], L.f[0]); kf_stage_z(sz[1], L.f[1]);
     __syncthreads();
   }
-  const KfFrags F = {sfr, sfr + KF_FRAG, sfr + 2 * KF_FRAG, sfr + 3 * KF_FRAG, nullptr, nullptr};
+  const KfFrags F = {sfr, sfr + KF_FRAG, sfr + 2 * KF_FRAG, sfr + 3 * KF_FRAG, nullptr, nullptr, sz[0], sz[1]};
   const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
   for (int tile = w * a.tpw; tile < t1; ++tile) {
     const int64_t pn = (int64_t)tile * 16 + n;
     const bool valid = pn < a.N;
-    KfFwdTile t;
-    kf_forward_tile(t, L, F, a.X + (valid ? pn : 0) * a.ldx, valid, g, slot);
+    KfTile<NB0, NB1> t;
+    kf_forward_tile<NB0, NB1, true>(t, L, F, a.X + (valid ? pn : 0) * a.ldx, valid, g, slot);
     double q0 = 0.0, q1 = 0.0, mu = 0.0, st = 0.0;
 #pragma unroll
-    for (int q = 0; q < KF_Q; ++q) {
+    for (int q = 0; q < 4 * NB0; ++q) {
       q0 = fma(t.K0[q], t.A0[q], q0);
-      q1 = fma(t.K1[q], t.A1[q], q1);
       mu = fma(t.K0[q], t.B0[q], mu);
       st = fma(t.A0[q] * t.A0[q], t.C0[q], st);
     }
+#pragma unroll
+    for (int q = 0; q < 4 * NB1; ++q) q1 = fma(t.K1[q], t.A1[q], q1);
     q0 = kf_colsum(q0); q1 = kf_colsum(q1); mu = kf_colsum(mu); st = kf_colsum(st);
     if (g == 0) { L.part[pn] = q0; L.part[a.Npad + pn] = q1; L.part[2 * a.Npad + pn] = mu; L.part[3 * a.Npad + pn] = st; }
   }
 }
 
 // tile in registers -> LDS image [row][KF_LD]
-__device__ __forceinline__ void kf_store_tile(double* T, const double (&V)[KF_Q], int nb, int g, int n) {
+template <int Q>
+__device__ __forceinline__ void kf_store_tile(double* T, const double (&V)[Q], int g, int n) {
 #pragma unroll
-  for (int q = 0; q < KF_Q; ++q)
-    if (q < 4 * nb) T[(4 * q + g) * KF_LD + n] = V[q];
+  for (int q = 0; q < Q; ++q) T[(4 * q + g) * KF_LD + n] = V[q];
 }
 // acc[(rb, cb)] += A(rows of rb, 16 points) . B(16 points, cols of cb), A / B from LDS tiles (rows x points), optional squares and
 // per-point scale on B;  MODE 0: plain, 1: both squared
-template <int NBR, int NBC, int MODE>
-__device__ __forceinline__ void kf_accum(double (&acc)[NBR * NBC][4], const double* TA, int nbr, const double* TB, int nbc,
-                                         const double (&sck)[4], bool scaled, int lane) {
+template <int NBR, int NBC, int MODE, bool SCALED>
+__device__ __forceinline__ void kf_accum(double (&acc)[NBR * NBC][4], const double* TA, const double* TB, const double (&sck)[4], int lane) {
   const int ai = lane & 3, kk = lane >> 4, bj = lane & 15;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     double bf[NBC];
 #pragma unroll
     for (int cb = 0; cb < NBC; ++cb) {
-      double b = (cb < nbc) ? TB[(16 * cb + bj) * KF_LD + 4 * ks + kk] : 0.0;
+      double b = TB[(16 * cb + bj) * KF_LD + 4 * ks + kk];
       if (MODE == 1) b *= b;
-      if (scaled) b *= sck[ks];
+      if (SCALED) b *= sck[ks];
       bf[cb] = b;
     }
 #pragma unroll
     for (int rb = 0; rb < NBR; ++rb) {
-      if (rb < nbr) {
-        double af[4];
+      double af[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double v = TA[(16 * rb + 4 * r + ai) * KF_LD + 4 * ks + kk];
-          if (MODE == 1) v *= v;
-          af[r] = v;
-        }
-#pragma unroll
-        for (int cb = 0; cb < NBC; ++cb)
-          if (cb < nbc) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rb * NBC + cb][r] = kf_mfma(af[r], bf[cb], acc[rb * NBC + cb][r]);
-          }
+      for (int r = 0; r < 4; ++r) {
+        double v = TA[(16 * rb + 4 * r + ai) * KF_LD + 4 * ks + kk];
+        if (MODE == 1) v *= v;
+        af[r] = v;
       }
+#pragma unroll
+      for (int cb = 0; cb < NBC; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[rb * NBC + cb][r] = kf_mfma(af[r], bf[cb], acc[rb * NBC + cb][r]);
     }
   }
 }
@@ -229,144 +267,166 @@ __device__ __forceinline__ void kf_accum(double (&acc)[NBR * NBC][4], const doub
 //   B1 = Alpha^T K0, C1 = S2^T A0^2 ;  dA_p = 2 gv A_p . C_p ;  dK_p = gm B_p + 2 dq_p A_p + P_p dA_p ;  E_p = dq_p K_p + dA_p
 //   dAlpha += K0 diag(gm) K1^T ; dS2 += A0^2 diag(gv) (A1^2)^T ; dP_p += E_p K_p^T
 //   moments of t_p = dK_p . K_p against {1, x - zc, (x - zc)^2}  (-> d var_p, d Z_p, d ell_p in k_kf_finish)
+template <int NB0, int NB1>
 __global__ void __launch_bounds__(64 * KF_WAVES, 1)
 k_kf_backward(KfArgs a) {
   extern __shared__ double lds[];
-  const KfLat& L = a.lat[blockIdx.y];
+  const KfLat& L = a.lat[a.lat0 + blockIdx.y];
   const KfFac &f0 = L.f[0], &f1 = L.f[1];
   const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
   const int wib = threadIdx.x >> 6;
   const int w = blockIdx.x * KF_WAVES + wib;
+  constexpr int Q0 = 4 * NB0, Q1 = 4 * NB1;
   constexpr int TILE = 16 * KF_NBMAX * KF_LD;
   double* bK0 = lds + wib * 4 * TILE; double* bK1 = bK0 + TILE; double* c0 = bK1 + TILE; double* c1 = c0 + TILE;
   double* sfr = lds + KF_WAVES * 4 * TILE;
   {
-    const int n0 = f0.nb * f0.nb * 256, n1 = f1.nb * f1.nb * 256, n01 = f0.nb * f1.nb * 256;
+    constexpr int n0 = NB0 * NB0 * 256, n1 = NB1 * NB1 * 256, n01 = NB0 * NB1 * 256;
     kf_stage_frag(sfr, f0.PF, n0); kf_stage_frag(sfr + KF_FRAG, f1.PF, n1);
     kf_stage_frag(sfr + 2 * KF_FRAG, L.AlF, n01); kf_stage_frag(sfr + 3 * KF_FRAG, L.S2F, n01);
     kf_stage_frag(sfr + 4 * KF_FRAG, L.AlTF, n01); kf_stage_frag(sfr + 5 * KF_FRAG, L.S2TF, n01);
+    kf_stage_z(sfr + 6 * KF_FRAG, f0); kf_stage_z(sfr + 6 * KF_FRAG + KF_MQ_ * MAXD, f1);
     __syncthreads();
   }
-  const KfFrags F = {sfr, sfr + KF_FRAG, sfr + 2 * KF_FRAG, sfr + 3 * KF_FRAG, sfr + 4 * KF_FRAG, sfr + 5 * KF_FRAG};
-  double accAl[KF_NBMAX * KF_NBMAX][4], accS2[KF_NBMAX * KF_NBMAX][4], accP0[KF_NBMAX * KF_NBMAX][4], accP1[KF_NBMAX * KF_NBMAX][4];
-  double accK0[KF_NBMAX][4], accK1[KF_NBMAX][4];
+  const KfFrags F = {sfr, sfr + KF_FRAG, sfr + 2 * KF_FRAG, sfr + 3 * KF_FRAG, sfr + 4 * KF_FRAG, sfr + 5 * KF_FRAG,
+                     sfr + 6 * KF_FRAG, sfr + 6 * KF_FRAG + KF_MQ_ * MAXD};
+  double accAl[NB0 * NB1][4], accS2[NB0 * NB1][4], accP0[NB0 * NB0][4], accP1[NB1 * NB1][4], accK0[NB0][4], accK1[NB1][4];
 #pragma unroll
-  for (int b = 0; b < KF_NBMAX * KF_NBMAX; ++b)
+  for (int r = 0; r < 4; ++r) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { accAl[b][r] = 0.0; accS2[b][r] = 0.0; accP0[b][r] = 0.0; accP1[b][r] = 0.0; }
+    for (int b = 0; b < NB0 * NB1; ++b) { accAl[b][r] = 0.0; accS2[b][r] = 0.0; }
 #pragma unroll
-  for (int b = 0; b < KF_NBMAX; ++b)
+    for (int b = 0; b < NB0 * NB0; ++b) accP0[b][r] = 0.0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { accK0[b][r] = 0.0; accK1[b][r] = 0.0; }
+    for (int b = 0; b < NB1 * NB1; ++b) accP1[b][r] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB0; ++b) accK0[b][r] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB1; ++b) accK1[b][r] = 0.0;
+  }
   const double one4[4] = {1.0, 1.0, 1.0, 1.0};
+  // column j = n of the moment matrix Psi_p: 0 -> 1, 1..D -> x_d - zc_d, D+1..2D -> (x_d - zc_d)^2, beyond -> 0   (fixed per lane)
+  int psi_kind[2], psi_col[2]; double psi_zc[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const KfFac& f = L.f[p];
+    const int d = (n == 0) ? 0 : ((n <= f.D) ? n - 1 : ((n <= 2 * f.D) ? n - 1 - f.D : 0));
+    psi_kind[p] = (n == 0) ? 0 : ((n <= f.D) ? 1 : ((n <= 2 * f.D) ? 2 : 3));
+    psi_col[p] = f.col0 + d; psi_zc[p] = f.zc[d];
+  }
 
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
   for (int tile = w * a.tpw; tile < t1; ++tile) {
     const int64_t pn = (int64_t)tile * 16 + n;
     const bool valid = pn < a.N;
     const double* xrow = a.X + (valid ? pn : 0) * a.ldx;
-    KfFwdTile t;
-    kf_forward_tile(t, L, F, xrow, valid, g, slot);
+    KfTile<NB0, NB1> t;
+    kf_forward_tile<NB0, NB1, true>(t, L, F, xrow, valid, g, slot);
     const double gmn = L.gm[pn], gvn = L.gv[pn], dq0n = L.dq0[pn], dq1n = L.dq1[pn];   // zero for padding points (scale 0 in the point-wise kernel)
-    double B1[KF_Q], C1[KF_Q], sq[KF_Q];
+    double B1[Q1], C1[Q1], sq[Q0];
 #pragma unroll
-    for (int q = 0; q < KF_Q; ++q) { B1[q] = 0.0; C1[q] = 0.0; sq[q] = t.A0[q] * t.A0[q]; }
-    kf_frag_mm<KF_NBMAX, KF_Q>(B1, F.AlT, f1.nb, 4 * f0.nb, t.K0, slot);
-    kf_frag_mm<KF_NBMAX, KF_Q>(C1, F.S2T, f1.nb, 4 * f0.nb, sq, slot);
-    double dA0[KF_Q], dA1[KF_Q], PdA0[KF_Q], PdA1[KF_Q];
+    for (int q = 0; q < Q1; ++q) { B1[q] = 0.0; C1[q] = 0.0; }
 #pragma unroll
-    for (int q = 0; q < KF_Q; ++q) {
-      dA0[q] = 2.0 * gvn * t.A0[q] * t.C0[q];
-      dA1[q] = 2.0 * gvn * t.A1[q] * C1[q];
-      PdA0[q] = 0.0; PdA1[q] = 0.0;
-    }
-    kf_frag_mm<KF_NBMAX, KF_Q>(PdA0, F.P0, f0.nb, 4 * f0.nb, dA0, slot);
-    kf_frag_mm<KF_NBMAX, KF_Q>(PdA1, F.P1, f1.nb, 4 * f1.nb, dA1, slot);
+    for (int q = 0; q < Q0; ++q) sq[q] = t.A0[q] * t.A0[q];
+    kf_frag_mm<NB1, Q0>(B1, F.AlT, NB1, Q0, t.K0, slot);
+    kf_frag_mm<NB1, Q0>(C1, F.S2T, NB1, Q0, sq, slot);
+    double dA0[Q0], dA1[Q1], PdA0[Q0], PdA1[Q1];
+#pragma unroll
+    for (int q = 0; q < Q0; ++q) { dA0[q] = 2.0 * gvn * t.A0[q] * t.C0[q]; PdA0[q] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < Q1; ++q) { dA1[q] = 2.0 * gvn * t.A1[q] * C1[q]; PdA1[q] = 0.0; }
+    kf_frag_mm<NB0, Q0>(PdA0, F.P0, NB0, Q0, dA0, slot);
+    kf_frag_mm<NB1, Q1>(PdA1, F.P1, NB1, Q1, dA1, slot);
     // ---- LDS images for the sums over points (k index = point): K tiles, E tiles
-    kf_store_tile(bK0, t.K0, f0.nb, g, n);
-    kf_store_tile(bK1, t.K1, f1.nb, g, n);
+    kf_store_tile<Q0>(bK0, t.K0, g, n);
+    kf_store_tile<Q1>(bK1, t.K1, g, n);
     {
-      double E[KF_Q];
+      double E0[Q0], E1[Q1];
 #pragma unroll
-      for (int q = 0; q < KF_Q; ++q) E[q] = fma(dq0n, t.K0[q], dA0[q]);
-      kf_store_tile(c0, E, f0.nb, g, n);
+      for (int q = 0; q < Q0; ++q) E0[q] = fma(dq0n, t.K0[q], dA0[q]);
+      kf_store_tile<Q0>(c0, E0, g, n);
 #pragma unroll
-      for (int q = 0; q < KF_Q; ++q) E[q] = fma(dq1n, t.K1[q], dA1[q]);
-      kf_store_tile(c1, E, f1.nb, g, n);
+      for (int q = 0; q < Q1; ++q) E1[q] = fma(dq1n, t.K1[q], dA1[q]);
+      kf_store_tile<Q1>(c1, E1, g, n);
     }
     kf_wave_sync();
     double gmk[4], gvk[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { gmk[ks] = __shfl(gmn, 4 * ks + g, 64); gvk[ks] = __shfl(gvn, 4 * ks + g, 64); }
-    kf_accum<KF_NBMAX, KF_NBMAX, 0>(accAl, bK0, f0.nb, bK1, f1.nb, gmk, true, lane);
-    kf_accum<KF_NBMAX, KF_NBMAX, 0>(accP0, c0, f0.nb, bK0, f0.nb, one4, false, lane);
-    kf_accum<KF_NBMAX, KF_NBMAX, 0>(accP1, c1, f1.nb, bK1, f1.nb, one4, false, lane);
+    kf_accum<NB0, NB1, 0, true>(accAl, bK0, bK1, gmk, lane);
+    kf_accum<NB0, NB0, 0, false>(accP0, c0, bK0, one4, lane);
+    kf_accum<NB1, NB1, 0, false>(accP1, c1, bK1, one4, lane);
     kf_wave_sync();
-    kf_store_tile(c0, t.A0, f0.nb, g, n);
-    kf_store_tile(c1, t.A1, f1.nb, g, n);
+    // B operand of the moment products: lane (kk = g, column j = n) needs psi_j of point 4 ks + g -- loaded here (most of the tile state
+    // is dead by now), the round trip hides behind the dS2 products
+    double psi[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int64_t pt = (int64_t)tile * 16 + 4 * ks + g;
+        double v = psi_kind[p] == 0 ? 1.0 : 0.0;
+        if (psi_kind[p] >= 1 && psi_kind[p] <= 2 && pt < a.N) {
+          const double xv = a.X[pt * a.ldx + psi_col[p]] - psi_zc[p];
+          v = psi_kind[p] == 1 ? xv : xv * xv;
+        }
+        psi[p][ks] = (pt < a.N) ? v : 0.0;
+      }
+    kf_store_tile<Q0>(c0, t.A0, g, n);
+    kf_store_tile<Q1>(c1, t.A1, g, n);
     kf_wave_sync();
-    kf_accum<KF_NBMAX, KF_NBMAX, 1>(accS2, c0, f0.nb, c1, f1.nb, gvk, true, lane);
+    kf_accum<NB0, NB1, 1, true>(accS2, c0, c1, gvk, lane);
     kf_wave_sync();
     {
-      double tt[KF_Q];
+      double t0[Q0], t1v[Q1];
 #pragma unroll
-      for (int q = 0; q < KF_Q; ++q) tt[q] = fma(gmn, t.B0[q], fma(2.0 * dq0n, t.A0[q], PdA0[q])) * t.K0[q];
-      kf_store_tile(c0, tt, f0.nb, g, n);
+      for (int q = 0; q < Q0; ++q) t0[q] = fma(gmn, t.B0[q], fma(2.0 * dq0n, t.A0[q], PdA0[q])) * t.K0[q];
+      kf_store_tile<Q0>(c0, t0, g, n);
 #pragma unroll
-      for (int q = 0; q < KF_Q; ++q) tt[q] = fma(gmn, B1[q], fma(2.0 * dq1n, t.A1[q], PdA1[q])) * t.K1[q];
-      kf_store_tile(c1, tt, f1.nb, g, n);
+      for (int q = 0; q < Q1; ++q) t1v[q] = fma(gmn, B1[q], fma(2.0 * dq1n, t.A1[q], PdA1[q])) * t.K1[q];
+      kf_store_tile<Q1>(c1, t1v, g, n);
     }
     kf_wave_sync();
     // moments: acc(rows of factor p, col j) += sum_n t_p[row, n] psi_j(x_n),  psi = {1, xc_d, xc_d^2}
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const KfFac& f = L.f[p];
-      double xc[MAXD];
+    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int d = 0; d < MAXD; ++d) xc[d] = (d < f.D && valid) ? xrow[f.col0 + d] - f.zc[d] : 0.0;
-      const double* T = p == 0 ? c0 : c1;
+      for (int rb = 0; rb < NB0; ++rb)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        double psi = (n == 0) ? 1.0 : 0.0;
+        for (int r = 0; r < 4; ++r)
+          accK0[rb][r] = kf_mfma(c0[(16 * rb + 4 * r + (lane & 3)) * KF_LD + 4 * ks + g], psi[0][ks], accK0[rb][r]);
 #pragma unroll
-        for (int d = 0; d < MAXD; ++d)
-          if (d < f.D) {
-            const double xv = __shfl(xc[d], 4 * ks + g, 64);
-            if (n == 1 + d) psi = xv;
-            if (n == 1 + f.D + d) psi = xv * xv;
-          }
+      for (int rb = 0; rb < NB1; ++rb)
 #pragma unroll
-        for (int rb = 0; rb < KF_NBMAX; ++rb)
-          if (rb < f.nb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const double av = T[(16 * rb + 4 * r + (lane & 3)) * KF_LD + 4 * ks + g];
-              if (p == 0) accK0[rb][r] = kf_mfma(av, psi, accK0[rb][r]);
-              else accK1[rb][r] = kf_mfma(av, psi, accK1[rb][r]);
-            }
-          }
-      }
+        for (int r = 0; r < 4; ++r)
+          accK1[rb][r] = kf_mfma(c1[(16 * rb + 4 * r + (lane & 3)) * KF_LD + 4 * ks + g], psi[1][ks], accK1[rb][r]);
     }
     kf_wave_sync();
   }
-  // per-wave partials, [block][r][lane]
+  // per-wave partials, [block][r][lane]; blocks numbered for the CAPACITY grid (KF_NBMAX x KF_NBMAX) that k_kf_reduce / k_kf_finish index
   double* out = L.acc + (int64_t)w * KF_ACC_DOUBLES;
 #pragma unroll
-  for (int b = 0; b < KF_NBMAX * KF_NBMAX; ++b)
+  for (int r = 0; r < 4; ++r) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      out[((KF_B_AL + b) * 4 + r) * 64 + lane] = accAl[b][r];
-      out[((KF_B_S2 + b) * 4 + r) * 64 + lane] = accS2[b][r];
-      out[((KF_B_P0 + b) * 4 + r) * 64 + lane] = accP0[b][r];
-      out[((KF_B_P1 + b) * 4 + r) * 64 + lane] = accP1[b][r];
-    }
+    for (int rb = 0; rb < NB0; ++rb)
 #pragma unroll
-  for (int b = 0; b < KF_NBMAX; ++b)
+      for (int cb = 0; cb < NB1; ++cb) {
+        out[((KF_B_AL + rb * KF_NBMAX + cb) * 4 + r) * 64 + lane] = accAl[rb * NB1 + cb][r];
+        out[((KF_B_S2 + rb * KF_NBMAX + cb) * 4 + r) * 64 + lane] = accS2[rb * NB1 + cb][r];
+      }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      out[((KF_B_K0 + b) * 4 + r) * 64 + lane] = accK0[b][r];
-      out[((KF_B_K1 + b) * 4 + r) * 64 + lane] = accK1[b][r];
-    }
+    for (int rb = 0; rb < NB0; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < NB0; ++cb) out[((KF_B_P0 + rb * KF_NBMAX + cb) * 4 + r) * 64 + lane] = accP0[rb * NB0 + cb][r];
+#pragma unroll
+    for (int rb = 0; rb < NB1; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < NB1; ++cb) out[((KF_B_P1 + rb * KF_NBMAX + cb) * 4 + r) * 64 + lane] = accP1[rb * NB1 + cb][r];
+#pragma unroll
+    for (int rb = 0; rb < NB0; ++rb) out[((KF_B_K0 + rb) * 4 + r) * 64 + lane] = accK0[rb][r];
+#pragma unroll
+    for (int rb = 0; rb < NB1; ++rb) out[((KF_B_K1 + rb) * 4 + r) * 64 + lane] = accK1[rb][r];
+  }
 }
 
 // ---- fixed-order sum of the partial accumulators; un-permutes the accumulator layout into row-major matrices ------------------
@@ -440,6 +500,7 @@ struct KfFactorJob {
   double* P;        // [Mq][Mq] row-major K^-1 (zero padded)
   double* PF;       // fragment order
   double* dvec;     // [Mq] diag(P), then dvec[Mq] = logdet K = sum log L_ii^2
+  double* Zs;       // [Mq][D] Z / ell, zero rows beyond M (the point kernels' K tiles)
 };
 struct KfFactorArgs { KfFactorJob job[4]; double jitter; int* info; };
 
@@ -464,6 +525,7 @@ k_kf_factor(KfFactorArgs a) {
   __shared__ double red[16];
   const KfFactorJob& jb = a.job[blockIdx.x];
   const int t = threadIdx.x, M = jb.M, Mq = jb.Mq, D = jb.D;
+  for (int idx = t; idx < Mq * D; idx += 1024) { const int m = idx / D, d = idx - m * D; jb.Zs[idx] = m < M ? jb.Z[idx] * jb.inv_ell[d] : 0.0; }
   const int nreal = ((M + PNB - 1) / PNB) * PNB;   // the factorisation touches the 32-column panels that hold real rows only
   for (int idx = t; idx < nreal * nreal; idx += 1024) {
     const int i = idx / nreal, j = idx - i * nreal;
@@ -722,7 +784,7 @@ namespace zigp {
 // =============================================================================================================================
 // host orchestration
 // =============================================================================================================================
-constexpr size_t KF_BWD_LDS = sizeof(double) * (KF_WAVES * 4 * 16 * KF_NBMAX * KF_LD + 6 * KF_FRAG);
+constexpr size_t KF_BWD_LDS = sizeof(double) * (KF_WAVES * 4 * 16 * KF_NBMAX * KF_LD + 6 * KF_FRAG + 2 * KF_MQ_ * MAXD);
 struct KfState {
   DevBuf in, mat, pts, acc, res, out, spill;
 };
@@ -746,6 +808,37 @@ static KfPlan kf_plan(const zigp_kron_params* p, int nlat) {
   return pl;
 }
 static bool kf_eligible(const zigp_kron_params* p, int nlat) { return kf_plan(p, nlat).ok; }
+
+// launch helpers: the small-grid kernels are instantiated for the exact block counts (1 or 2 per factor)
+template <int NB0, int NB1>
+static int kf_launch_small(zigp_ctx* c, bool backward, dim3 grid, const KfArgs& ka) {
+  if (backward) {
+    static bool attr = false;
+    if (!attr) {
+      ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_backward<NB0, NB1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KF_BWD_LDS));
+      attr = true;
+    }
+    hipLaunchKernelGGL((k_kf_backward<NB0, NB1>), grid, dim3(64 * KF_WAVES), KF_BWD_LDS, c->stream, ka);
+  } else {
+    hipLaunchKernelGGL((k_kf_forward<NB0, NB1>), grid, dim3(64 * KF_WAVES), 0, c->stream, ka);
+  }
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+static int kf_launch_small(zigp_ctx* c, int nb0, int nb1, bool backward, dim3 grid, const KfArgs& ka) {
+  if (nb0 == 1 && nb1 == 1) return kf_launch_small<1, 1>(c, backward, grid, ka);
+  if (nb0 == 1 && nb1 == 2) return kf_launch_small<1, 2>(c, backward, grid, ka);
+  if (nb0 == 2 && nb1 == 1) return kf_launch_small<2, 1>(c, backward, grid, ka);
+  return kf_launch_small<2, 2>(c, backward, grid, ka);
+}
+// one launch for both latents when their block counts agree, else one per latent (KfArgs::lat0 selects it)
+static int kf_launch_small_latents(zigp_ctx* c, const int (*Mq)[2], int nlat, bool backward, unsigned gx, KfArgs& ka) {
+  const bool same = nlat == 1 || (Mq[0][0] == Mq[1][0] && Mq[0][1] == Mq[1][1]);
+  if (same) { ka.lat0 = 0; return kf_launch_small(c, Mq[0][0] / 16, Mq[0][1] / 16, backward, dim3(gx, nlat), ka); }
+  for (int h = 0; h < nlat; ++h) { ka.lat0 = h; ZIGP_TRY(kf_launch_small(c, Mq[h][0] / 16, Mq[h][1] / 16, backward, dim3(gx, 1), ka)); }
+  ka.lat0 = 0;
+  return 0;
+}
 
 struct KfHostLatent { int M[2]; const double* Z[2]; const double* ell[2]; double var[2]; const double* u; const double* s; };
 constexpr int KF_KROW_W = 2 + 2 * MAXD;
@@ -772,7 +865,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   const size_t r01 = (size_t)R0 * R1;
   // per-factor region of KfState::mat: K [128][128] | P | PF | dvec ; per-latent: U S2 T0 T1 Al | AlF S2F AlTF S2TF | work | scratch
   const size_t rmax = (size_t)wl.ldw * wl.ldw;
-  const size_t FAC_P = (size_t)PB * PB, FAC_PF = FAC_P + rmax, FAC_DV = FAC_PF + rmax, FAC_SIZE = FAC_DV + wl.ldw + 8;
+  const size_t FAC_P = (size_t)PB * PB, FAC_PF = FAC_P + rmax, FAC_DV = FAC_PF + rmax, FAC_ZS = FAC_DV + wl.ldw + 8, FAC_SIZE = FAC_ZS + (size_t)wl.ldw * MAXD;
   const size_t LAT_U = 0, LAT_S2 = r01, LAT_T0 = 2 * r01, LAT_T1 = 3 * r01, LAT_AL = 4 * r01, LAT_ALF = 5 * r01, LAT_S2F = 6 * r01, LAT_ALTF = 7 * r01,
                LAT_S2TF = 8 * r01, LAT_WORK = 9 * r01, LAT_SCR = LAT_WORK + wl.total, SCR_SET = 3 * rmax + r01, LAT_SIZE = LAT_SCR + 2 * SCR_SET;
   const size_t RES_KLV = 0, RES_KROW0 = 8, RES_KROW1 = RES_KROW0 + (size_t)R0 * KF_KROW_W, RES_GU = RES_KROW1 + (size_t)R1 * KF_KROW_W,
@@ -818,6 +911,8 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   int Mq[2][2];
   for (int h = 0; h < nlat; ++h)
     for (int q = 0; q < 2; ++q) Mq[h][q] = (int)round_up(hl[h].M[q], 16);
+  bool large_exact = pl.large;   // every latent has exactly the capacity's block counts: the instantiation with compile-time bounds
+  for (int h = 0; h < nlat; ++h) large_exact = large_exact && Mq[h][0] == 16 * pl.nb0c && Mq[h][1] == 16 * pl.nb1c;
   // LDS of the larger-grid point kernels: fragment images packed by the actual block counts (max over the latents)
   size_t lds_fwd = 0, lds_bwd = 0;
   for (int h = 0; h < nlat; ++h) {
@@ -828,10 +923,11 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   static bool attr_set = false;
   if (!attr_set) {
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * PB * PBLD)));
-    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_backward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KF_BWD_LDS));
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KF_FIN_LDS));
-    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_forward<1, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_backward<1, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_forward<1, 7, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_backward<1, 7, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_forward<1, 7, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_backward<1, 7, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   // ---- factor stage
@@ -846,7 +942,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
         jb.Z = ks.in.p + off_z[h][q]; jb.M = M; jb.D = D; jb.Mq = Mq[h][q];
         for (int d = 0; d < MAXD; ++d) jb.inv_ell[d] = d < D ? 1.0 / hl[h].ell[q][d] : 0.0;
         jb.var = hl[h].var[q];
-        jb.K = fac(h, q); jb.P = fac(h, q) + FAC_P; jb.PF = fac(h, q) + FAC_PF; jb.dvec = fac(h, q) + FAC_DV;
+        jb.K = fac(h, q); jb.P = fac(h, q) + FAC_P; jb.PF = fac(h, q) + FAC_PF; jb.dvec = fac(h, q) + FAC_DV; jb.Zs = fac(h, q) + FAC_ZS;
         for (int d = 0; d < MAXD; ++d) {
           double lo = 0.0, hi = 0.0;
           if (d < D) {
@@ -892,7 +988,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       f.M = hl[h].M[q]; f.nb = Mq[h][q] / 16; f.D = D; f.col0 = q == 0 ? 0 : D0;
       for (int d = 0; d < MAXD; ++d) { f.inv_ell[d] = d < D ? 1.0 / hl[h].ell[q][d] : 0.0; f.zc[d] = zc[h][q][d]; }
       f.var = hl[h].var[q];
-      f.Z = ks.in.p + off_z[h][q]; f.PF = fac(h, q) + FAC_PF;
+      f.Zs = fac(h, q) + FAC_ZS; f.PF = fac(h, q) + FAC_PF;
     }
     double* Lm = lat(h);
     L.AlF = Lm + LAT_ALF; L.S2F = Lm + LAT_S2F; L.AlTF = Lm + LAT_ALTF; L.S2TF = Lm + LAT_S2TF;
@@ -905,9 +1001,9 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     ka.tpw = (ka.ntiles + waves - 1) / waves;
     const int nw = (ka.ntiles + ka.tpw - 1) / ka.tpw;
     const dim3 grid((nw + KF_WAVES - 1) / KF_WAVES, nlat);
-    if (pl.large && ka.tpw > 0) hipLaunchKernelGGL((k_kfl_forward<1, 7, true>), grid, dim3(64 * KF_WAVES), lds_fwd, c->stream, ka);
-    else if (pl.large) hipLaunchKernelGGL((k_kfl_forward<1, 7, false>), grid, dim3(64 * KF_WAVES), 0, c->stream, ka);
-    else hipLaunchKernelGGL(k_kf_forward, grid, dim3(64 * KF_WAVES), 0, c->stream, ka);
+    if (pl.large && large_exact) hipLaunchKernelGGL((k_kfl_forward<1, 7, true, true>), grid, dim3(64 * KF_WAVES), lds_fwd, c->stream, ka);
+    else if (pl.large) hipLaunchKernelGGL((k_kfl_forward<1, 7, true, false>), grid, dim3(64 * KF_WAVES), lds_fwd, c->stream, ka);
+    else ZIGP_TRY(kf_launch_small_latents(c, Mq, nlat, false, grid.x, ka));
     ZIGP_HIP(c, hipGetLastError());
   }
   KronPwArgs a;
@@ -941,16 +1037,15 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       nparts = nwg * KF_WAVES;
       ZIGP_ENSURE(c, ks.acc, (size_t)2 * nparts * nblk * 256);
       for (int h = 0; h < nlat; ++h) ka.lat[h].acc = ks.acc.p + (size_t)h * nparts * nblk * 256;
-      hipLaunchKernelGGL(k_kf_backward, dim3(nwg, nlat), dim3(64 * KF_WAVES), KF_BWD_LDS, c->stream, ka);
-      ZIGP_HIP(c, hipGetLastError());
+      ZIGP_TRY(kf_launch_small_latents(c, Mq, nlat, true, (unsigned)nwg, ka));
     } else {
       size_t rec[2] = {0, 0}, spill_total = 0;
       for (int h = 0; h < nlat; ++h) { rec[h] = (size_t)64 * (Mq[h][0] + Mq[h][1]); spill_total += rec[h] * ka.ntiles; }
       ZIGP_ENSURE(c, ks.spill, spill_total);
       ka.lat[0].spill = ks.spill.p;
       if (nlat == 2) ka.lat[1].spill = ks.spill.p + rec[0] * ka.ntiles;
-      if (ka.tpw > 0) hipLaunchKernelGGL((k_kfl_backward<1, 7, true>), dim3(nwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
-      else hipLaunchKernelGGL((k_kfl_backward<1, 7, false>), dim3(nwg, nlat), dim3(64 * KF_WAVES), 0, c->stream, ka);
+      if (large_exact) hipLaunchKernelGGL((k_kfl_backward<1, 7, true, true>), dim3(nwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
+      else hipLaunchKernelGGL((k_kfl_backward<1, 7, true, false>), dim3(nwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
       ZIGP_HIP(c, hipGetLastError());
       // sums over points: one wave per output block and split of tps tiles (4 for a minibatch: the chain of dependent loads is short)
       const int tps = std::max(4, std::min(64, ka.ntiles / 16));

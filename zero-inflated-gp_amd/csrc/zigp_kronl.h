@@ -5,14 +5,12 @@
 // k_kfl_accum forms the sums over points, one wave per 16 x 16 output block and point split.
 // Included inside namespace zigp by zigp_kronf.hip.
 
-template <int NB0, int NB1> struct KflTile { double K0[4 * NB0], K1[4 * NB1], A0[4 * NB0], A1[4 * NB1], B0[4 * NB0], C0[4 * NB0]; };
-
 // LDS layout of the fragment images: P0 | P1 | Al | S2 | AlT | S2T, packed by the ACTUAL block counts
 // STAGE = false: a wave that owns only a tile or two reads the fragments straight from global memory (L2): staging would move the
 // same bytes once per workgroup and put a barrier in front of the first MFMA
 template <bool STAGE>
 __device__ __forceinline__ KfFrags kfl_stage_frags(double* lds, const KfLat& L, bool with_transposes) {
-  if (!STAGE) { KfFrags G = {L.f[0].PF, L.f[1].PF, L.AlF, L.S2F, L.AlTF, L.S2TF}; return G; }
+  if (!STAGE) { KfFrags G = {L.f[0].PF, L.f[1].PF, L.AlF, L.S2F, L.AlTF, L.S2TF, L.f[0].Zs, L.f[1].Zs}; return G; }
   const int nb0 = L.f[0].nb, nb1 = L.f[1].nb;
   const int n0 = nb0 * nb0 * 256, n1 = nb1 * nb1 * 256, n01 = nb0 * nb1 * 256;
   double* p = lds;
@@ -22,6 +20,7 @@ __device__ __forceinline__ KfFrags kfl_stage_frags(double* lds, const KfLat& L, 
   F.Al = p; kf_stage_frag(p, L.AlF, n01); p += n01;
   F.S2 = p; kf_stage_frag(p, L.S2F, n01); p += n01;
   F.AlT = nullptr; F.S2T = nullptr;
+  F.Z0 = L.f[0].Zs; F.Z1 = L.f[1].Zs;      // global (L1-resident): the LDS of these kernels is full of fragment images
   if (with_transposes) {
     F.AlT = p; kf_stage_frag(p, L.AlTF, n01); p += n01;
     F.S2T = p; kf_stage_frag(p, L.S2TF, n01);
@@ -30,30 +29,11 @@ __device__ __forceinline__ KfFrags kfl_stage_frags(double* lds, const KfLat& L, 
   return F;
 }
 
-template <int NB0, int NB1>
-__device__ __forceinline__ void kfl_forward_tile(KflTile<NB0, NB1>& t, const KfLat& L, const KfFrags& F, const double* __restrict__ xrow, bool valid,
-                                                 int g, int slot) {
-  const KfFac &f0 = L.f[0], &f1 = L.f[1];
-  kf_ktile<4 * NB0>(t.K0, f0, xrow, valid, g);
-  kf_ktile<4 * NB1>(t.K1, f1, xrow, valid, g);
-#pragma unroll
-  for (int q = 0; q < 4 * NB0; ++q) { t.A0[q] = 0.0; t.B0[q] = 0.0; t.C0[q] = 0.0; }
-#pragma unroll
-  for (int q = 0; q < 4 * NB1; ++q) t.A1[q] = 0.0;
-  kf_frag_mm<NB0, 4 * NB0>(t.A0, F.P0, f0.nb, 4 * f0.nb, t.K0, slot);
-  kf_frag_mm<NB1, 4 * NB1>(t.A1, F.P1, f1.nb, 4 * f1.nb, t.K1, slot);
-  kf_frag_mm<NB0, 4 * NB1>(t.B0, F.Al, f0.nb, 4 * f1.nb, t.K1, slot);
-  double sq[4 * NB1];
-#pragma unroll
-  for (int q = 0; q < 4 * NB1; ++q) sq[q] = t.A1[q] * t.A1[q];
-  kf_frag_mm<NB0, 4 * NB1>(t.C0, F.S2, f0.nb, 4 * f1.nb, sq, slot);
-}
-
-template <int NB0, int NB1, bool STAGE>
+template <int NB0, int NB1, bool STAGE, bool EXACT>
 __global__ void __launch_bounds__(64 * KF_WAVES, 1)
 k_kfl_forward(KfArgs a) {
   extern __shared__ double lds[];
-  const KfLat& L = a.lat[blockIdx.y];
+  const KfLat& L = a.lat[a.lat0 + blockIdx.y];
   const KfFrags F = kfl_stage_frags<STAGE>(lds, L, false);
   const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
@@ -61,8 +41,8 @@ k_kfl_forward(KfArgs a) {
   for (int tile = w * a.tpw; tile < t1; ++tile) {
     const int64_t pn = (int64_t)tile * 16 + n;
     const bool valid = pn < a.N;
-    KflTile<NB0, NB1> t;
-    kfl_forward_tile<NB0, NB1>(t, L, F, a.X + (valid ? pn : 0) * a.ldx, valid, g, slot);
+    KfTile<NB0, NB1> t;
+    kf_forward_tile<NB0, NB1, EXACT>(t, L, F, a.X + (valid ? pn : 0) * a.ldx, valid, g, slot);
     double q0 = 0.0, q1 = 0.0, mu = 0.0, st = 0.0;
 #pragma unroll
     for (int q = 0; q < 4 * NB0; ++q) {
@@ -90,40 +70,41 @@ __device__ __forceinline__ void kfl_spill(double* __restrict__ base, const doubl
 
 // backward for the larger grids: the per-point reverse pass of k_kf_backward, operands of the sums over points spilled per tile:
 // record = K0 | E0 | A0 | t0 (16 Mq0 doubles each) | K1 | E1 | A1 | t1 (16 Mq1 each)
-template <int NB0, int NB1, bool STAGE>
+template <int NB0, int NB1, bool STAGE, bool EXACT>
 __global__ void __launch_bounds__(64 * KF_WAVES, 1)
 k_kfl_backward(KfArgs a) {
   extern __shared__ double lds[];
-  const KfLat& L = a.lat[blockIdx.y];
+  const KfLat& L = a.lat[a.lat0 + blockIdx.y];
   const KfFac &f0 = L.f[0], &f1 = L.f[1];
   const KfFrags F = kfl_stage_frags<STAGE>(lds, L, true);
   const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
-  const int Mq0 = 16 * f0.nb, Mq1 = 16 * f1.nb;
+  const int nb0 = EXACT ? NB0 : f0.nb, nb1 = EXACT ? NB1 : f1.nb;
+  const int Mq0 = 16 * nb0, Mq1 = 16 * nb1;
   const int64_t rec = 64 * (int64_t)(Mq0 + Mq1);
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
   for (int tile = w * a.tpw; tile < t1; ++tile) {
     const int64_t pn = (int64_t)tile * 16 + n;
     const bool valid = pn < a.N;
     const double* xrow = a.X + (valid ? pn : 0) * a.ldx;
-    KflTile<NB0, NB1> t;
-    kfl_forward_tile<NB0, NB1>(t, L, F, xrow, valid, g, slot);
+    KfTile<NB0, NB1> t;
+    kf_forward_tile<NB0, NB1, EXACT>(t, L, F, xrow, valid, g, slot);
     const double gmn = L.gm[pn], gvn = L.gv[pn], dq0n = L.dq0[pn], dq1n = L.dq1[pn];
     double* R = L.spill + (int64_t)tile * rec;
     double* R1 = R + 64 * Mq0;
-    kfl_spill<NB0>(R, t.K0, f0.nb, Mq0, g, n);
-    kfl_spill<NB1>(R1, t.K1, f1.nb, Mq1, g, n);
-    kfl_spill<NB0>(R + 32 * Mq0, t.A0, f0.nb, Mq0, g, n);
-    kfl_spill<NB1>(R1 + 32 * Mq1, t.A1, f1.nb, Mq1, g, n);
+    kfl_spill<NB0>(R, t.K0, nb0, Mq0, g, n);
+    kfl_spill<NB1>(R1, t.K1, nb1, Mq1, g, n);
+    kfl_spill<NB0>(R + 32 * Mq0, t.A0, nb0, Mq0, g, n);
+    kfl_spill<NB1>(R1 + 32 * Mq1, t.A1, nb1, Mq1, g, n);
     {   // factor 0: B0, C0 are part of the forward tile
       double dA[4 * NB0], PdA[4 * NB0], E[4 * NB0];
 #pragma unroll
       for (int q = 0; q < 4 * NB0; ++q) { dA[q] = 2.0 * gvn * t.A0[q] * t.C0[q]; PdA[q] = 0.0; E[q] = fma(dq0n, t.K0[q], dA[q]); }
-      kfl_spill<NB0>(R + 16 * Mq0, E, f0.nb, Mq0, g, n);
-      kf_frag_mm<NB0, 4 * NB0>(PdA, F.P0, f0.nb, 4 * f0.nb, dA, slot);
+      kfl_spill<NB0>(R + 16 * Mq0, E, nb0, Mq0, g, n);
+      kf_frag_mm<NB0, 4 * NB0>(PdA, F.P0, nb0, 4 * nb0, dA, slot);
 #pragma unroll
       for (int q = 0; q < 4 * NB0; ++q) E[q] = fma(gmn, t.B0[q], fma(2.0 * dq0n, t.A0[q], PdA[q])) * t.K0[q];
-      kfl_spill<NB0>(R + 48 * Mq0, E, f0.nb, Mq0, g, n);
+      kfl_spill<NB0>(R + 48 * Mq0, E, nb0, Mq0, g, n);
     }
     {   // factor 1: B1 = Alpha^T K0, C1 = S2^T A0^2
       double B1[4 * NB1], C1[4 * NB1], sq[4 * NB0];
@@ -131,19 +112,19 @@ k_kfl_backward(KfArgs a) {
       for (int q = 0; q < 4 * NB1; ++q) { B1[q] = 0.0; C1[q] = 0.0; }
 #pragma unroll
       for (int q = 0; q < 4 * NB0; ++q) sq[q] = t.A0[q] * t.A0[q];
-      kf_frag_mm<NB1, 4 * NB0>(B1, F.AlT, f1.nb, 4 * f0.nb, t.K0, slot);
-      kf_frag_mm<NB1, 4 * NB0>(C1, F.S2T, f1.nb, 4 * f0.nb, sq, slot);
+      kf_frag_mm<NB1, 4 * NB0>(B1, F.AlT, nb1, 4 * nb0, t.K0, slot);
+      kf_frag_mm<NB1, 4 * NB0>(C1, F.S2T, nb1, 4 * nb0, sq, slot);
       double PdA[4 * NB1];
 #pragma unroll
       for (int q = 0; q < 4 * NB1; ++q) { C1[q] = 2.0 * gvn * t.A1[q] * C1[q]; PdA[q] = 0.0; }       // C1 <- dA1
-      kf_frag_mm<NB1, 4 * NB1>(PdA, F.P1, f1.nb, 4 * f1.nb, C1, slot);
+      kf_frag_mm<NB1, 4 * NB1>(PdA, F.P1, nb1, 4 * nb1, C1, slot);
 #pragma unroll
       for (int q = 0; q < 4 * NB1; ++q) {
         PdA[q] = fma(gmn, B1[q], fma(2.0 * dq1n, t.A1[q], PdA[q])) * t.K1[q];                          // PdA <- t1
         C1[q] = fma(dq1n, t.K1[q], C1[q]);                                                             // C1 <- E1
       }
-      kfl_spill<NB1>(R1 + 16 * Mq1, C1, f1.nb, Mq1, g, n);
-      kfl_spill<NB1>(R1 + 48 * Mq1, PdA, f1.nb, Mq1, g, n);
+      kfl_spill<NB1>(R1 + 16 * Mq1, C1, nb1, Mq1, g, n);
+      kfl_spill<NB1>(R1 + 48 * Mq1, PdA, nb1, Mq1, g, n);
     }
   }
 }
