@@ -551,23 +551,40 @@ k_kf_factor(KfFactorArgs a) {
     __syncthreads();
     if (t == 0) { double q = 0.0; for (int w = 0; w < 16; ++w) q += red[w]; jb.dvec[Mq] = q; }
   }
-  // P = W^T W:  P[i][j] = sum_{k >= max(i,j)} W[k][i] W[k][j].  Column i of W (below its diagonal) is ROW i of the LDS image right
-  // of the diagonal, so for i <= j:  P[i][j] = W[j][i] W[j][j] + sum_{k > j} S[i][k] S[j][k]  -- two contiguous rows, no branches
-  for (int idx = t; idx < Mq * Mq; idx += 1024) {
-    const int i = idx / Mq, j = idx - i * Mq;
-    if (i > j) continue;
-    double v = 0.0;
-    if (j < M) {
-      v = (i == j) ? psh.dinv[j] * psh.dinv[j] : S[i * PBLD + j] * psh.dinv[j];
-      const double* si = S + i * PBLD; const double* sj = S + j * PBLD;
-#pragma unroll 4
-      for (int k = j + 1; k < M; ++k) v = fma(si[k], sj[k], v);
+  // P = W^T W on the MFMA pipe, operands straight from the LDS image: W[k][i] (k > i) is S[i][k], the diagonal is dinv, zero above.
+  // A(i, k) = W[k][i], B(k, j) = W[k][j]; block (rb, cb) needs k >= 16 max(rb, cb).  Each lane ends with P(16 rb + 4 r + g, 16 cb + n),
+  // r = 0..3 -- exactly one 32-byte granule of the fragment image PF (no second pass over P).  (In-kernel stamps at M = 100: the scalar
+  // loop + the fragment pass took 95 k of the kernel's 415 k cycles.)
+  {
+    const int lane = t & 63, g = lane >> 4, n = lane & 15, ai = lane & 3, wave = t >> 6;
+    const int nbq = Mq / 16, ksn = Mq / 4;
+    for (int blk = wave; blk < nbq * nbq; blk += 16) {
+      const int rb = blk / nbq, cb = blk - rb * nbq;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      const int j = 16 * cb + n;
+      for (int ks = 4 * max(rb, cb); ks < ksn; ++ks) {
+        const int k = 4 * ks + g;
+        const double bv = k > j ? S[j * PBLD + k] : (k == j ? psh.dinv[j] : 0.0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * rb + 4 * r + ai;
+          const double av = k > i ? S[i * PBLD + k] : (k == i ? psh.dinv[i] : 0.0);
+          acc[r] = kf_mfma(av, bv, acc[r]);
+        }
+      }
+      double4 o;
+      double* ov = reinterpret_cast<double*>(&o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * rb + 4 * r + g;
+        const double v = (i < M && j < M) ? acc[r] : 0.0;
+        ov[r] = v;
+        jb.P[i * Mq + j] = v;
+        if (i == j) jb.dvec[i] = v;
+      }
+      *reinterpret_cast<double4*>(jb.PF + ((int64_t)((rb * ksn + 4 * cb + (n >> 2)) * 16 + g + 4 * (n & 3))) * 4) = o;
     }
-    jb.P[i * Mq + j] = v; jb.P[j * Mq + i] = v;
-    if (i == j) jb.dvec[i] = v;
   }
-  __syncthreads();   // P is re-read below by other threads of this workgroup
-  kf_write_frag(jb.PF, Mq / 16, Mq / 4, t, 1024, jb.P, Mq, false);
 }
 
 // ---- small dense algebra of the M x M stages: every operand lives in LDS with row stride KF_SLD (odd: column walks are conflict free)

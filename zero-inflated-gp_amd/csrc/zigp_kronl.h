@@ -238,7 +238,7 @@ __device__ __forceinline__ void kf_frag_gmm_cb(double* __restrict__ C, int ldc, 
     double acc[CB][4];
 #pragma unroll
     for (int c = 0; c < CB; ++c) { acc[c][0] = 0.0; acc[c][1] = 0.0; acc[c][2] = 0.0; acc[c][3] = 0.0; }
-#pragma unroll (CB == 1 ? 8 : 2)
+#pragma unroll (CB == 1 ? 8 : 4)
     for (int ks = 0; ks < ksn; ++ks) {
       const double4 av = F4[(rb * ksn + ks) * 16 + slot];
       double bv[CB];
