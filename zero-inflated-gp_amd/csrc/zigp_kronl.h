@@ -238,20 +238,28 @@ __device__ __forceinline__ void kf_frag_gmm_cb(double* __restrict__ C, int ldc, 
     double acc[CB][4];
 #pragma unroll
     for (int c = 0; c < CB; ++c) { acc[c][0] = 0.0; acc[c][1] = 0.0; acc[c][2] = 0.0; acc[c][3] = 0.0; }
-#pragma unroll (CB == 1 ? 8 : 4)
-    for (int ks = 0; ks < ksn; ++ks) {
-      const double4 av = F4[(rb * ksn + ks) * 16 + slot];
-      double bv[CB];
+    // k-steps in batches of 4 (ksn is a multiple of 4): the 4 fragment loads and 4 CB operand loads of a batch are issued together,
+    // then its 16 CB MFMAs -- one memory round trip per batch instead of one per k-step
+    for (int k0 = 0; k0 < ksn; k0 += 4) {
+      double4 av[4];
+      double bv[4][CB];
 #pragma unroll
-      for (int c = 0; c < CB; ++c) {
-        const int cb = min(cb0 + c, ncb - 1);      // clamped: the surplus chains of the last group are computed and dropped
-        bv[c] = TB ? B[(16 * cb + n) * ldb + 4 * ks + g] : B[(4 * ks + g) * ldb + 16 * cb + n];
+      for (int u = 0; u < 4; ++u) {
+        const int ks = k0 + u;
+        av[u] = F4[(rb * ksn + ks) * 16 + slot];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+          const int cb = min(cb0 + c, ncb - 1);      // clamped: the surplus chains of the last group are computed and dropped
+          bv[u][c] = TB ? B[(16 * cb + n) * ldb + 4 * ks + g] : B[(4 * ks + g) * ldb + 16 * cb + n];
+        }
       }
 #pragma unroll
-      for (int c = 0; c < CB; ++c) {
-        acc[c][0] = kf_mfma(av.x, bv[c], acc[c][0]); acc[c][1] = kf_mfma(av.y, bv[c], acc[c][1]);
-        acc[c][2] = kf_mfma(av.z, bv[c], acc[c][2]); acc[c][3] = kf_mfma(av.w, bv[c], acc[c][3]);
-      }
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+          acc[c][0] = kf_mfma(av[u].x, bv[u][c], acc[c][0]); acc[c][1] = kf_mfma(av[u].y, bv[u][c], acc[c][1]);
+          acc[c][2] = kf_mfma(av[u].z, bv[u][c], acc[c][2]); acc[c][3] = kf_mfma(av[u].w, bv[u][c], acc[c][3]);
+        }
     }
 #pragma unroll
     for (int c = 0; c < CB; ++c)
