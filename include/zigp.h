@@ -8,7 +8,8 @@
  *
  * Conventions: every function returns 0 on success and < 0 on error (never throws across the ABI):
  *   ZIGP_EARG  bad argument        ZIGP_EHIP   HIP runtime error
- *   ZIGP_ENOTPD  Cholesky hit a non-positive pivot (tf.cholesky raises InvalidArgumentError there);
+ *   ZIGP_ENOTPD  Cholesky hit a pivot <= 8 eps (variance + jitter), i.e. non-positive or zero to rounding (tf.cholesky raises
+ *                InvalidArgumentError on a non-positive pivot; an exactly singular Kuu rounds either way there);
  *                zigp_last_info() returns 1-based pivot index, zigp_last_error() the message.
  * All arrays are float64, C-contiguous (row-major), owned by the caller.  Pointers are HOST pointers
  * unless the name says "device".  One ctx per GPU; a ctx is not thread-safe; calls are synchronous

@@ -59,7 +59,7 @@ int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double j
                      (int64_t)h.M, hyp, jitter, lt.Kuu.p, (int64_t)Mp, (int64_t)Mp, (int64_t)Mp);
   ZIGP_HIP(c, hipGetLastError());
   ZIGP_HIP(c, hipMemcpyAsync(lt.L.p, lt.Kuu.p, sizeof(double) * Mp * Mp, hipMemcpyDeviceToDevice, c->stream));
-  ZIGP_TRY(potrf_trtri(c, lt.L.p, lt.W.p, lt.T1.p, Mp, want_W, lt.M));
+  ZIGP_TRY(potrf_trtri(c, lt.L.p, lt.W.p, lt.T1.p, Mp, want_W, lt.M, pivot_tol(h.var, jitter)));
   return 0;
 }
 

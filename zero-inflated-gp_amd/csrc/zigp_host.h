@@ -186,11 +186,14 @@ static int check_info(zigp_ctx* c, const char* what) {
   return 0;
 }
 
+// smallest pivot accepted in a Cholesky of an RBF Kuu (constant diagonal variance + jitter): see potrf_diag_lds
+static inline double pivot_tol(double var, double jitter) { return 8.0 * 2.220446049250313e-16 * (var + jitter); }
+
 // ------------------------------------------------------------------------------------------------
 // L = chol(A) in place in `Lb` (which holds a copy of A on entry), W = L^-1.  Mp multiple of 128.
 // ------------------------------------------------------------------------------------------------
 // Mreal = rows that are not identity padding (diagonal blocks factor only the panels that hold real rows)
-static int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool want_W, int Mreal = -1) {
+static int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool want_W, int Mreal = -1, double piv_tol = 0.0) {
   if (Mreal < 0 || Mreal > Mp) Mreal = Mp;
   const int nb = Mp / BM;
   const int kb = BM / BK;  // k-steps per block
@@ -201,7 +204,7 @@ static int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, 
     double* Ajj = Lb + (int64_t)j * BM * Mp + (int64_t)j * BM;
     double* Wjj = Wb + (int64_t)j * BM * Mp + (int64_t)j * BM;
     const int nreal_j = std::max(0, std::min(BM, Mreal - j * BM));
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(1024), shm, c->stream, Ajj, Ajj, Wjj, (int64_t)Mp, j * BM, c->d_info, (nreal_j + PNB - 1) / PNB);
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(1024), shm, c->stream, Ajj, Ajj, Wjj, (int64_t)Mp, j * BM, c->d_info, (nreal_j + PNB - 1) / PNB, piv_tol);
     ZIGP_HIP(c, hipGetLastError());
     if (j + 1 < nb) {
       TileList tp, ts;

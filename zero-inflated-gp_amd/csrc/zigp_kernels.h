@@ -512,12 +512,16 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // LDS image: S[i][j], j <= i: L;  W[i][c], i > c, lives at S[c][i];  diag(W) in dinv.  ~25 workgroup barriers in total.
 // Body shared by k_potrf_diag and the fused Kronecker factor kernel (zigp_kronf.hip): on entry S[i][j], j <= i, holds the lower
 // triangle of the SPD block (identity beyond the real rows); on exit L in the lower triangle, W = L^-1 as described above
-// (only if want_W).  Returns false when a pivot was not positive (info set, S unfinished).  All 1024 threads must call it.
+// (only if want_W).  Returns false when a pivot was not above `tol` (info set, S unfinished).  All 1024 threads must call it.
+// tol: the callers pass 8 eps (variance + jitter) -- the diagonal of an RBF Kuu is constant -- so that an exactly singular matrix
+// (duplicate inducing points, jitter 0: tf.cholesky raises, onofftf/main.py:355) is reported whichever way its +-1e-16 pivot rounds;
+// tol = 0 is the bare LAPACK / Eigen test.
 struct PotrfShared { double dinv[PB]; double T[3][PNB][PNB + 1]; int fail; };
 __device__ __forceinline__ double potrf_wget(const double* S, const double* dinv, int x, int y) {
   return x > y ? S[y * PBLD + x] : (x == y ? dinv[x] : 0.0);
 }
-__device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int j0, int* info, int npan, bool want_W) {
+#if defined(ZIGP_POTRF_V1)
+__device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int j0, int* info, int npan, bool want_W, double tol) {
   double* dinv = psh.dinv;
   double (*T)[PNB][PNB + 1] = psh.T;
   int& fail = psh.fail;
@@ -538,7 +542,7 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
         int rr = r;
         asm volatile("" : "+v"(rr));   // lane masks of (rr == j) are recomputed per column instead of living in 2 SGPRs each
         const double d = readlane_f64(a[j], j);
-        if (!(d > 0.0)) { if (!bad) bad = j + 1; }   // non-positive or NaN pivot (uniform); keep going on garbage, report below
+        if (!(d > tol)) { if (!bad) bad = j + 1; }   // non-positive or NaN pivot (uniform); keep going on garbage, report below
         const double rd = 1.0 / sqrt(d);
         const double l = (rr == j) ? sqrt(d) : a[j] * rd;
         a[j] = l;
@@ -652,8 +656,226 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
   return true;
 }
 
+#else
+// ---- second version: the serial work is the 32 x 32 factorisation only; everything else runs beside it or on the MFMA pipe.
+//   per panel j:  [A] wave 0 factors the diagonal block (registers, v_readlane broadcasts, v_rsq_f64 + two Newton steps per pivot)
+//                     wave 1 inverts the PREVIOUS diagonal block (needed for W only, so it is off the critical path)
+//                     waves 2..15 apply the PREVIOUS panel to the columns beyond panel j (16 x 16 MFMA tiles, operands from LDS)
+//                 [B] rows below: L21 = A21 L11^-T by forward substitution, one thread per row (no inverse on the critical path)
+//                 [C] panel j -> the next panel's 32 columns only (MFMA tiles), so that [A] can start on them
+//   then W = L^-1 block diagonal by block diagonal, both products (T = sum L_ik W_kj, W_ij = -W_ii T) as MFMA tiles.
+// In-kernel stamps of the first version at M = 100: 296 k cycles, 4 x 30 k of them in the serial factor + inverse of wave 0 and most of
+// the rest in LDS-bandwidth-bound scalar dot products of the trailing updates and of W.
+__device__ __forceinline__ double potrf_mfma(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ double potrf_rsqrt(double d) {      // d > 0: hardware estimate + two Newton steps
+  double y = __builtin_amdgcn_rsq(d);
+  double e = fma(-d * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-d * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  return y;
+}
+// S[i0 + ., k0 + .] (16 x 16) -= sum_{c = c0 .. c0 + 31} S[i][c] S[k][c]     (one wave)
+__device__ __forceinline__ void potrf_tile_update(double* S, int i0, int k0, int c0) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, ai = lane & 3;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < PNB / 4; ++ks) {
+    const int c = c0 + 4 * ks + g;
+    const double bv = S[(k0 + n) * PBLD + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = potrf_mfma(S[(i0 + 4 * r + ai) * PBLD + c], bv, acc[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[(i0 + 4 * r + g) * PBLD + k0 + n] -= acc[r];
+}
+// lower tiles (ti >= tk) of the tile range [t0, nt): the idx-th in row-major order
+__device__ __forceinline__ void potrf_tri_decode(int idx, int& ti, int& tk) {
+  int r = 0;
+  while (idx >= r + 1) { idx -= r + 1; ++r; }
+  ti = r; tk = idx;
+}
+// one wave: Cholesky of the 32 x 32 diagonal block at jb -> T[0] (L11, rows), T[1][0][.] and dinv = 1 / diag.  Returns the failing
+// 1-based column or 0.
+__device__ __forceinline__ int potrf_factor32(const double* S, PotrfShared& psh, int jb, double tol) {
+  const int lane = threadIdx.x & 63, r = lane & 31;     // lanes 32..63 shadow lanes 0..31 (they never store)
+  double a[PNB];
+#pragma unroll
+  for (int k = 0; k < PNB; ++k) a[k] = S[(jb + r) * PBLD + jb + k];
+  int bad = 0;
+  double rdv = 1.0;
+#pragma unroll
+  for (int j = 0; j < PNB; ++j) {
+    int rr = r;
+    asm volatile("" : "+v"(rr));   // lane masks of (rr == j) are recomputed per column instead of living in 2 SGPRs each
+    const double d = readlane_f64(a[j], j);
+    if (!(d > tol)) { if (!bad) bad = j + 1; }   // pivot <= tol or NaN (uniform); keep going on garbage, report below
+    const double rd = potrf_rsqrt(d);
+    double sq = d * rd;
+    sq = fma(0.5 * rd, fma(-sq, sq, d), sq);
+    const double l = (rr == j) ? sq : a[j] * rd;
+    rdv = (rr == j) ? rd : rdv;
+    asm volatile("" : "+v"(rdv));      // select now (otherwise every column's rd stays live to the end)
+    a[j] = l;
+#pragma unroll
+    for (int k = j + 1; k < PNB; ++k) {   // row r, column k (k > r: unused)
+      a[k] = fma(-l, readlane_f64(l, k), a[k]);
+      asm volatile("" : "+v"(a[k]));     // materialise now: otherwise the update is sunk to column k and every broadcast stays live
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the broadcasts (SGPR pairs) of one column from piling up across columns
+  }
+  if (!bad && lane < 32) {
+#pragma unroll
+    for (int k = 0; k < PNB; ++k) psh.T[0][r][k] = a[k];
+    psh.T[1][0][r] = rdv;
+    psh.dinv[jb + r] = rdv;
+  }
+  return bad;
+}
+// one wave: inverse of the lower-triangular diagonal block at pb (already in S, diagonal reciprocals in dinv), transposed into the
+// upper triangle of the same block.  Columns right to left:  w_rj = -w_jj sum_{k=j+1..r} w_rk l_kj   (w_rk lane-local, l_kj: lane k)
+__device__ __forceinline__ void potrf_invert32(double* S, PotrfShared& psh, int pb) {
+  const int lane = threadIdx.x & 63, r = lane & 31;
+  double a[PNB];
+#pragma unroll
+  for (int k = 0; k < PNB; ++k) a[k] = S[(pb + r) * PBLD + pb + k];
+  {
+    int rr = r;
+    asm volatile("" : "+v"(rr));
+#pragma unroll
+    for (int k = 1; k < PNB; ++k) a[k] = (k <= rr) ? a[k] : 0.0;
+  }
+  const double dv = psh.dinv[pb + r];
+#pragma unroll
+  for (int j = PNB - 1; j >= 0; --j) {
+    int rr = r;
+    asm volatile("" : "+v"(rr));
+    const double wjj = readlane_f64(dv, j);
+    double sum = 0.0;
+#pragma unroll
+    for (int k = j + 1; k < PNB; ++k) sum = fma(a[k], readlane_f64(a[j], k), sum);   // a[k] = 0 for k > r
+    a[j] = (rr == j) ? wjj : ((rr > j) ? -wjj * sum : 0.0);
+    asm volatile("" : "+v"(a[j]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // rows through the staging tile T[2] with unconditional stores (predicated stores would keep one lane mask per column in SGPRs)
+  if (lane < 32) {
+#pragma unroll
+    for (int k = 0; k < PNB; ++k) psh.T[2][r][k] = a[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int idx = lane; idx < PNB * PNB; idx += 64) {
+    const int rr = idx >> 5, k = idx & 31;
+    if (k < rr) S[(pb + k) * PBLD + pb + rr] = psh.T[2][rr][k];
+  }
+}
+__device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int j0, int* info, int npan, bool want_W, double tol) {
+  double* dinv = psh.dinv;
+  double (*T)[PNB][PNB + 1] = psh.T;
+  const int t = threadIdx.x, wave = t >> 6;
+  if (t == 0) psh.fail = 0;
+  if (t < PB) dinv[t] = 1.0;
+  __syncthreads();
+  const int nreal = npan * PNB, nt = nreal / 16;
+  for (int jb = 0; jb < nreal; jb += PNB) {
+    // [A]
+    if (wave == 0) {
+      const int bad = potrf_factor32(S, psh, jb, tol);
+      if (bad && t == 0) { atomicCAS(info, 0, j0 + jb + bad); psh.fail = 1; }
+    } else if (jb > 0) {
+      if (wave == 1) {
+        if (want_W) potrf_invert32(S, psh, jb - PNB);
+      } else {
+        const int t0 = (jb + PNB) / 16, n = nt - t0;
+        for (int idx = wave - 2; idx < n * (n + 1) / 2; idx += 14) {
+          int ti, tk;
+          potrf_tri_decode(idx, ti, tk);
+          potrf_tile_update(S, 16 * (t0 + ti), 16 * (t0 + tk), jb - PNB);
+        }
+      }
+    }
+    __syncthreads();
+    if (psh.fail) return false;
+    // [B] scatter L11 into the lower triangle; the rows below solve against it
+    {
+      const int r = t >> 5, k = t & 31;
+      if (k <= r) S[(jb + r) * PBLD + jb + k] = T[0][r][k];
+    }
+    const int nbelow = nreal - jb - PNB;
+    if (t < nbelow) {
+      const int i = jb + PNB + t;
+      double a[PNB];
+#pragma unroll
+      for (int k = 0; k < PNB; ++k) a[k] = S[i * PBLD + jb + k];
+#pragma unroll
+      for (int c = 0; c < PNB; ++c) {
+        const double x = a[c] * T[1][0][c];
+        a[c] = x;
+#pragma unroll
+        for (int k = c + 1; k < PNB; ++k) a[k] = fma(-x, T[0][k][c], a[k]);
+        __builtin_amdgcn_sched_barrier(0);     // one column's broadcast reads at a time
+      }
+#pragma unroll
+      for (int k = 0; k < PNB; ++k) S[i * PBLD + jb + k] = a[k];
+    }
+    __syncthreads();
+    // [C] panel jb -> the next panel's columns
+    if (nbelow > 0) {
+      const int t1 = (jb + PNB) / 16, nrow = nt - t1;     // tiles (t1 + ti, t1 + tk), tk in {0, 1}, ti >= tk
+      for (int idx = wave; idx < 2 * nrow - 1; idx += 16) {
+        const int tk = idx >= nrow ? 1 : 0, ti = tk ? idx - nrow + 1 : idx;
+        potrf_tile_update(S, 16 * (t1 + ti), 16 * (t1 + tk), jb);
+      }
+    }
+    __syncthreads();
+  }
+  if (!want_W) return true;
+  if (wave == 0) potrf_invert32(S, psh, nreal - PNB);
+  __syncthreads();
+  // W[x][y]: x > y at S[y][x], x == y in dinv, x < y zero
+  const int lane = t & 63, g = lane >> 4, n = lane & 15, ai = lane & 3;
+  for (int dist = 1; dist < npan; ++dist) {
+    const int nblk = npan - dist;                 // blocks (b + dist, b), b = 0 .. nblk-1, four 16 x 16 tiles each
+    for (int tile = wave; tile < 4 * nblk; tile += 16) {   // T = sum_x L[ib + r][x] W[x][jb + c],  jb <= x < ib
+      const int b = tile >> 2, rt = (tile >> 1) & 1, ct = tile & 1, jb = b * PNB, ib = (b + dist) * PNB;
+      const int y = jb + 16 * ct + n;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int ks = 4 * ct; ks < 8 * dist; ++ks) {
+        const int x = jb + 4 * ks + g;
+        const double bv = x > y ? S[y * PBLD + x] : (x == y ? dinv[y] : 0.0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = potrf_mfma(S[(ib + 16 * rt + 4 * r + ai) * PBLD + x], bv, acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[b][16 * rt + 4 * r + g][16 * ct + n] = acc[r];
+    }
+    __syncthreads();
+    for (int tile = wave; tile < 4 * nblk; tile += 16) {   // W_ij = -W_ii T
+      const int b = tile >> 2, rt = (tile >> 1) & 1, ct = tile & 1, jb = b * PNB, ib = (b + dist) * PNB;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int ks = 0; ks < 4 * (rt + 1); ++ks) {
+        const int m = 4 * ks + g;
+        const double bv = T[b][m][16 * ct + n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * rt + 4 * r + ai;
+          const double av = row > m ? S[(ib + m) * PBLD + ib + row] : (row == m ? dinv[ib + row] : 0.0);
+          acc[r] = potrf_mfma(av, bv, acc[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[(jb + 16 * ct + n) * PBLD + ib + 16 * rt + 4 * r + g] = -acc[r];
+    }
+    __syncthreads();
+  }
+  return true;
+}
+#endif
+
 __global__ void __launch_bounds__(1024)
-k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __restrict__ W, int64_t ld, int j0, int* info, int npan) {
+k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __restrict__ W, int64_t ld, int j0, int* info, int npan, double tol) {
   // npan = number of 32-column panels that hold real rows; the rest of the block is identity padding (L = W = I there)
   extern __shared__ double S[];   // [128][129]
   __shared__ PotrfShared psh;
@@ -663,7 +885,7 @@ k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __res
     S[i * PBLD + j] = (j <= i) ? A[(int64_t)i * ld + j] : 0.0;
   }
   __syncthreads();
-  if (!potrf_diag_lds(S, psh, j0, info, npan, W != nullptr)) return;
+  if (!potrf_diag_lds(S, psh, j0, info, npan, W != nullptr, tol)) return;
   if (L) {
     for (int idx = t; idx < PB * PB; idx += 1024) {
       const int i = idx >> 7, j = idx & 127;

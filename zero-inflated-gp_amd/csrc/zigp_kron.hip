@@ -384,7 +384,7 @@ int factor_forward(zigp_ctx* c, KronFactor& f, int M, int D, int col0, const dou
                      f.K.p, (int64_t)Mq, (int64_t)Mq, (int64_t)Mq);
   ZIGP_HIP(c, hipGetLastError());
   ZIGP_HIP(c, hipMemcpyAsync(f.L.p, f.K.p, sizeof(double) * mm_, hipMemcpyDeviceToDevice, c->stream));
-  ZIGP_TRY(potrf_trtri(c, f.L.p, f.W.p, f.T.p, Mq, true, M));
+  ZIGP_TRY(potrf_trtri(c, f.L.p, f.W.p, f.T.p, Mq, true, M, pivot_tol(var, jitter)));
   TileList t;
   ZIGP_TRY(get_tiles(c, "bw_s:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
     for (int bi = 0; bi < nb; ++bi)

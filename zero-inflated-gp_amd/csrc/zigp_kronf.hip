@@ -541,7 +541,7 @@ k_kf_factor(KfFactorArgs a) {
     S[i * PBLD + j] = (j <= i) ? v : 0.0;
   }
   __syncthreads();
-  if (!potrf_diag_lds(S, psh, 1000 * (int)blockIdx.x, a.info, (M + PNB - 1) / PNB, true)) return;
+  if (!potrf_diag_lds(S, psh, 1000 * (int)blockIdx.x, a.info, (M + PNB - 1) / PNB, true, 8.0 * 2.220446049250313e-16 * (jb.var + a.jitter))) return;
   // logdet K = sum log L_ii^2 (fixed order: strided partials, then 16 wave sums in order)
   {
     double ld = 0.0;
@@ -884,7 +884,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   const size_t rmax = (size_t)wl.ldw * wl.ldw;
   const size_t FAC_P = (size_t)PB * PB, FAC_PF = FAC_P + rmax, FAC_DV = FAC_PF + rmax, FAC_ZS = FAC_DV + wl.ldw + 8, FAC_SIZE = FAC_ZS + (size_t)wl.ldw * MAXD;
   const size_t LAT_U = 0, LAT_S2 = r01, LAT_T0 = 2 * r01, LAT_T1 = 3 * r01, LAT_AL = 4 * r01, LAT_ALF = 5 * r01, LAT_S2F = 6 * r01, LAT_ALTF = 7 * r01,
-               LAT_S2TF = 8 * r01, LAT_WORK = 9 * r01, LAT_SCR = LAT_WORK + wl.total, SCR_SET = 3 * rmax + r01, LAT_SIZE = LAT_SCR + 2 * SCR_SET;
+               LAT_S2TF = 8 * r01, LAT_WORK = 9 * r01, LAT_SCR = LAT_WORK + wl.total, SCR_SET = 3 * rmax + r01 + wl.ldw, LAT_SIZE = LAT_SCR + 2 * SCR_SET;
   const size_t RES_KLV = 0, RES_KROW0 = 8, RES_KROW1 = RES_KROW0 + (size_t)R0 * KF_KROW_W, RES_GU = RES_KROW1 + (size_t)R1 * KF_KROW_W,
                RES_GS = RES_GU + r01, RES_SIZE = RES_GS + r01;
   // ---- one staged host -> device copy: X, Y, per latent Z0, Z1, u, s
@@ -1103,7 +1103,12 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     fa.ldw = wl.ldw; fa.wS2 = wl.S2; fa.wP0 = wl.P0; fa.wP1 = wl.P1; fa.wK0 = wl.K0; fa.wK1 = wl.K1;
     fa.scratch_off = (int64_t)wl.total; fa.scratch_set = (int64_t)SCR_SET;
     if (pl.large) {
-      hipLaunchKernelGGL(k_kfl_finish, dim3(2, nlat), dim3(1024), 0, c->stream, fa);
+      int nbmax = 1;
+      for (int h = 0; h < nlat; ++h) nbmax = std::max(nbmax, std::max(Mq[h][0], Mq[h][1]) / 16);
+      const dim3 grid(nbmax, 2, nlat);
+      hipLaunchKernelGGL(k_kfl_finish<1>, grid, dim3(KFL_FIN_THREADS), 0, c->stream, fa);
+      hipLaunchKernelGGL(k_kfl_finish<2>, grid, dim3(KFL_FIN_THREADS), 0, c->stream, fa);
+      hipLaunchKernelGGL(k_kfl_finish<3>, grid, dim3(KFL_FIN_THREADS), 0, c->stream, fa);
     } else {
       KfFinishArgs fs;
       memset(&fs, 0, sizeof(fs));

@@ -342,13 +342,67 @@ __device__ __forceinline__ void kf_gmm_wave(double* C, int ldc, const double* __
 // global-operand twin of k_kf_finish: grid (2, latents); work matrices have leading dimension ldw, scratch behind them
 struct KflFinishArgs { KfFinishJob job[2]; double jitter; int with_kl; int ldw, wS2, wP0, wP1, wK0, wK1; int64_t scratch_off, scratch_set; };
 
-__global__ void __launch_bounds__(1024)
+// Crows (16 x n) = A (16 x k) . B (k x n), B row-major in global memory (coalesced over the columns), A through a lambda (LDS or a
+// broadcast global read); a thread owns 4 rows x 1 column, k unrolled by 4 (k is a multiple of 16)
+template <class AF, class ST>
+__device__ __forceinline__ void kf_rowblock_mm(int n, int k, AF af, const double* __restrict__ B, int ldb, ST st) {
+  // the B loads are the latency of this loop (two waves per SIMD, nothing else to switch to): 16 of them are in flight while the
+  // previous 16 are consumed
+  for (int idx = threadIdx.x; idx < 4 * n; idx += blockDim.x) {
+    const int rq = idx / n, j = idx - rq * n;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    double bv[16], bn[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bv[u] = B[u * ldb + j];
+    for (int q0 = 0; q0 < k; q0 += 16) {
+      const bool more = q0 + 16 < k;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bn[u] = B[(q0 + 16 + u) * ldb + j];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fma(af(4 * rq + r, q0 + u), bv[u], v[r]);
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bv[u] = bn[u];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st(4 * rq + r, j, v[r]);
+  }
+}
+
+// C (16 x 16) = A (16 x k, LDS, row stride xs) . B (k x 16 through a lambda); 512 threads: (output, k parity), pair sum by one shuffle
+template <class BF, class ST>
+__device__ __forceinline__ void kf_small_mm(int k, const double* A, int xs, BF bf, ST st) {
+  const int t = threadIdx.x, half = t & 1, out = t >> 1, i = out >> 4, j = out & 15;
+  double v = 0.0;
+#pragma unroll 8
+  for (int q = half; q < k; q += 2) v = fma(A[i * xs + q], bf(q, j), v);
+  v += __shfl_xor(v, 1);
+  if (!half) st(i, j, v);
+}
+
+// The M x M reverse pass of the larger grids, spread over the chip: grid (row blocks, 2 factors, latents), three launches (STAGE 1..3)
+// with the global dependencies between them.  A single workgroup doing the 112^3 products of factor 1 is bound by ONE compute unit's
+// L1 / L2 pipe (in-kernel stamps: 328 k cycles = 137 us, none of it arithmetic); a workgroup per 16-row block of the outputs needs its
+// own rows of the left operand only, so the three stages are embarrassingly parallel over the row blocks:
+//   1  dP_p += (data-term products), Q_p (KL), w_p ;  factor 0: X0 = dAl P1 by column blocks
+//   2  factor 0: dU = P0 X0 -> gu, gs by column blocks ;  X rows = sym(dP) - kl (1/4 (Q + Q^T) + 1/2 diag w) -> Q2 rows = X rows . P
+//   3  G rows = P rows . Q2 ;  Kuu-style reductions of the rows against K_p -> krow (+ the re-centred data moments)
+constexpr int KFL_FIN_THREADS = 512;     // kf_small_mm: 256 outputs x 2 k parities
+template <int STAGE>
+__global__ void __launch_bounds__(KFL_FIN_THREADS)
 k_kfl_finish(KflFinishArgs a) {
-  const KfFinishJob& jb = a.job[blockIdx.y];
-  const int p = blockIdx.x;
+  __shared__ double Xs[(STAGE == 1 ? 3 : 1) * 16 * (16 * 8 + 1)];      // 16 rows of X or P (row stride Mq + 1); stage 1: dAl, T0, U
+  const KfFinishJob& jb = a.job[blockIdx.z];
+  const int p = blockIdx.y, rbk = blockIdx.x;
   const int t = threadIdx.x, M0 = jb.M0, M1 = jb.M1, Mq0 = jb.Mq0, Mq1 = jb.Mq1, ldw = a.ldw;
   const bool kl = a.with_kl != 0;
   const int M = p == 0 ? M0 : M1, Mq = p == 0 ? Mq0 : Mq1, Mo = p == 0 ? M1 : M0, D = p == 0 ? jb.D0 : jb.D1;
+  const int nb = Mq / 16, nb1 = Mq1 / 16;
   const double* Z = p == 0 ? jb.Z0 : jb.Z1;
   const double* zc = p == 0 ? jb.zc0 : jb.zc1;
   const double* P = p == 0 ? jb.P0 : jb.P1;
@@ -358,59 +412,101 @@ k_kfl_finish(KflFinishArgs a) {
   double* dP = work + (p == 0 ? a.wP0 : a.wP1);
   const double* Kr = work + (p == 0 ? a.wK0 : a.wK1);
   double* krow = p == 0 ? jb.krow0 : jb.krow1;
-  double* X = work + a.scratch_off + (int64_t)p * a.scratch_set;     // this workgroup's scratch: X, G, Q (ldw x ldw each), dU
-  double* G = X + (int64_t)ldw * ldw; double* Q = G + (int64_t)ldw * ldw; double* dU = Q + (int64_t)ldw * ldw;
-  if (p == 0) {
-    kf_frag_gmm<true, true>(X, ldw, jb.PF1, Mq1 / 16, Mq1 / 4, dAl, ldw, Mq0 / 16);  // X^T = P1 dAl^T
-    kf_gmm_wave<false, true, true>(dP, ldw, dAl, ldw, jb.T0, Mq1, Mq0, Mq0, Mq1);    // dP0 += dAl T0^T
-    if (kl) kf_gmm_wave<false, true, false>(Q, ldw, jb.T0, Mq1, jb.U, Mq1, Mq0, Mq0, Mq1);   // Q0 = T0 U^T
-    __syncthreads();
-    kf_frag_gmm<false, false>(dU, ldw, jb.PF0, Mq0 / 16, Mq0 / 4, X, ldw, Mq1 / 16);   // dU = P0 X
-    __syncthreads();
-    for (int idx = t; idx < M0 * M1; idx += 1024) {
-      const int i = idx / M1, j = idx - i * M1;
-      const double sv = jb.s[idx];
-      double gu = dU[i * ldw + j], gs = 2.0 * sv * work[a.wS2 + i * ldw + j];
-      if (kl) { gu -= jb.Al[i * Mq1 + j]; gs -= (-1.0 / sv + jb.dvec0[i] * jb.dvec1[j] * sv); }
-      jb.gu[idx] = gu; jb.gs[idx] = gs;
-    }
-  } else {
-    kf_gmm<true, false, true>(dP, ldw, jb.T1, Mq1, dAl, ldw, Mq1, Mq1, Mq0);         // dP1 += T1^T dAl
-    if (kl) kf_gmm<true, false, false>(Q, ldw, jb.U, Mq1, jb.T1, Mq1, Mq1, Mq1, Mq0);   // Q1 = U^T T1
-  }
-  __syncthreads();
-  for (int idx = t; idx < Mq * Mq; idx += 1024) {       // X = sym(dP) [- kl pieces]
-    const int i = idx / Mq, j = idx - i * Mq;
-    double v = 0.5 * (dP[i * ldw + j] + dP[j * ldw + i]);
-    if (kl) {
-      v -= 0.25 * (Q[i * ldw + j] + Q[j * ldw + i]);
-      if (i == j) {
-        double w = 0.0;
-        if (p == 0) { for (int o = 0; o < M1; ++o) w = fma(jb.dvec1[o], jb.S2[i * Mq1 + o], w); }
-        else { for (int o = 0; o < M0; ++o) w = fma(jb.dvec0[o], jb.S2[o * Mq1 + i], w); }
-        v -= 0.5 * w;
+  double* Xb = work + a.scratch_off + (int64_t)p * a.scratch_set;     // per factor: Xb, G, Q (ldw x ldw each), dU, w
+  double* G = Xb + (int64_t)ldw * ldw; double* Q = G + (int64_t)ldw * ldw; double* dU = Q + (int64_t)ldw * ldw;
+  double* wv = Xb + a.scratch_set - ldw;           // w_p: the tail of the factor's scratch set
+  const int R = 16 * rbk;
+  const int xs = Mq + 1, xs1 = Mq1 + 1;
+  if (STAGE == 1) {
+    if (p == 1) {
+      if (rbk >= nb) return;
+      kf_rowblock_mm(Mq1, Mq0, [&](int r, int q) { return jb.T1[q * Mq1 + R + r]; }, dAl, ldw,
+                     [&](int r, int j, double v) { dP[(R + r) * ldw + j] += v; });                                    // dP1 += T1^T dAl
+      if (kl) {
+        kf_rowblock_mm(Mq1, Mq0, [&](int r, int q) { return jb.U[q * Mq1 + R + r]; }, jb.T1, Mq1,
+                       [&](int r, int j, double v) { Q[(R + r) * ldw + j] = v; });                                    // Q1 = U^T T1
+        if (rbk == 0 && t < Mq1) { double w = 0.0; if (t < M1) for (int o = 0; o < M0; ++o) w = fma(jb.dvec0[o], jb.S2[o * Mq1 + t], w); wv[t] = w; }
+      }
+    } else {
+      if (rbk >= nb1) return;
+      // factor 0 has few rows (M0 <= 16): its 16 x 16 products over k = M1 run from LDS copies of the 16-row operands, a thread per
+      // (output, k parity); the M0 x M1 product X0 = dAl P1 is spread over the column blocks of the grid
+      double* As = Xs; double* Ts = Xs + 16 * xs1; double* Us = Ts + 16 * xs1;
+      for (int idx = t; idx < 16 * Mq1; idx += KFL_FIN_THREADS) {
+        const int r = idx / Mq1, c = idx - r * Mq1;
+        const bool in = r < Mq0;
+        As[r * xs1 + c] = in ? dAl[r * ldw + c] : 0.0;
+        if (rbk == 0) { Ts[r * xs1 + c] = in ? jb.T0[r * Mq1 + c] : 0.0; if (kl) Us[r * xs1 + c] = in ? jb.U[r * Mq1 + c] : 0.0; }
+      }
+      __syncthreads();
+      kf_small_mm(Mq1, As, xs1, [&](int q, int j) { return jb.P1[q * Mq1 + R + j]; },
+                  [&](int i, int j, double v) { if (i < Mq0) Xb[i * ldw + R + j] = v; });                              // X0 = dAl P1
+      if (rbk == 0) {
+        kf_small_mm(Mq1, As, xs1, [&](int q, int j) { return Ts[j * xs1 + q]; },
+                    [&](int i, int j, double v) { if (i < Mq0 && j < Mq0) dP[i * ldw + j] += v; });                    // dP0 += dAl T0^T
+        if (kl) {
+          kf_small_mm(Mq1, Ts, xs1, [&](int q, int j) { return Us[j * xs1 + q]; },
+                      [&](int i, int j, double v) { if (i < Mq0 && j < Mq0) Q[i * ldw + j] = v; });                    // Q0 = T0 U^T
+          {   // w0 = S2 dvec1: 32 lanes per row
+            const int r = t >> 5, l = t & 31;
+            double w = 0.0;
+            if (r < M0) for (int o = l; o < M1; o += 32) w = fma(jb.dvec1[o], jb.S2[r * Mq1 + o], w);
+#pragma unroll
+            for (int sft = 16; sft >= 1; sft >>= 1) w += __shfl_xor(w, sft);
+            if (l == 0 && r < Mq0) wv[r] = w;
+          }
+        }
       }
     }
-    X[i * ldw + j] = v;
+    return;
   }
+  if (STAGE == 2) {
+    if (p == 0 && rbk < nb1) {
+      // dU = P0 X0, column block rbk -> gu, gs of those columns
+      kf_rowblock_mm(16, Mq0, [&](int r, int q) { return r < Mq0 ? jb.P0[r * Mq0 + q] : 0.0; }, Xb + R, ldw,
+                     [&](int r, int j, double v) { if (r < Mq0) dU[r * ldw + R + j] = v; });
+      __syncthreads();
+      for (int idx = t; idx < M0 * 16; idx += KFL_FIN_THREADS) {
+        const int i = idx / 16, j = R + (idx & 15);
+        if (j < M1) {
+          const double sv = jb.s[i * M1 + j];
+          double gu = dU[i * ldw + j], gs = 2.0 * sv * work[a.wS2 + i * ldw + j];
+          if (kl) { gu -= jb.Al[i * Mq1 + j]; gs -= (-1.0 / sv + jb.dvec0[i] * jb.dvec1[j] * sv); }
+          jb.gu[i * M1 + j] = gu; jb.gs[i * M1 + j] = gs;
+        }
+      }
+    }
+    if (rbk >= nb) return;
+    // X rows of this block in LDS (the transposed reads dP[c][R + r] are 128-byte row segments), then Q2 rows = X rows . P
+    for (int idx = t; idx < 16 * Mq; idx += KFL_FIN_THREADS) {
+      const int c = idx / 16, r = idx & 15;
+      double v = 0.5 * (dP[(R + r) * ldw + c] + dP[c * ldw + R + r]);
+      if (kl) { v -= 0.25 * (Q[(R + r) * ldw + c] + Q[c * ldw + R + r]); if (c == R + r) v -= 0.5 * wv[c]; }
+      Xs[r * xs + c] = v;
+    }
+    __syncthreads();
+    kf_rowblock_mm(Mq, Mq, [&](int r, int q) { return Xs[r * xs + q]; }, P, Mq, [&](int r, int j, double v) { G[(R + r) * ldw + j] = v; });   // Q2 -> G region
+    return;
+  }
+  // ---- STAGE 3
+  if (rbk >= nb) return;
+  for (int idx = t; idx < 16 * Mq; idx += KFL_FIN_THREADS) { const int r = idx / Mq, c = idx - r * Mq; Xs[r * xs + c] = P[(R + r) * Mq + c]; }
   __syncthreads();
-  const double* PF = p == 0 ? jb.PF0 : jb.PF1;
-  kf_frag_gmm<false, true>(Q, ldw, PF, Mq / 16, Mq / 4, X, ldw, Mq / 16);            // Q = (P X)^T = X P     (X = sym(dP), P symmetric)
-  __syncthreads();
-  kf_frag_gmm<false, false>(G, ldw, PF, Mq / 16, Mq / 4, Q, ldw, Mq / 16);           // G = P X P   (sign and KL term below)
+  double* Gm = Q;     // the KL product is dead: G rows go there
+  kf_rowblock_mm(Mq, Mq, [&](int r, int q) { return Xs[r * xs + q]; }, G, ldw, [&](int r, int j, double v) { Gm[(R + r) * ldw + j] = v; });     // G = P Q2
   __syncthreads();
   // krow[m][c]: Kuu part (as k_kuu_grad, Kz = K_p - jitter I) + data moments rebuilt around z_m.  A wave owns row m, its lanes sweep the
   // columns j (coalesced rows of G, P, K_p), fixed-order wave sums
   const double coef = kl ? 0.5 * (double)Mo : 0.0;
   const int W = 2 + 2 * D;
   const int lane = t & 63;
-  for (int m = t >> 6; m < M; m += 16) {
+  for (int m = R + (t >> 6); m < min(R + 16, M); m += KFL_FIN_THREADS / 64) {
     double s0 = 0.0, s1[MAXD], s2[MAXD], zm[MAXD];
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) { s1[d] = 0.0; s2[d] = 0.0; zm[d] = d < D ? Z[m * D + d] : 0.0; }
     for (int j = lane; j < M; j += 64) {
       const double kz = Kuu[m * PB + j] - ((m == j) ? a.jitter : 0.0);
-      const double tt = (-G[m * ldw + j] - coef * P[m * Mq + j]) * kz;
+      const double tt = (-Gm[m * ldw + j] - coef * P[m * Mq + j]) * kz;
       s0 += tt;
 #pragma unroll
       for (int d = 0; d < MAXD; ++d)
