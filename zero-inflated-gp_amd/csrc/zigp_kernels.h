@@ -497,6 +497,7 @@ __global__ void k_rowscale(const double* __restrict__ P, const double* __restric
 // A/L/W point at the (j0,j0) block; ld = leading dimension.  info: first failing 1-based pivot index.
 // ---------------------------------------------------------------------------------------------
 constexpr int PB = 128, PBLD = 129, PNB = 32;   // block size, LDS row stride, panel width
+constexpr int PHB = 16;                          // half a panel: the register-level pieces of the second version work on 16 x 16 blocks
 // broadcast of one lane's double through the scalar unit (lane index is a compile-time constant after unrolling)
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -659,9 +660,10 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
 #else
 // ---- second version: the serial work is the 32 x 32 factorisation only; everything else runs beside it or on the MFMA pipe.
 //   per panel j:  [A] wave 0 factors the diagonal block (registers, v_readlane broadcasts, v_rsq_f64 + two Newton steps per pivot)
-//                     wave 1 inverts the PREVIOUS diagonal block (needed for W only, so it is off the critical path)
+//                     wave 1 inverts the PREVIOUS diagonal block (needed for W only, so it is off the critical path): two 16 x 16
+//                     halves in registers, the coupling block as two chained MFMA products
 //                     waves 2..15 apply the PREVIOUS panel to the columns beyond panel j (16 x 16 MFMA tiles, operands from LDS)
-//                 [B] rows below: L21 = A21 L11^-T by forward substitution, one thread per row (no inverse on the critical path)
+//                 [B] rows below: L21 = A21 L11^-T by forward substitution, four threads per row (no inverse on the critical path)
 //                 [C] panel j -> the next panel's 32 columns only (MFMA tiles), so that [A] can start on them
 //   then W = L^-1 block diagonal by block diagonal, both products (T = sum L_ik W_kj, W_ij = -W_ii T) as MFMA tiles.
 // In-kernel stamps of the first version at M = 100: 296 k cycles, 4 x 30 k of them in the serial factor + inverse of wave 0 and most of
@@ -696,16 +698,13 @@ __device__ __forceinline__ void potrf_tri_decode(int idx, int& ti, int& tk) {
   ti = r; tk = idx;
 }
 // one wave: Cholesky of the 32 x 32 diagonal block at jb -> T[0] (L11, rows), T[1][0][.] and dinv = 1 / diag.  Returns the failing
-// 1-based column or 0.
-__device__ __forceinline__ int potrf_factor32(const double* S, PotrfShared& psh, int jb, double tol) {
-  const int lane = threadIdx.x & 63, r = lane & 31;     // lanes 32..63 shadow lanes 0..31 (they never store)
-  double a[PNB];
+// 1-based column or 0.  Row per lane, rank-1 updates fed by v_readlane broadcasts -- in two 16-column halves: the 256 updates of the
+// lower-right 16 x 16 block by the first 16 columns go through LDS and the MFMA pipe instead (in-kernel stamps: 17 k cycles per
+// block with all 496 readlane-fed updates).
+template <int J0, int J1>
+__device__ __forceinline__ void potrf_factor_cols(double (&a)[PNB], int r, double tol, int& bad, double& rdv) {
 #pragma unroll
-  for (int k = 0; k < PNB; ++k) a[k] = S[(jb + r) * PBLD + jb + k];
-  int bad = 0;
-  double rdv = 1.0;
-#pragma unroll
-  for (int j = 0; j < PNB; ++j) {
+  for (int j = J0; j < J1; ++j) {
     int rr = r;
     asm volatile("" : "+v"(rr));   // lane masks of (rr == j) are recomputed per column instead of living in 2 SGPRs each
     const double d = readlane_f64(a[j], j);
@@ -718,58 +717,153 @@ __device__ __forceinline__ int potrf_factor32(const double* S, PotrfShared& psh,
     asm volatile("" : "+v"(rdv));      // select now (otherwise every column's rd stays live to the end)
     a[j] = l;
 #pragma unroll
-    for (int k = j + 1; k < PNB; ++k) {   // row r, column k (k > r: unused)
+    for (int k = j + 1; k < J1; ++k) {   // row r, column k (k > r: unused)
       a[k] = fma(-l, readlane_f64(l, k), a[k]);
       asm volatile("" : "+v"(a[k]));     // materialise now: otherwise the update is sunk to column k and every broadcast stays live
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the broadcasts (SGPR pairs) of one column from piling up across columns
   }
+}
+__device__ __forceinline__ void potrf_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int potrf_factor32(const double* S, PotrfShared& psh, int jb, double tol) {
+  const int lane = threadIdx.x & 63, r = lane & 31;     // lanes 32..63 shadow lanes 0..31 (they never store)
+  const int g = lane >> 4, n = lane & 15, ai = lane & 3;
+  double a[PNB];
+#pragma unroll
+  for (int k = 0; k < PNB; ++k) a[k] = S[(jb + r) * PBLD + jb + k];
+  int bad = 0;
+  double rdv = 1.0;
+  potrf_factor_cols<0, PHB>(a, r, tol, bad, rdv);
+  // rows 16..31, columns 16..31 -= L21 L21^T: L21 (the first 16 columns of those rows) through T[0], the product through T[1][16..31]
+  if (lane < 32) {
+#pragma unroll
+    for (int k = 0; k < PHB; ++k) psh.T[0][r][k] = a[k];
+  }
+  potrf_wave_sync();
+  {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < PHB / 4; ++ks) {
+      const double bv = psh.T[0][PHB + n][4 * ks + g];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = potrf_mfma(psh.T[0][PHB + 4 * q + ai][4 * ks + g], bv, acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) psh.T[1][PHB + 4 * q + g][n] = acc[q];
+  }
+  potrf_wave_sync();
+#pragma unroll
+  for (int c = 0; c < PHB; ++c) a[PHB + c] -= psh.T[1][PHB + (r & 15)][c];      // lanes of rows 0..15: leftovers, never used
+  potrf_factor_cols<PHB, PNB>(a, r, tol, bad, rdv);
   if (!bad && lane < 32) {
 #pragma unroll
-    for (int k = 0; k < PNB; ++k) psh.T[0][r][k] = a[k];
+    for (int k = PHB; k < PNB; ++k) psh.T[0][r][k] = a[k];
     psh.T[1][0][r] = rdv;
     psh.dinv[jb + r] = rdv;
   }
   return bad;
 }
-// one wave: inverse of the lower-triangular diagonal block at pb (already in S, diagonal reciprocals in dinv), transposed into the
-// upper triangle of the same block.  Columns right to left:  w_rj = -w_jj sum_{k=j+1..r} w_rk l_kj   (w_rk lane-local, l_kj: lane k)
-__device__ __forceinline__ void potrf_invert32(double* S, PotrfShared& psh, int pb) {
-  const int lane = threadIdx.x & 63, r = lane & 31;
-  double a[PNB];
+// Inverse of the lower-triangular 32 x 32 diagonal block at pb (already in S, diagonal reciprocals in dinv), transposed into the
+// upper triangle of the same block: the two 16 x 16 diagonal halves by one wave each (potrf_invert16), then the coupling block
+// W21 = -W22 L21 W11 as two chained MFMA products (potrf_invert_couple).
+// potrf_invert16, columns right to left:  w_rj = -w_jj sum_{k=j+1..r} w_rk l_kj   (w_rk lane-local, l_kj: lane k)
+__device__ __forceinline__ void potrf_invert16(double* S, PotrfShared& psh, int pb, int h) {
+  const int lane = threadIdx.x & 63, r = lane & 15, p0 = pb + PHB * h;     // lanes 16..63 shadow lanes 0..15
+  double a[PHB];
 #pragma unroll
-  for (int k = 0; k < PNB; ++k) a[k] = S[(pb + r) * PBLD + pb + k];
+  for (int k = 0; k < PHB; ++k) a[k] = S[(p0 + r) * PBLD + p0 + k];
   {
     int rr = r;
     asm volatile("" : "+v"(rr));
 #pragma unroll
-    for (int k = 1; k < PNB; ++k) a[k] = (k <= rr) ? a[k] : 0.0;
+    for (int k = 1; k < PHB; ++k) a[k] = (k <= rr) ? a[k] : 0.0;
   }
-  const double dv = psh.dinv[pb + r];
+  const double dv = psh.dinv[p0 + r];
 #pragma unroll
-  for (int j = PNB - 1; j >= 0; --j) {
+  for (int j = PHB - 1; j >= 0; --j) {
     int rr = r;
     asm volatile("" : "+v"(rr));
     const double wjj = readlane_f64(dv, j);
     double sum = 0.0;
 #pragma unroll
-    for (int k = j + 1; k < PNB; ++k) sum = fma(a[k], readlane_f64(a[j], k), sum);   // a[k] = 0 for k > r
+    for (int k = j + 1; k < PHB; ++k) sum = fma(a[k], readlane_f64(a[j], k), sum);   // a[k] = 0 for k > r
     a[j] = (rr == j) ? wjj : ((rr > j) ? -wjj * sum : 0.0);
     asm volatile("" : "+v"(a[j]));
     __builtin_amdgcn_sched_barrier(0);
   }
   // rows through the staging tile T[2] with unconditional stores (predicated stores would keep one lane mask per column in SGPRs)
-  if (lane < 32) {
+  if (lane < PHB) {
 #pragma unroll
-    for (int k = 0; k < PNB; ++k) psh.T[2][r][k] = a[k];
+    for (int k = 0; k < PHB; ++k) psh.T[2][PHB * h + r][k] = a[k];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int idx = lane; idx < PNB * PNB; idx += 64) {
-    const int rr = idx >> 5, k = idx & 31;
-    if (k < rr) S[(pb + k) * PBLD + pb + rr] = psh.T[2][rr][k];
+  for (int idx = lane; idx < PHB * PHB; idx += 64) {
+    const int rr = idx >> 4, k = idx & 15;
+    if (k < rr) S[(p0 + k) * PBLD + p0 + rr] = psh.T[2][PHB * h + rr][k];
   }
+}
+// one wave, after both halves: X = L21 W11 stays in the accumulators (the D layout of one product is the B layout of the next),
+// W21 = -W22 X goes to S[pb + col][pb + 16 + row]
+__device__ __forceinline__ void potrf_invert_couple(double* S, PotrfShared& psh, int pb) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, ai = lane & 3;
+  double x[4] = {0.0, 0.0, 0.0, 0.0}, w[4] = {0.0, 0.0, 0.0, 0.0};
+  const double dn = psh.dinv[pb + n];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int k = 4 * ks + g;                                  // B = W11[k][n]: S[pb + n][pb + k] for k > n
+    const double sv = S[(pb + n) * PBLD + pb + k];
+    const double bv = k > n ? sv : (k == n ? dn : 0.0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = potrf_mfma(S[(pb + PHB + 4 * r + ai) * PBLD + pb + k], bv, x[r]);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int k = 4 * ks + g;                                  // A = W22[row][k]: S[pb + 16 + k][pb + 16 + row] for row > k
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * r + ai;
+      const double sv = S[(pb + PHB + k) * PBLD + pb + PHB + row], dv = psh.dinv[pb + PHB + row];
+      const double av = row > k ? sv : (row == k ? dv : 0.0);
+      w[r] = potrf_mfma(av, x[ks], w[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[(pb + n) * PBLD + pb + PHB + 4 * r + g] = -w[r];
+}
+// forward substitution of the rows below a factored diagonal block: L21 = A21 L11^-T.  Four threads per row, thread q owns the columns
+// k = q (mod 4); the owner of column c scales it and hands x to its quad through a DPP broadcast, everyone updates the columns it owns
+template <int SEL> __device__ __forceinline__ double potrf_quad_bcast(double v) {
+  constexpr int ctrl = SEL * 0x55;     // quad_perm [SEL, SEL, SEL, SEL]
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void potrf_solve_rows(double* S, PotrfShared& psh, int jb, int nbelow) {
+  const int t = threadIdx.x;
+  if (t >= 4 * nbelow) return;
+  const int i = jb + PNB + (t >> 2), q = t & 3;
+  double a[PNB / 4];
+#pragma unroll
+  for (int s = 0; s < PNB / 4; ++s) a[s] = S[i * PBLD + jb + 4 * s + q];
+#pragma unroll
+  for (int c = 0; c < PNB; ++c) {
+    const int sc = c >> 2, qc = c & 3;
+    double x = a[sc] * psh.T[1][0][c];
+    switch (qc) { case 0: x = potrf_quad_bcast<0>(x); break; case 1: x = potrf_quad_bcast<1>(x); break;
+                  case 2: x = potrf_quad_bcast<2>(x); break; default: x = potrf_quad_bcast<3>(x); break; }
+    const double upd = fma(-x, psh.T[0][4 * sc + q][c], a[sc]);
+    a[sc] = q > qc ? upd : (q == qc ? x : a[sc]);
+#pragma unroll
+    for (int s = sc + 1; s < PNB / 4; ++s) a[s] = fma(-x, psh.T[0][4 * s + q][c], a[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < PNB / 4; ++s) S[i * PBLD + jb + 4 * s + q] = a[s];
 }
 __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int j0, int* info, int npan, bool want_W, double tol) {
   double* dinv = psh.dinv;
@@ -786,7 +880,14 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
       if (bad && t == 0) { atomicCAS(info, 0, j0 + jb + bad); psh.fail = 1; }
     } else if (jb > 0) {
       if (wave == 1) {
-        if (want_W) potrf_invert32(S, psh, jb - PNB);
+        if (want_W) {
+          potrf_invert16(S, psh, jb - PNB, 0);
+          potrf_invert16(S, psh, jb - PNB, 1);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          potrf_invert_couple(S, psh, jb - PNB);
+        }
       } else {
         const int t0 = (jb + PNB) / 16, n = nt - t0;
         for (int idx = wave - 2; idx < n * (n + 1) / 2; idx += 14) {
@@ -804,22 +905,7 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
       if (k <= r) S[(jb + r) * PBLD + jb + k] = T[0][r][k];
     }
     const int nbelow = nreal - jb - PNB;
-    if (t < nbelow) {
-      const int i = jb + PNB + t;
-      double a[PNB];
-#pragma unroll
-      for (int k = 0; k < PNB; ++k) a[k] = S[i * PBLD + jb + k];
-#pragma unroll
-      for (int c = 0; c < PNB; ++c) {
-        const double x = a[c] * T[1][0][c];
-        a[c] = x;
-#pragma unroll
-        for (int k = c + 1; k < PNB; ++k) a[k] = fma(-x, T[0][k][c], a[k]);
-        __builtin_amdgcn_sched_barrier(0);     // one column's broadcast reads at a time
-      }
-#pragma unroll
-      for (int k = 0; k < PNB; ++k) S[i * PBLD + jb + k] = a[k];
-    }
+    potrf_solve_rows(S, psh, jb, nbelow);
     __syncthreads();
     // [C] panel jb -> the next panel's columns
     if (nbelow > 0) {
@@ -832,7 +918,9 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
     __syncthreads();
   }
   if (!want_W) return true;
-  if (wave == 0) potrf_invert32(S, psh, nreal - PNB);
+  if (wave < 2) potrf_invert16(S, psh, nreal - PNB, wave);
+  __syncthreads();
+  if (wave == 0) potrf_invert_couple(S, psh, nreal - PNB);
   __syncthreads();
   // W[x][y]: x > y at S[y][x], x == y in dinv, x < y zero
   const int lane = t & 63, g = lane >> 4, n = lane & 15, ai = lane & 3;
@@ -842,11 +930,20 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
       const int b = tile >> 2, rt = (tile >> 1) & 1, ct = tile & 1, jb = b * PNB, ib = (b + dist) * PNB;
       const int y = jb + 16 * ct + n;
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int ks = 4 * ct; ks < 8 * dist; ++ks) {
-        const int x = jb + 4 * ks + g;
-        const double bv = x > y ? S[y * PBLD + x] : (x == y ? dinv[y] : 0.0);
+      for (int ks4 = 4 * ct; ks4 < 8 * dist; ks4 += 4) {     // four k-steps of loads at a time
+        double bv[4], av[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = potrf_mfma(S[(ib + 16 * rt + 4 * r + ai) * PBLD + x], bv, acc[r]);
+        for (int u = 0; u < 4; ++u) {
+          const int x = jb + 4 * (ks4 + u) + g;
+          const double sv = S[y * PBLD + x], dv = dinv[y];
+          bv[u] = x > y ? sv : (x == y ? dv : 0.0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) av[u][r] = S[(ib + 16 * rt + 4 * r + ai) * PBLD + x];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = potrf_mfma(av[u][r], bv[u], acc[r]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[b][16 * rt + 4 * r + g][16 * ct + n] = acc[r];
@@ -855,15 +952,23 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
     for (int tile = wave; tile < 4 * nblk; tile += 16) {   // W_ij = -W_ii T
       const int b = tile >> 2, rt = (tile >> 1) & 1, ct = tile & 1, jb = b * PNB, ib = (b + dist) * PNB;
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int ks = 0; ks < 4 * (rt + 1); ++ks) {
-        const int m = 4 * ks + g;
-        const double bv = T[b][m][16 * ct + n];
+      for (int ks4 = 0; ks4 < 4 * (rt + 1); ks4 += 4) {
+        double bv[4], av[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * rt + 4 * r + ai;
-          const double av = row > m ? S[(ib + m) * PBLD + ib + row] : (row == m ? dinv[ib + row] : 0.0);
-          acc[r] = potrf_mfma(av, bv, acc[r]);
+        for (int u = 0; u < 4; ++u) {
+          const int m = 4 * (ks4 + u) + g;
+          bv[u] = T[b][m][16 * ct + n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + 4 * r + ai;
+            const double sv = S[(ib + m) * PBLD + ib + row], dv = dinv[ib + row];
+            av[u][r] = row > m ? sv : (row == m ? dv : 0.0);
+          }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = potrf_mfma(av[u][r], bv[u], acc[r]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) S[(jb + 16 * ct + n) * PBLD + ib + 16 * rt + 4 * r + g] = -acc[r];

@@ -525,20 +525,32 @@ k_kf_factor(KfFactorArgs a) {
   __shared__ double red[16];
   const KfFactorJob& jb = a.job[blockIdx.x];
   const int t = threadIdx.x, M = jb.M, Mq = jb.Mq, D = jb.D;
-  for (int idx = t; idx < Mq * D; idx += 1024) { const int m = idx / D, d = idx - m * D; jb.Zs[idx] = m < M ? jb.Z[idx] * jb.inv_ell[d] : 0.0; }
+  // inducing inputs into LDS first (the T tiles are idle until the factorisation): with Z read from global memory inside the loop
+  // every entry of K sat behind two dependent L2 round trips (in-kernel stamps: 23 k cycles for 16 entries per thread).  K is built
+  // for j <= i only and mirrored: rows i and nreal - 1 - i fold into one row of nreal + 1 entries.
+  double* zl = &psh.T[0][0][0];
+  for (int idx = t; idx < Mq * D; idx += 1024) {
+    const int m = idx / D, d = idx - m * D;
+    const double z = m < M ? jb.Z[idx] : 0.0;
+    zl[idx] = z;
+    jb.Zs[idx] = z * jb.inv_ell[d];
+  }
+  __syncthreads();
   const int nreal = ((M + PNB - 1) / PNB) * PNB;   // the factorisation touches the 32-column panels that hold real rows only
-  for (int idx = t; idx < nreal * nreal; idx += 1024) {
-    const int i = idx / nreal, j = idx - i * nreal;
+  for (int idx = t; idx < (nreal / 2) * (nreal + 1); idx += 1024) {
+    int i = idx / (nreal + 1), j = idx - i * (nreal + 1);
+    if (j > i) { j -= i + 1; i = nreal - 1 - i; }
     double v;
     if (i < M && j < M) {
       double r2 = 0.0;
-      for (int d = 0; d < D; ++d) { const double q = (jb.Z[i * D + d] - jb.Z[j * D + d]) * jb.inv_ell[d]; r2 = fma(q, q, r2); }
+      for (int d = 0; d < D; ++d) { const double q = (zl[i * D + d] - zl[j * D + d]) * jb.inv_ell[d]; r2 = fma(q, q, r2); }
       v = jb.var * exp(-0.5 * r2) + ((i == j) ? a.jitter : 0.0);     // same expression as k_rbf_matrix
     } else {
       v = (i == j) ? 1.0 : 0.0;
     }
     jb.K[i * PB + j] = v;
-    S[i * PBLD + j] = (j <= i) ? v : 0.0;
+    S[i * PBLD + j] = v;
+    if (i != j) { jb.K[j * PB + i] = v; S[j * PBLD + i] = 0.0; }
   }
   __syncthreads();
   if (!potrf_diag_lds(S, psh, 1000 * (int)blockIdx.x, a.info, (M + PNB - 1) / PNB, true, 8.0 * 2.220446049250313e-16 * (jb.var + a.jitter))) return;
@@ -552,25 +564,56 @@ k_kf_factor(KfFactorArgs a) {
     if (t == 0) { double q = 0.0; for (int w = 0; w < 16; ++w) q += red[w]; jb.dvec[Mq] = q; }
   }
   // P = W^T W on the MFMA pipe, operands straight from the LDS image: W[k][i] (k > i) is S[i][k], the diagonal is dinv, zero above.
-  // A(i, k) = W[k][i], B(k, j) = W[k][j]; block (rb, cb) needs k >= 16 max(rb, cb).  Each lane ends with P(16 rb + 4 r + g, 16 cb + n),
-  // r = 0..3 -- exactly one 32-byte granule of the fragment image PF (no second pass over P).  (In-kernel stamps at M = 100: the scalar
-  // loop + the fragment pass took 95 k of the kernel's 415 k cycles.)
+  // A(i, k) = W[k][i], B(k, j) = W[k][j].  P is symmetric: blocks rb >= cb only, which need k >= 16 rb; the first four k-steps of a
+  // block cross the diagonal of the A rows (and of the B rows when rb == cb) and take the select-guarded reads, the rest read S
+  // directly; four k-steps of loads go out together (in-kernel stamps at M = 100: 57 k cycles with one guarded k-step at a time,
+  // every LDS round trip exposed).  Dearest blocks first over the 16 waves.  Each lane ends with P(16 rb + 4 r + g, 16 cb + n),
+  // r = 0..3 -- one 32-byte granule of the fragment image PF -- and mirrors it into block (cb, rb).
   {
     const int lane = t & 63, g = lane >> 4, n = lane & 15, ai = lane & 3, wave = t >> 6;
     const int nbq = Mq / 16, ksn = Mq / 4;
-    for (int blk = wave; blk < nbq * nbq; blk += 16) {
-      const int rb = blk / nbq, cb = blk - rb * nbq;
+    for (int blk = wave; blk < nbq * (nbq + 1) / 2; blk += 16) {
+      int rb = 0, cb = blk;
+      while (cb > rb) { cb -= rb + 1; ++rb; }
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
       const int j = 16 * cb + n;
-      for (int ks = 4 * max(rb, cb); ks < ksn; ++ks) {
-        const int k = 4 * ks + g;
-        const double bv = k > j ? S[j * PBLD + k] : (k == j ? psh.dinv[j] : 0.0);
+      const double* Sb = S + j * PBLD + g;
+      const double* Sa = S + (16 * rb + ai) * PBLD + g;
+      {
+        double bv[4], av[4][4];
+        const double dj = psh.dinv[j];
+        double di[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * rb + 4 * r + ai;
-          const double av = k > i ? S[i * PBLD + k] : (k == i ? psh.dinv[i] : 0.0);
-          acc[r] = kf_mfma(av, bv, acc[r]);
+        for (int r = 0; r < 4; ++r) di[r] = psh.dinv[16 * rb + 4 * r + ai];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = 16 * rb + 4 * u + g;
+          const double sb = Sb[4 * (4 * rb + u)];
+          bv[u] = k > j ? sb : (k == j ? dj : 0.0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * rb + 4 * r + ai;
+            const double sa = Sa[4 * r * PBLD + 4 * (4 * rb + u)];
+            av[u][r] = k > i ? sa : (k == i ? di[r] : 0.0);
+          }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = kf_mfma(av[u][r], bv[u], acc[r]);
+      }
+      for (int ks = 4 * rb + 4; ks < ksn; ks += 4) {
+        double bv[4], av[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          bv[u] = Sb[4 * (ks + u)];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) av[u][r] = Sa[4 * r * PBLD + 4 * (ks + u)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = kf_mfma(av[u][r], bv[u], acc[r]);
       }
       double4 o;
       double* ov = reinterpret_cast<double*>(&o);
@@ -580,6 +623,10 @@ k_kf_factor(KfFactorArgs a) {
         const double v = (i < M && j < M) ? acc[r] : 0.0;
         ov[r] = v;
         jb.P[i * Mq + j] = v;
+        if (rb != cb) {
+          jb.P[j * Mq + i] = v;
+          jb.PF[((int64_t)((cb * ksn + 4 * rb + r) * 16 + (n & 3) + 4 * g)) * 4 + (n >> 2)] = v;     // element (row j, column i) of block (cb, rb)
+        }
         if (i == j) jb.dvec[i] = v;
       }
       *reinterpret_cast<double4*>(jb.PF + ((int64_t)((rb * ksn + 4 * cb + (n >> 2)) * 16 + g + 4 * (n & 3))) * 4) = o;
