@@ -157,7 +157,7 @@ def main():
     ap.add_argument('--rows', type=int, default=1000000, help='rows per GPU (weak) or in total (strong)')
     ap.add_argument('--M', type=int, default=1024)
     ap.add_argument('--D', type=int, default=3)
-    ap.add_argument('--chunk', type=int, default=32768)
+    ap.add_argument('--chunk', type=int, default=None, help='rows per pass; default: the library rule 32768 * 1024 / M, clamped to [32768, 131072]')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
@@ -209,7 +209,10 @@ def main():
         N = hi - lo
         total_rows = args.rows
     eng = zigp.DenseEngine(dev)               # raises if libzigp.so is missing: no CPU fallback
-    eng.set_chunk(args.chunk)
+    if args.chunk is not None:
+        eng.set_chunk(args.chunk)
+    else:
+        args.chunk = min(131072, max(32768, -(-(32768 * 1024 // max(-(-M // 128) * 128, 128)) // 1024) * 1024))   # what the library picks (reported below)
     Xd = torch.from_numpy(X).to('cuda:%d' % dev)
     Yd = torch.from_numpy(Y).to('cuda:%d' % dev)
     eng.set_data_device(Xd, Yd)               # inputs resident in HBM before timing

@@ -60,7 +60,7 @@ const char* zigp_last_error(zigp_ctx* ctx);
 int zigp_last_info(zigp_ctx* ctx);
 
 /* Tunables: chunk = number of data rows processed per pass through the fused pipeline (multiple of
- * 1024 and <= 1048576; default 32768). */
+ * 1024 and <= 1048576).  Default, until this is called: 32768 * 1024 / M rows, clamped to [32768, 131072]. */
 int zigp_set_chunk(zigp_ctx* ctx, int64_t chunk_rows);
 
 /* Training data.  Replaces the MinibatchData / DataHolder objects of OnOffSVGP.__init__

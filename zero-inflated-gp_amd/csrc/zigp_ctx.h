@@ -86,6 +86,7 @@ struct zigp_ctx {
   std::string err;
   int info = 0;
   int64_t chunk = 32768;
+  bool chunk_auto = true;                // no zigp_set_chunk yet: the chunk follows M (32768 rows at M = 1024, more for smaller M)
   // data
   const double* dX = nullptr; const double* dY = nullptr;
   zigp::DevBuf ownX, ownY;

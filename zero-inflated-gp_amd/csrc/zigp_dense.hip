@@ -289,10 +289,17 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
 
   // chunk rows: the row range is cut into ceil(span / chunk) chunks of (nearly) equal size, a multiple of 1024, so that the
   // last chunk is not a sliver whose GEMMs leave most of the 512 workgroup slots empty (N = 1e5, chunk 32768: 4 x 25600)
-  int64_t Nc = c->chunk;
+  // Unless the caller fixed it (zigp_set_chunk), the chunk scales with 1 / M so that a launch keeps its ~2000 tiles (4 waves of the 512
+  // workgroup slots) and the panels their size: 32768 rows at M = 1024, 65536 at M = 512 (cfg2: 2 chunks instead of 4, 8.05 -> 7.6 ms)
+  int64_t chunk = c->chunk;
+  if (c->chunk_auto) {
+    const int64_t Mmax = std::max(c->lat[0].Mp, c->lat[1].Mp);
+    chunk = std::min<int64_t>(131072, std::max<int64_t>(32768, round_up(32768 * 1024 / std::max<int64_t>(Mmax, 128), 1024)));
+  }
+  int64_t Nc = chunk;
   const int64_t span = has_rows ? (row_end - row_begin) : 0;
   if (span > 0) {
-    const int64_t nchunks = (span + c->chunk - 1) / c->chunk;
+    const int64_t nchunks = (span + chunk - 1) / chunk;
     Nc = std::max<int64_t>(1024, round_up((span + nchunks - 1) / nchunks, 1024));
   } else {
     Nc = 1024;
@@ -607,6 +614,7 @@ int zigp_set_chunk(zigp_ctx* c, int64_t chunk_rows) {
   if (chunk_rows < 1024 || chunk_rows % 1024 != 0) return fail_arg(c, "chunk must be a positive multiple of 1024");
   if (chunk_rows > (1 << 20)) return fail_arg(c, "chunk must be <= 1048576 rows (32-bit staging offsets; 5 panels of 8*M*chunk bytes per latent)");
   c->chunk = chunk_rows;
+  c->chunk_auto = false;
   return ZIGP_OK;
 }
 

@@ -50,6 +50,7 @@ class ShardedELBO:
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self._buf = None
+        self._host = None
 
     def elbo(self, p, jitter=1e-6, scale=1.0, g_offset=0.0, rows=None):
         ed, kl, g = self.engine.elbo(p, jitter=jitter, scale=scale, g_offset=g_offset, rows=rows,
@@ -60,6 +61,17 @@ class ShardedELBO:
         vec, shapes = pack(ed, kl, g)
         if self._buf is None or self._buf.numel() != vec.size:
             self._buf = torch.empty(vec.size, dtype=torch.float64, device=self.device or 'cpu')
-        self._buf.copy_(torch.from_numpy(vec))
-        self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
-        return unpack(self._buf.cpu().numpy(), shapes)
+            # page-locked staging for the packed vector when the exchange runs on the GPU (RCCL): no pageable copies per step
+            on_gpu = self._buf.is_cuda
+            self._host = torch.empty(vec.size, dtype=torch.float64, pin_memory=on_gpu)
+        self._host.numpy()[:] = vec
+        if self._buf.is_cuda:
+            self._buf.copy_(self._host, non_blocking=True)
+            self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
+            self._host.copy_(self._buf)           # synchronises with the all-reduce on the current stream
+            out = self._host.numpy().copy()
+        else:
+            self._buf.copy_(self._host)
+            self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
+            out = self._buf.numpy().copy()
+        return unpack(out, shapes)
