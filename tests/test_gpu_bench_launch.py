@@ -54,3 +54,15 @@ def test_bench_self_launches_two_ranks_strong(engine):
     engine.set_data(X, Y)
     ed, kl, _ = engine.elbo(p, jitter=1e-6)
     assert abs(res['elbo_data'] - ed) <= 1e-11 * abs(ed) and abs(res['kl'] - kl) <= 1e-12 * abs(kl)
+
+
+def test_rccl_single_rank_exchange():
+    """The RCCL leg of the N > 1 path on the one-GPU box: process group 'nccl' with one rank, the packed vector through ShardedELBO's
+    pinned staging -> all_reduce on the GPU -> pinned -> unpack, barrier and MAX reduce (tools/nccl_selftest.py, own process)."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    env['MASTER_ADDR'] = '127.0.0.1'
+    env['MASTER_PORT'] = '29671'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'nccl_selftest.py')], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and 'single-rank exchange ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -20,6 +20,10 @@ buf = torch.empty(vec.size, dtype=torch.float64, device='cuda:0'); buf.copy_(tor
 dist.all_reduce(buf, op=dist.ReduceOp.SUM)
 ed2, kl2, g2 = unpack(buf.cpu().numpy(), shapes)
 assert ed2 == ed and kl2 == kl and all(np.array_equal(np.asarray(g[k]), np.asarray(g2[k])) for k in g)
+sh.world = 2                                 # force the N > 1 branch (pinned staging -> all_reduce on the GPU -> pinned -> unpack); the sum over ONE rank is the identity
+ed3, kl3, g3 = sh.elbo(p)
+assert ed3 == ed and kl3 == kl and all(np.array_equal(np.asarray(g[k]), np.asarray(g3[k])) for k in g)
+assert sh._buf.is_cuda and sh._host.is_pinned()
 t = torch.tensor([1.25], dtype=torch.float64, device='cuda:0'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
 assert float(t.item()) == 1.25
 dist.destroy_process_group()
