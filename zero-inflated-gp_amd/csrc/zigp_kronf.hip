@@ -677,9 +677,10 @@ struct KfLatentArgs { KfLatentJob job[2]; };
 
 __global__ void __launch_bounds__(1024)
 k_kf_latent(KfLatentArgs a) {
-  __shared__ double sm[6 * KF_SMAT];
-  __shared__ double sh[16];
-  double *sP0 = sm, *sP1 = sm + KF_SMAT, *sU = sm + 2 * KF_SMAT, *sS2 = sm + 3 * KF_SMAT, *sT = sm + 4 * KF_SMAT, *sAl = sm + 5 * KF_SMAT;
+  __shared__ double sm[7 * KF_SMAT];
+  __shared__ double sh[3][16];
+  double *sP0 = sm, *sP1 = sm + KF_SMAT, *sU = sm + 2 * KF_SMAT, *sS2 = sm + 3 * KF_SMAT, *sT = sm + 4 * KF_SMAT, *sAl = sm + 5 * KF_SMAT,
+         *sT1 = sm + 6 * KF_SMAT;
   const KfLatentJob& jb = a.job[blockIdx.x];
   const int t = threadIdx.x, M0 = jb.M0, M1 = jb.M1, Mq0 = jb.Mq0, Mq1 = jb.Mq1;
   kf_lds_load(sP0, jb.P0, Mq0, Mq0, Mq0);
@@ -692,12 +693,10 @@ k_kf_latent(KfLatentArgs a) {
     jb.U[idx] = uv; jb.S2[idx] = sv * sv;
   }
   __syncthreads();
-  kf_lds_mm<false, false, false>(sT, sP0, sU, Mq0, Mq1, Mq0);       // T1 = P0 U
+  kf_lds_mm<false, false, false>(sT1, sP0, sU, Mq0, Mq1, Mq0);      // T1 = P0 U
+  kf_lds_mm<false, false, false>(sT, sU, sP1, Mq0, Mq1, Mq1);       // T0 = U P1   (independent: same phase, own buffer)
   __syncthreads();
-  kf_lds_store(jb.T1, sT, Mq0, Mq1, Mq1);
-  __syncthreads();
-  kf_lds_mm<false, false, false>(sT, sU, sP1, Mq0, Mq1, Mq1);       // T0 = U P1
-  __syncthreads();
+  kf_lds_store(jb.T1, sT1, Mq0, Mq1, Mq1);
   kf_lds_store(jb.T0, sT, Mq0, Mq1, Mq1);
   kf_lds_mm<false, false, false>(sAl, sP0, sT, Mq0, Mq1, Mq0);      // Alpha = P0 (U P1)   (= __kron_mv, scripts/onoff.py:193)
   __syncthreads();
@@ -718,12 +717,11 @@ k_kf_latent(KfLatentArgs a) {
   double vals[3] = {av, bv, cv};
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    double v = wave_sum(vals[q]);
-    __syncthreads();
-    if ((t & 63) == 0) sh[t >> 6] = v;
-    __syncthreads();
-    if (t == 0) { double r = 0.0; for (int w = 0; w < 16; ++w) r += sh[w]; jb.klv[q] = r; }
+    const double v = wave_sum(vals[q]);
+    if ((t & 63) == 0) sh[q][t >> 6] = v;
   }
+  __syncthreads();
+  if (t < 3) { double r = 0.0; for (int w = 0; w < 16; ++w) r += sh[t][w]; jb.klv[t] = r; }
   if (t == 0) { jb.klv[3] = jb.dvec0[Mq0]; jb.klv[4] = jb.dvec1[Mq1]; }
 }
 
@@ -766,6 +764,21 @@ k_kf_finish(KfFinishArgs a) {
   kf_lds_load(sU, jb.U, Mq0, Mq1, Mq1);
   kf_lds_load(sK, p == 0 ? jb.K0 : jb.K1, M, M, PB);
   if (p == 0) kf_lds_load(sPo, jb.P1, Mq1, Mq1, Mq1);
+  // small per-row operands of the later phases in LDS: the inducing inputs and (KL) w_i = sum_o d_o S2[i, o] -- read inside serial loops
+  // they cost an L2 round trip per element (the diagonal threads of the X phase walked 32 of them one after the other)
+  __shared__ double sZ[KF_MQ * MAXD], sW[KF_MQ];
+  for (int idx = t; idx < M * D; idx += 1024) sZ[idx] = Z[idx];
+  if (kl) {
+    const int i = t >> 5, l = t & 31;        // 32 lanes per row
+    double w = 0.0;
+    if (i < M) {
+      if (p == 0) { for (int o = l; o < M1; o += 32) w = fma(jb.dvec1[o], jb.S2[i * Mq1 + o], w); }
+      else { for (int o = l; o < M0; o += 32) w = fma(jb.dvec0[o], jb.S2[o * Mq1 + i], w); }
+    }
+#pragma unroll
+    for (int sft = 16; sft >= 1; sft >>= 1) w += __shfl_xor(w, sft, 64);
+    if (l == 0 && i < KF_MQ) sW[i] = w;
+  }
   __syncthreads();
   if (p == 0) {
     kf_lds_mm<false, false, false>(sX, sdAl, sPo, Mq0, Mq1, Mq1);       // X = dAl P1
@@ -792,12 +805,7 @@ k_kf_finish(KfFinishArgs a) {
     double v = 0.5 * (sdP[i * KF_SLD + j] + sdP[j * KF_SLD + i]);
     if (kl) {
       v -= 0.25 * (sQ[i * KF_SLD + j] + sQ[j * KF_SLD + i]);
-      if (i == j) {
-        double w = 0.0;
-        if (p == 0) { for (int o = 0; o < M1; ++o) w = fma(jb.dvec1[o], jb.S2[i * Mq1 + o], w); }
-        else { for (int o = 0; o < M0; ++o) w = fma(jb.dvec0[o], jb.S2[o * Mq1 + i], w); }
-        v -= 0.5 * w;
-      }
+      if (i == j) v -= 0.5 * sW[i];
     }
     sX[i * KF_SLD + j] = v;
   }
@@ -814,28 +822,36 @@ k_kf_finish(KfFinishArgs a) {
   }
   __syncthreads();
   // krow[m][c]: Kuu part (as k_kuu_grad, Kz = K_p - jitter I) + data moments rebuilt around z_m
+  // eight lanes per (m, c) entry sweep j (fixed-order tree over the eight partial sums)
   const int W = 2 + 2 * D;
-  for (int idx = t; idx < M * W; idx += 1024) {
-    const int m = idx / W, c = idx - m * W;
+  for (int base = 0; base < M * W; base += 128) {
+    const int idx = base + (t >> 3), l = t & 7;
+    const bool on = idx < M * W;
+    const int m = on ? idx / W : 0, c = on ? idx - m * W : 0;
     double v = 0.0;
-    if (c <= 2 * D) {
-      const int d = (c == 0) ? 0 : (c - 1) % D;
-      const double zm = Z[m * D + d];
-      for (int j = 0; j < M; ++j) {
+    const int d = (c == 0) ? 0 : (c - 1) % D;
+    const double zm = sZ[m * D + d];
+    if (on && c <= 2 * D) {
+      for (int j = l; j < M; j += 8) {
         const double kz = sK[m * KF_SLD + j] - ((m == j) ? a.jitter : 0.0);
         const double tt = sG[m * KF_SLD + j] * kz;
-        const double df = Z[j * D + d] - zm;
+        const double df = sZ[j * D + d] - zm;
         v += (c == 0) ? tt : ((c <= D) ? 2.0 * tt * df : tt * df * df);
       }
-      const double s0 = Kr[m * 16];
-      if (c == 0) v += s0;
-      else {
-        const double dz = zm - zc[d], s1 = Kr[m * 16 + 1 + d];
-        if (c <= D) v += s1 - dz * s0;
-        else v += Kr[m * 16 + 1 + D + d] - 2.0 * dz * s1 + dz * dz * s0;
-      }
     }
-    krow[idx] = v;
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    if (on && l == 0) {
+      if (c <= 2 * D) {
+        const double s0 = Kr[m * 16];
+        if (c == 0) v += s0;
+        else {
+          const double dz = zm - zc[d], s1 = Kr[m * 16 + 1 + d];
+          if (c <= D) v += s1 - dz * s0;
+          else v += Kr[m * 16 + 1 + D + d] - 2.0 * dz * s1 + dz * dz * s0;
+        }
+      }
+      krow[idx] = v;
+    }
   }
 }
 
