@@ -502,7 +502,10 @@ struct KfFactorJob {
   double* dvec;     // [Mq] diag(P), then dvec[Mq] = logdet K = sum log L_ii^2
   double* Zs;       // [Mq][D] Z / ell, zero rows beyond M (the point kernels' K tiles)
 };
-struct KfFactorArgs { KfFactorJob job[4]; double jitter; int* info; };
+// info: Cholesky status word(s).  own_slots = 0: one word shared by every factor, zeroed by the host (predict).  own_slots = 1: word
+// info + 2 * job (an 8-byte slot each, inside the result block that is downloaded anyway); the job's workgroup zeroes its own slot, so
+// a step needs neither a memset launch nor a separate status copy.
+struct KfFactorArgs { KfFactorJob job[4]; double jitter; int* info; int own_slots; };
 
 // fragment image of a row-major matrix: F[((rb * ksn + ks) * 16 + slot) * 4 + r] = A(16 rb + 4 r + slot % 4, 4 ks + slot / 4)
 __device__ __forceinline__ void kf_write_frag(double* __restrict__ F, int nbr, int ksn, int t, int nthreads, const double* __restrict__ A, int64_t lda,
@@ -525,6 +528,8 @@ k_kf_factor(KfFactorArgs a) {
   __shared__ double red[16];
   const KfFactorJob& jb = a.job[blockIdx.x];
   const int t = threadIdx.x, M = jb.M, Mq = jb.Mq, D = jb.D;
+  int* const info = a.own_slots ? a.info + 2 * blockIdx.x : a.info;
+  if (a.own_slots && t == 0) { info[0] = 0; info[1] = 0; }       // ordered before the factorisation's atomicCAS by the barriers below
   // inducing inputs into LDS first (the T tiles are idle until the factorisation): with Z read from global memory inside the loop
   // every entry of K sat behind two dependent L2 round trips (in-kernel stamps: 23 k cycles for 16 entries per thread).  K is built
   // for j <= i only and mirrored: rows i and nreal - 1 - i fold into one row of nreal + 1 entries.
@@ -553,7 +558,7 @@ k_kf_factor(KfFactorArgs a) {
     if (i != j) { jb.K[j * PB + i] = v; S[j * PBLD + i] = 0.0; }
   }
   __syncthreads();
-  if (!potrf_diag_lds(S, psh, 1000 * (int)blockIdx.x, a.info, (M + PNB - 1) / PNB, true, 8.0 * 2.220446049250313e-16 * (jb.var + a.jitter))) return;
+  if (!potrf_diag_lds(S, psh, 1000 * (int)blockIdx.x, info, (M + PNB - 1) / PNB, true, 8.0 * 2.220446049250313e-16 * (jb.var + a.jitter))) return;
   // logdet K = sum log L_ii^2 (fixed order: strided partials, then 16 wave sums in order)
   {
     double ld = 0.0;
@@ -948,7 +953,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   const size_t FAC_P = (size_t)PB * PB, FAC_PF = FAC_P + rmax, FAC_DV = FAC_PF + rmax, FAC_ZS = FAC_DV + wl.ldw + 8, FAC_SIZE = FAC_ZS + (size_t)wl.ldw * MAXD;
   const size_t LAT_U = 0, LAT_S2 = r01, LAT_T0 = 2 * r01, LAT_T1 = 3 * r01, LAT_AL = 4 * r01, LAT_ALF = 5 * r01, LAT_S2F = 6 * r01, LAT_ALTF = 7 * r01,
                LAT_S2TF = 8 * r01, LAT_WORK = 9 * r01, LAT_SCR = LAT_WORK + wl.total, SCR_SET = 3 * rmax + r01 + wl.ldw, LAT_SIZE = LAT_SCR + 2 * SCR_SET;
-  const size_t RES_KLV = 0, RES_KROW0 = 8, RES_KROW1 = RES_KROW0 + (size_t)R0 * KF_KROW_W, RES_GU = RES_KROW1 + (size_t)R1 * KF_KROW_W,
+  const size_t RES_KLV = 0, RES_INFO = 8 /* 4 status slots (first latent's block) */, RES_KROW0 = 16, RES_KROW1 = RES_KROW0 + (size_t)R0 * KF_KROW_W, RES_GU = RES_KROW1 + (size_t)R1 * KF_KROW_W,
                RES_GS = RES_GU + r01, RES_SIZE = RES_GS + r01;
   // ---- one staged host -> device copy: X, Y, per latent Z0, Z1, u, s
   size_t off_x = 0, off_y = dev_xy ? 0 : (size_t)N * ldx, off = dev_xy ? 0 : off_y + (size_t)N;
@@ -975,7 +980,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     }
     ZIGP_HIP(c, hipMemcpyAsync(ks.in.p, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, c->stream));
   }
-  ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+  if (predict) ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
   ZIGP_ENSURE(c, ks.mat, (size_t)4 * FAC_SIZE + 2 * LAT_SIZE);
   const int pw_blocks = (int)(Npad / PW_THREADS);
   const size_t pts_lat = (size_t)8 * Npad;   // part[4], gm, gv, dq0, dq1
@@ -1032,12 +1037,14 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
           zc[h][q][d] = 0.5 * (lo + hi);
         }
       }
-    fa.jitter = jitter; fa.info = c->d_info;
+    fa.jitter = jitter;
+    if (predict) { fa.info = c->d_info; fa.own_slots = 0; }
+    else { fa.info = reinterpret_cast<int*>(res(0) + RES_INFO); fa.own_slots = 1; }
     hipLaunchKernelGGL(k_kf_factor, dim3(2 * nlat), dim3(1024), sizeof(double) * PB * PBLD, c->stream, fa);
     ZIGP_HIP(c, hipGetLastError());
   }
   int* hinfo = nullptr;
-  ZIGP_TRY(request_info(c, &hinfo));
+  if (predict) ZIGP_TRY(request_info(c, &hinfo));   // value / gradient steps: the status slots come back with the result block
   {
     KfLatentArgs la;
     memset(&la, 0, sizeof(la));
@@ -1183,7 +1190,11 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   double* hres = nullptr;
   ZIGP_TRY(download(c, ks.res.p, n_res, &hres));
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
-  ZIGP_TRY(info_result(c, hinfo, "a Kronecker factor of Kuu"));
+  {
+    int first = 0;
+    for (int j = 0; j < 2 * nlat && !first; ++j) first = reinterpret_cast<const int*>(hres + RES_INFO)[2 * j];
+    ZIGP_TRY(info_result(c, &first, "a Kronecker factor of Kuu"));
+  }
   const double* hacc = hres + (size_t)2 * RES_SIZE;
   double s_ve = 0, s_dn = 0, s_gv[2] = {0, 0};
   for (int b = 0; b < pw_blocks; ++b) { s_ve += hacc[4 * b]; s_dn += hacc[4 * b + 1]; s_gv[0] += hacc[4 * b + 2]; s_gv[1] += hacc[4 * b + 3]; }
