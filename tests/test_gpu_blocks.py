@@ -25,7 +25,7 @@ def test_gemm_layouts(engine, ta, tb, m, n, k):
     assert np.array_equal(Ci, (Ai.T if ta else Ai) @ (Bi.T if tb else Bi))
 
 
-@pytest.mark.parametrize('n', [1, 9, 50, 128, 200, 512, 1024])
+@pytest.mark.parametrize('n', [1, 9, 31, 32, 33, 50, 64, 65, 96, 97, 100, 127, 128, 129, 200, 512, 1024])   # every panel count and boundary of the blocked factorisation
 def test_potrf_trtri(engine, n):
     rs = np.random.RandomState(n)
     Z = rs.rand(n, 3)
