@@ -58,6 +58,11 @@ class _Packed:
         self.struct = s
 
 
+def _scalar(v):
+    """float of a Python number or a size-1 array (np.squeeze on a plain float costs 1.5 us)"""
+    return float(v) if isinstance(v, (float, int)) else float(np.asarray(v).reshape(-1)[0])
+
+
 class DenseEngine:
     def __init__(self, device=0):
         self.lib = _lib.load()
@@ -212,10 +217,10 @@ class DenseEngine:
             setattr(s, 'M0' + tag, M0); setattr(s, 'M1' + tag, M1)
             setattr(s, 'Z0' + tag, ptr(Z0)); setattr(s, 'Z1' + tag, ptr(Z1))
             setattr(s, 'ell0' + tag, ptr(l0)); setattr(s, 'ell1' + tag, ptr(l1))
-            setattr(s, 'var0' + tag, float(np.squeeze(p['var_' + tag][0]))); setattr(s, 'var1' + tag, float(np.squeeze(p['var_' + tag][1])))
+            setattr(s, 'var0' + tag, _scalar(p['var_' + tag][0])); setattr(s, 'var1' + tag, _scalar(p['var_' + tag][1]))
             setattr(s, 'u_%sm' % tag, ptr(um)); setattr(s, 'u_%ss_sqrt' % tag, ptr(us))
         s.D0, s.D1 = dims
-        s.noise = float(np.squeeze(p.get('noise', 1.0)))
+        s.noise = _scalar(p.get('noise', 1.0))
         return s, keep, dims
 
     def kron_elbo(self, p, X=None, Y=None, jitter=1e-5, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True, rows=None):
@@ -236,10 +241,15 @@ class DenseEngine:
         if need_grad:
             g = {}
             gs = _lib.zigp_kron_grads()
+            # one allocation for the twelve gradient arrays (views into it): np.zeros_like twelve times is 6 us of a 190 us call
+            sizes = [a.size for tag in ('f', 'g') for a in keep[tag]]
+            flat = np.zeros(sum(sizes))
+            o = 0
             for tag in ('f', 'g'):
                 Z0, Z1, l0, l1, um, us = keep[tag]
-                arrs = dict(Z0=np.zeros_like(Z0), Z1=np.zeros_like(Z1), ell0=np.zeros_like(l0), ell1=np.zeros_like(l1),
-                            um=np.zeros_like(um), us=np.zeros_like(us))
+                arrs = {}
+                for name, a in (('Z0', Z0), ('Z1', Z1), ('ell0', l0), ('ell1', l1), ('um', um), ('us', us)):
+                    arrs[name] = flat[o:o + a.size].reshape(a.shape); o += a.size
                 g[tag] = arrs
                 setattr(gs, 'Z0' + tag, ptr(arrs['Z0'])); setattr(gs, 'Z1' + tag, ptr(arrs['Z1']))
                 setattr(gs, 'ell0' + tag, ptr(arrs['ell0'])); setattr(gs, 'ell1' + tag, ptr(arrs['ell1']))
