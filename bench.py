@@ -12,7 +12,8 @@ exec) and exits with its return code; under an external torch.distributed.run it
   --scaling weak   (default) every rank holds its own --rows shard (N=8: cfg4, 8e6 rows); `value` counts 1e6-row ELBO steps
                    per second summed over ranks
   --scaling strong the --rows rows are split over the ranks (zigp.parallel.shard_bounds); `value` = steps/s of that one job
-Each step ends with ONE all-reduce of the packed [ELBO, KL, gradient] vector (RCCL over xGMI with --backend nccl).
+Each step ends with ONE all-reduce of the packed [ELBO, KL, gradient] vector: with --backend nccl inside libzigp.so (ncclAllReduce on the
+device vector, zigp_comm_init -- RCCL over xGMI; torch.distributed carries the communicator id, the barriers and the MAX of the times).
 
 The timed region runs with kernel event timing OFF and the side-stream overlap ON (the fast configuration); the per-kernel
 numbers behind `roofline` come from a separate short profiled pass after it (every launch timed, single stream).
@@ -162,7 +163,6 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='timed region without stream overlap')
-    ap.add_argument('--overlap-mode', type=int, default=1, help='1: HBM-bound side kernels under the rank-N updates; 2: f and g chunk chains on two streams')
     ap.add_argument('--profile-steps', type=int, default=1, help='steps of the separate profiled pass (0: none)')
     ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL, the default) or 'gloo' to rehearse the multi-rank path on fewer GPUs than ranks")
     ap.add_argument('--cpu-sample-rows', type=int, default=60000)
@@ -211,8 +211,7 @@ def main():
     eng = zigp.DenseEngine(dev)               # raises if libzigp.so is missing: no CPU fallback
     if args.chunk is not None:
         eng.set_chunk(args.chunk)
-    else:
-        args.chunk = min(131072, max(32768, -(-(32768 * 1024 // max(-(-M // 128) * 128, 128)) // 1024) * 1024))   # what the library picks (reported below)
+    args.chunk = eng.get_chunk(M)             # what the library uses (its own rule unless --chunk fixed it): reported, and matched against PMC summaries
     Xd = torch.from_numpy(X).to('cuda:%d' % dev)
     Yd = torch.from_numpy(Y).to('cuda:%d' % dev)
     eng.set_data_device(Xd, Yd)               # inputs resident in HBM before timing
@@ -227,7 +226,7 @@ def main():
         torch.cuda.synchronize()
 
     eng.profile_enable(False)
-    eng.set_overlap(0 if args.no_overlap else args.overlap_mode)
+    eng.set_overlap(0 if args.no_overlap else 1)
     for _ in range(args.warmup):
         out = sh.elbo(p, jitter=jitter, scale=scale)
     barrier()
@@ -258,7 +257,7 @@ def main():
         prof = eng.profile_get()
         eng.profile_enable(False)
         eng.profile_sampling(8)
-        eng.set_overlap(0 if args.no_overlap else args.overlap_mode)
+        eng.set_overlap(0 if args.no_overlap else 1)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -270,9 +269,11 @@ def main():
             'config': {'workload': 'dense zero-inflated GP ELBO step (value+gradient), N=%d rows %s, D=%d, M=%d per latent, full batch'
                                    % (args.rows, 'per GPU' if args.scaling == 'weak' else 'in total', D, M),
                        'rows_this_rank': N, 'rows_total': total_rows, 'M': M, 'D': D, 'chunk_rows': args.chunk, 'jitter': jitter,
-                       'parallelism': 'row-shard x%d, 1 all-reduce/step' % world, 'timed_region': 'event timing off, stream overlap %s' % ('off' if args.no_overlap else 'mode %d' % args.overlap_mode)},
+                       'parallelism': 'row-shard x%d, 1 all-reduce/step' % world, 'timed_region': 'event timing off, stream overlap %s' % ('off' if args.no_overlap else 'on')},
             'n_ranks_seen': dist.get_world_size() if dist is not None else 1,
             'backend': (('rccl(nccl)' if args.backend == 'nccl' else args.backend) if dist is not None else 'none'),
+            'exchange': ('ncclAllReduce inside libzigp.so (zigp_comm_init), %d calls' % eng.comm_info()['allreduce_calls']) if sh.library_comm
+                        else ('torch.distributed all_reduce of the packed host vector' if dist is not None else 'none'),
             'elbo': elbo_data - kl, 'elbo_data': elbo_data, 'kl': kl,
         }
         if prof is not None:
@@ -361,6 +362,7 @@ def main():
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()
+        sh.close()
         dist.destroy_process_group()
     eng.close()
 

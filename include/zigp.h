@@ -7,10 +7,11 @@
  * would add on the reference side.
  *
  * Conventions: every function returns 0 on success and < 0 on error (never throws across the ABI):
- *   ZIGP_EARG  bad argument        ZIGP_EHIP   HIP runtime error
- *   ZIGP_ENOTPD  Cholesky hit a pivot <= 8 eps (variance + jitter), i.e. non-positive or zero to rounding (tf.cholesky raises
- *                InvalidArgumentError on a non-positive pivot; an exactly singular Kuu rounds either way there);
- *                zigp_last_info() returns 1-based pivot index, zigp_last_error() the message.
+ *   ZIGP_EARG  bad argument        ZIGP_EHIP   HIP runtime error        ZIGP_ECOMM  RCCL error (zigp_comm_*)
+ *   ZIGP_ENOTPD  Cholesky hit a pivot <= rtol * eps * (variance + jitter), rtol = 8 by default: non-positive, or zero to rounding
+ *                (tf.cholesky raises InvalidArgumentError on a non-positive pivot; an exactly singular Kuu rounds either way there;
+ *                zigp_set_pivot_rtol(ctx, 0) gives that bare `pivot > 0` test); zigp_last_info() returns the 1-based pivot index
+ *                within the failing matrix, zigp_last_error() the message (which names the matrix).
  * All arrays are float64, C-contiguous (row-major), owned by the caller.  Pointers are HOST pointers
  * unless the name says "device".  One ctx per GPU; a ctx is not thread-safe; calls are synchronous
  * (all internal streams are joined before returning).  Reductions are fixed-order: results are
@@ -27,6 +28,7 @@ extern "C" {
 #define ZIGP_EARG (-1)
 #define ZIGP_EHIP (-2)
 #define ZIGP_ENOTPD (-3)
+#define ZIGP_ECOMM (-4)
 
 typedef struct zigp_ctx zigp_ctx;
 
@@ -62,6 +64,11 @@ int zigp_last_info(zigp_ctx* ctx);
 /* Tunables: chunk = number of data rows processed per pass through the fused pipeline (multiple of
  * 1024 and <= 1048576).  Default, until this is called: 32768 * 1024 / M rows, clamped to [32768, 131072]. */
 int zigp_set_chunk(zigp_ctx* ctx, int64_t chunk_rows);
+/* The chunk (rows per pass) the dense path uses for M inducing points per latent: the zigp_set_chunk value, else the default rule. */
+int64_t zigp_get_chunk(zigp_ctx* ctx, int32_t M);
+/* Smallest Cholesky pivot accepted, as a multiple of eps * (kernel variance + jitter).  Default 8 (see ZIGP_ENOTPD above);
+ * 0 reproduces tf.cholesky / LAPACK potrf, which fail on a non-positive pivot only (onofftf/main.py:200,268,355). */
+int zigp_set_pivot_rtol(zigp_ctx* ctx, double rtol);
 
 /* Training data.  Replaces the MinibatchData / DataHolder objects of OnOffSVGP.__init__
  * (onoffgpf/OnOffSVGP.py:38-47) and the X/Y feed_dict of scripts/onoff.py:379-381.
@@ -120,18 +127,21 @@ typedef struct {
 
 /* ELBO / step on an explicit minibatch (host arrays), as scripts/onoff.py:377-381 feeds it.
  * Replaces build_prior_kl + build_predict/kron_inf + cost (scripts/onoff.py:143-213,286-319). */
+/* f_mu: the optional constant added to fmean (`if not f_mu is None: fmean = fmean + f_mu.get_tfv()`, scripts/onoff.py:161,168-169;
+ * onofftf/onoffpred.py:127,135-136; pass 0 for the reference's default f_mu=None); d_f_mu (nullable) receives its gradient. */
 int zigp_kron_elbo(zigp_ctx* ctx, const zigp_kron_params* p, const double* X, const double* Y, int64_t N,
-                   double jitter, double scale, double g_offset, int32_t include_kl,
-                   double* elbo_data, double* kl, zigp_kron_grads* grads);
+                   double jitter, double scale, double g_offset, double f_mu, int32_t include_kl,
+                   double* elbo_data, double* kl, zigp_kron_grads* grads, double* d_f_mu);
 /* The same step on rows [row_begin, row_end) of the RESIDENT data set (zigp_set_data / zigp_set_data_device, D = D0 + D1): no
  * host->device copy of the minibatch.  The reference's iterator (DataSet.next_batch, onofftf/main.py:98-133) shuffles once per
  * epoch and then hands out contiguous slices, so a host that makes the permuted epoch resident feeds every step by row range;
  * the full-batch configuration (BASELINE cfg5) is rows [0, N). */
 int zigp_kron_elbo_rows(zigp_ctx* ctx, const zigp_kron_params* p, int64_t row_begin, int64_t row_end, double jitter, double scale,
-                        double g_offset, int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads);
+                        double g_offset, double f_mu, int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads,
+                        double* d_f_mu);
 /* Replaces predict_onoff's graph (onofftf/onoffpred.py:127-200); out9 as zigp_predict. */
 int zigp_kron_predict(zigp_ctx* ctx, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter,
-                      double g_offset, double* out9);
+                      double g_offset, double f_mu, double* out9);
 
 /* Mean function of the latent f: m(x) = b + a . x, added to fmean before the likelihood and in zigp_predict
  * (`fmean = fmean + self.mean_function(Xnew)`, onoffgpf/OnOffSVGP.py:29,134).  Covers GPflow's Zero (the reference default:
@@ -162,47 +172,28 @@ int zigp_kron_head_elbo(zigp_ctx* ctx, const zigp_kron_params* p, int32_t lik, c
 int zigp_kron_head_predict(zigp_ctx* ctx, const zigp_kron_params* p, int32_t lik, const double* Xnew, int64_t N,
                            double jitter, double f_mu, double* out4);
 
-/* ---- measurement hooks (bench.py) ---- */
-/* Diagnostic: eager vs hipGraph-replayed Kronecker minibatch step; out_ms = {eager ms/step, replay ms/step} (tools/kron_graph.py). */
-int zigp_test_kron_graph(zigp_ctx* ctx, const zigp_kron_params* p, const double* X, const double* Y, int64_t N,
-                         double jitter, double scale, int32_t iters, double* out_ms);
+/* ---- data-parallel exchange (new: the reference is single-process) ----
+ * The ELBO data term is a sum over points (tf.reduce_sum(var_exp), onoffgpf/OnOffSVGP.py:122; scripts/onoff.py:307): one process per GPU
+ * holds a row shard, and ONE ncclAllReduce(sum, f64) per step adds the packed [elbo_data, kl, gradient] vector of every rank, on the
+ * device, on the library's stream (RCCL over xGMI; ~82 KB at M = 1024, D = 3).  RCCL is bound at run time (librccl.so.1).
+ *   rank 0:      zigp_comm_unique_id(id)  -> send the 128 bytes to the other ranks by any means (torch.distributed broadcast, MPI, a file)
+ *   every rank:  zigp_comm_init(ctx, rank, nranks, id)       (collective: returns when all ranks have joined)
+ * From then on zigp_elbo, zigp_kron_elbo, zigp_kron_elbo_rows and zigp_kron_head_elbo return the SUM over ranks of elbo_data, kl, grads
+ * (and d_f_mu, the mean-function gradient) on every rank: each rank passes its own rows and include_kl = (rank == 0), so that the KL
+ * and its gradient are counted once.  Every rank must make the same calls in the same order with the same model sizes.  Prediction
+ * entry points are unaffected.  A Cholesky failure is reported by every rank (their Kuu are identical), after the exchange. */
+#define ZIGP_COMM_ID_BYTES 128
+int zigp_comm_unique_id(void* id /* [ZIGP_COMM_ID_BYTES] */);
+int zigp_comm_init(zigp_ctx* ctx, int32_t rank, int32_t nranks, const void* id);
+int zigp_comm_destroy(zigp_ctx* ctx);
+/* rank / nranks of the context's communicator (nranks = 0: none) and the number of all-reduces issued through it so far */
+int zigp_comm_info(zigp_ctx* ctx, int32_t* rank, int32_t* nranks, int64_t* allreduce_calls);
+
 /* Stream overlap inside zigp_elbo (default off): when on, the HBM-bound kernels of a row chunk (Kuf-cotangent reductions,
  * the next chunk's Kuf panels) run on a second HIP stream underneath the chunk's two MFMA-bound rank-N updates.  Results
- * are bit-identical either way and the step is ~0.8 % shorter (tools/overlap_ab.py); it is off by default so that every
- * kernel runs alone on one stream and per-kernel durations (HIP events, rocprofv3 --stats) mean what they say. */
-int zigp_set_overlap(zigp_ctx* ctx, int32_t on);   /* 0 off; 1 as above; 2: the per-chunk kernel chains of the latents f and g on two
- * streams (they are independent up to the point-wise stage): measured 1.5 % SLOWER than mode 0 on cfg3 (two full-chip GEMMs in flight
- * share the LDS / L2 rather than fill each other's tails: tools/overlap_ab.py), kept as an option; bit-identical results; ignored while kernel timing (zigp_profile_enable) is on */
-/* Accumulated HIP-event time (ms), launch count and algorithmic flops per kernel class since the last reset,
- * measured with HIP events on the stream the kernels run on.  Classes (gemm_f64_kernel template arguments are
- * <A layout, B layout, ring stages, k-scale, triangular mode, waves, epilogue>):
- * 0 gemm_A1  A1 = W K            gemm_f64_kernel<0,1,2,false,1,4,EpiStoreColsum>
- * 1 gemm_A2  A2 = W^T A1         gemm_f64_kernel<1,1,2,false,2,8,EpiStoreColsum>
- * 2 gemm_H   H = W diag(s^2) A2  gemm_f64_kernel<0,1,2,false,1,4,EpiStore>
- * 3 gemm_J   J' = W^T H - A2     gemm_f64_kernel<1,1,2,false,2,8,EpiSubLoad>
- * 4 syrk     C1 += A1 G A1^T     gemm_f64_kernel<0,0,2,true,3,4,EpiAccum>
- * 5 kuf_build   6 pointwise   7 kgrad   8 MxM stage (all kernels)   9 everything else. */
-#define ZIGP_NCLASS 10
-int zigp_profile_enable(zigp_ctx* ctx, int32_t on);
-int zigp_profile_get(zigp_ctx* ctx, double* ms /*[ZIGP_NCLASS]*/, int64_t* launches /*[ZIGP_NCLASS]*/,
-                     double* flops /*[ZIGP_NCLASS] algorithmic*/);
-int zigp_profile_reset(zigp_ctx* ctx);
-/* Event pairs cost ~10 us each, so launches of the chunk loop are TIMED on every 8th full-size chunk only (ms / launches /
- * flops above describe those sampled launches); zigp_profile_totals returns the number of launches per class, sampled or not. */
-int zigp_profile_totals(zigp_ctx* ctx, int64_t* total_launches /*[ZIGP_NCLASS]*/);
-/* every = 1: time EVERY launch of the chunk loop, the partial last chunk included (sums are then exact, the step is ~1 % slower:
- * bench.py's separate profiled pass); every = n > 1: full-size chunks only, every n-th (default 8). */
-int zigp_profile_sampling(zigp_ctx* ctx, int32_t every);
-
-/* ---- diagnostics used by the parity tests (building blocks through the same kernels) ---- */
-/* Kronecker entry points: on != 0 forces the GEMM-panel path (zigp_kron.hip) also for grids the fused register-resident kernels
- * (zigp_kronf.hip) cover -- two independent implementations of the same factored algebra that the tests check against each other. */
-int zigp_set_kron_panels(zigp_ctx* ctx, int32_t on);
-/* C (m,n) = op(A) * op(B) with the fp64 MFMA GEMM core; transA/transB as BLAS; all dims padded internally. */
-int zigp_test_gemm(zigp_ctx* ctx, int32_t transA, int32_t transB, int64_t m, int64_t n, int64_t k,
-                   const double* A, const double* B, double* C);
-/* L = chol(A) (lower), W = L^-1, A is (n,n) SPD; either output may be NULL. */
-int zigp_test_potrf_trtri(zigp_ctx* ctx, int64_t n, const double* A, double* L, double* W);
+ * are bit-identical either way; it is off by default so that every kernel runs alone on one stream and per-kernel durations
+ * (HIP events, rocprofv3 --stats) mean what they say. */
+int zigp_set_overlap(zigp_ctx* ctx, int32_t on);
 
 #ifdef __cplusplus
 }

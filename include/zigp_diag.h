@@ -1,0 +1,45 @@
+/* libzigp -- measurement hooks (bench.py) and diagnostics used by the parity tests.  Not part of the drop-in boundary
+ * (include/zigp.h); exported by the same libzigp.so. */
+#ifndef ZIGP_DIAG_H
+#define ZIGP_DIAG_H
+#include "zigp.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- measurement hooks (bench.py) ---- */
+/* Accumulated HIP-event time (ms), launch count and algorithmic flops per kernel class since the last reset,
+ * measured with HIP events on the stream the kernels run on.  Classes (gemm_f64_kernel template arguments are
+ * <A layout, B layout, ring stages, k-scale, triangular mode, waves, epilogue>):
+ * 0 gemm_A1  A1 = W K            gemm_f64_kernel<0,1,2,false,1,4,EpiStoreColsum>
+ * 1 gemm_A2  A2 = W^T A1         gemm_f64_kernel<1,1,2,false,2,8,EpiStoreColsum>
+ * 2 gemm_H   H = W diag(s^2) A2  gemm_f64_kernel<0,1,2,false,1,4,EpiStore>
+ * 3 gemm_J   J' = W^T H - A2     gemm_f64_kernel<1,1,2,false,2,8,EpiSubLoad>
+ * 4 syrk     C1 += A1 G A1^T     gemm_f64_kernel<0,0,2,true,3,4,EpiAccum>
+ * 5 kuf_build   6 pointwise   7 kgrad   8 MxM stage (all kernels)   9 everything else. */
+#define ZIGP_NCLASS 10
+int zigp_profile_enable(zigp_ctx* ctx, int32_t on);
+int zigp_profile_get(zigp_ctx* ctx, double* ms /*[ZIGP_NCLASS]*/, int64_t* launches /*[ZIGP_NCLASS]*/,
+                     double* flops /*[ZIGP_NCLASS] algorithmic*/);
+int zigp_profile_reset(zigp_ctx* ctx);
+/* Event pairs cost ~10 us each, so launches of the chunk loop are TIMED on every 8th full-size chunk only (ms / launches /
+ * flops above describe those sampled launches); zigp_profile_totals returns the number of launches per class, sampled or not. */
+int zigp_profile_totals(zigp_ctx* ctx, int64_t* total_launches /*[ZIGP_NCLASS]*/);
+/* every = 1: time EVERY launch of the chunk loop, the partial last chunk included (sums are then exact, the step is ~1 % slower:
+ * bench.py's separate profiled pass); every = n > 1: full-size chunks only, every n-th (default 8). */
+int zigp_profile_sampling(zigp_ctx* ctx, int32_t every);
+
+/* ---- diagnostics used by the parity tests (building blocks through the same kernels) ---- */
+/* Kronecker entry points: on != 0 forces the GEMM-panel path (zigp_kron.hip) also for grids the fused register-resident kernels
+ * (zigp_kronf.hip) cover -- two independent implementations of the same factored algebra that the tests check against each other. */
+int zigp_set_kron_panels(zigp_ctx* ctx, int32_t on);
+/* C (m,n) = op(A) * op(B) with the fp64 MFMA GEMM core; transA/transB as BLAS; all dims padded internally. */
+int zigp_test_gemm(zigp_ctx* ctx, int32_t transA, int32_t transB, int64_t m, int64_t n, int64_t k,
+                   const double* A, const double* B, double* C);
+/* L = chol(A) (lower), W = L^-1, A is (n,n) SPD; either output may be NULL. */
+int zigp_test_potrf_trtri(zigp_ctx* ctx, int64_t n, const double* A, double* L, double* W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -249,9 +249,12 @@ def gauss_kl_kron(q_mu, q_sqrt, K_kron):
     return 0.5 * twoKL
 
 
-def kron_build_predict(Xnew, p, jitter, g_offset=0.0):
-    """scripts/onoff.py:161-184 (fit: g_offset=0) / onofftf/onoffpred.py:127-154 (predict: g_offset=-1, :141)."""
+def kron_build_predict(Xnew, p, jitter, g_offset=0.0, f_mu=None):
+    """scripts/onoff.py:161-184 (fit: g_offset=0) / onofftf/onoffpred.py:127-154 (predict: g_offset=-1, :141); f_mu: the optional
+    constant of :161,168-169 (None in every call the reference makes)."""
     fmean, fvar = kron_inf(Xnew, p['Zf'], p['ell_f'], p['var_f'], p['u_fm'], p['u_fs_sqrt'], jitter)
+    if f_mu is not None:
+        fmean = fmean + f_mu                                           # :168-169
     gmean, gvar = kron_inf(Xnew, p['Zg'], p['ell_g'], p['var_g'], p['u_gm'], p['u_gs_sqrt'], jitter)
     gmean = gmean + g_offset
     ephi_g, ephi2_g, evar_phi_g = probit_expectations(gmean, gvar)
@@ -265,10 +268,10 @@ def kron_prior_KL(p, jitter):                                          # scripts
     return gauss_kl_kron(p['u_fm'], p['u_fs_sqrt'], Kf), gauss_kl_kron(p['u_gm'], p['u_gs_sqrt'], Kg)
 
 
-def kron_elbo(X, Y, p, jitter, scale=1.0, g_offset=0.0):
+def kron_elbo(X, Y, p, jitter, scale=1.0, g_offset=0.0, f_mu=None):
     """scripts/onoff.py:286-319: cost = -(sum(var_exp)*scale - kl); returns (ELBO, data, KL_f, KL_g)."""
     klf, klg = kron_prior_KL(p, jitter)
-    gfmean, gfvar, gfmeanu = kron_build_predict(X, p, jitter, g_offset)[:3]
+    gfmean, gfvar, gfmeanu = kron_build_predict(X, p, jitter, g_offset, f_mu)[:3]
     data = np.sum(variational_expectations(gfmean, gfvar, gfmeanu, Y.reshape(-1, 1), p['noise']))
     return data * scale - (klf + klg), data, klf, klg
 

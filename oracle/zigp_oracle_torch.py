@@ -197,16 +197,20 @@ KRON_KEYS = ('Zf', 'Zg', 'ell_f', 'ell_g', 'var_f', 'var_g')  # lists (one entry
 KRON_VEC_KEYS = ('u_fm', 'u_gm', 'u_fs_sqrt', 'u_gs_sqrt', 'noise')
 
 
-def kron_elbo_and_grad(X, Y, p_np, jitter, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True):
-    """scripts/onoff.py:286-319 value (+ autograd gradient); literal dense order -> small batches only."""
+def kron_elbo_and_grad(X, Y, p_np, jitter, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True, f_mu=None):
+    """scripts/onoff.py:286-319 value (+ autograd gradient); literal dense order -> small batches only.  f_mu: the optional constant
+    of build_predict (:161,168-169); when given, grads['f_mu'] is its gradient."""
     Xt, Yt = _t(X), _t(Y).reshape(-1, 1)
     p = {}
     for k in KRON_KEYS:
         p[k] = [_t(v).clone().requires_grad_(need_grad) for v in p_np[k]]
     for k in KRON_VEC_KEYS:
         p[k] = _t(p_np[k]).clone().requires_grad_(need_grad)
+    fmu = None if f_mu is None else _t(f_mu).clone().requires_grad_(need_grad)
     with torch.set_grad_enabled(need_grad):
         fmean, fvar = kron_inf(Xt, p['Zf'], p['ell_f'], p['var_f'], p['u_fm'], p['u_fs_sqrt'], jitter)
+        if fmu is not None:
+            fmean = fmean + fmu
         gmean, gvar = kron_inf(Xt, p['Zg'], p['ell_g'], p['var_g'], p['u_gm'], p['u_gs_sqrt'], jitter)
         gmean = gmean + g_offset
         e1, e2, ev = probit_expectations(gmean, gvar)
@@ -225,6 +229,8 @@ def kron_elbo_and_grad(X, Y, p_np, jitter, scale=1.0, g_offset=0.0, include_kl=T
             grads[k] = [v.grad.numpy().copy() for v in p[k]]
         for k in KRON_VEC_KEYS:
             grads[k] = p[k].grad.numpy().copy()
+        if fmu is not None:
+            grads['f_mu'] = float(fmu.grad)
     return float(elbo.detach()), float(data.detach()), float(kl.detach()), grads
 
 

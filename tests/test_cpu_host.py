@@ -13,15 +13,18 @@ GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 
 def test_library_loads_and_exports_every_declared_symbol():
-    """Every function declared in include/zigp.h resolves in libzigp.so and is bound in zigp._lib."""
+    """Every function declared in include/zigp.h (the boundary) and include/zigp_diag.h (measurement hooks, test diagnostics) resolves in
+    libzigp.so and is bound in zigp._lib."""
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
     ge.build()
     from zigp import _lib
     lib = _lib.load()
     hdr = open(os.path.join(ROOT, 'include', 'zigp.h')).read()
-    names = sorted(set(re.findall(r'\b(zigp_[A-Za-z0-9_]+)\s*\(', hdr)))
-    assert len(names) >= 15
+    api = set(re.findall(r'\b(zigp_[A-Za-z0-9_]+)\s*\(', hdr))
+    assert len(api) >= 20 and {'zigp_comm_init', 'zigp_comm_unique_id', 'zigp_kron_elbo_rows', 'zigp_elbo'} <= api
+    assert not any(n.startswith(('zigp_test_', 'zigp_profile_')) for n in api)        # diagnostics live in zigp_diag.h
+    names = sorted(api | set(re.findall(r'\b(zigp_[A-Za-z0-9_]+)\s*\(', open(os.path.join(ROOT, 'include', 'zigp_diag.h')).read())))
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, 'declared in zigp.h but not bound: ' + n
@@ -151,11 +154,75 @@ def _gloo_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _OracleKronShardEngine:
+    """Test double with the DenseEngine.kron_elbo signature on its own shard (CPU oracle, literal dense order)."""
+
+    def __init__(self, X, Y):
+        self.X, self.Y = X, Y
+
+    def kron_elbo(self, p, X=None, Y=None, jitter=1e-5, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True, rows=None, f_mu=None):
+        import zigp_oracle_torch as ot
+        lo, hi = rows
+        e, d, kl, g = ot.kron_elbo_and_grad(self.X[lo:hi], self.Y[lo:hi], p, jitter, scale=scale, g_offset=g_offset, include_kl=include_kl)
+        return d * scale, kl, g
+
+
+def _gloo_kron_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from zigp.parallel import ShardedKronELBO, shard_bounds
+    from test_gpu_kron import make_kron_problem
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    X, Y, p = make_kron_problem(203, 5, 4, seed=8, M0g=4, M1g=6)
+    lo, hi = shard_bounds(X.shape[0], world, rank)
+    sh = ShardedKronELBO(_OracleKronShardEngine(X[lo:hi], Y[lo:hi]), dist)
+    assert not sh.library_comm                     # gloo: the packed host vector goes through torch.distributed
+    ed, kl, g = sh.kron_elbo(p, rows=(0, hi - lo), jitter=1e-5, scale=2.0)
+    if rank == 1:                                  # every rank holds the sums
+        q.put((ed, kl, g))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_kronecker_gloo_world2_equals_single_process():
+    """The Kronecker step (cfg5) sharded over rows: 2 gloo ranks, ragged shards, f and g on different grids; KL counted once."""
+    import torch.multiprocessing as mp
+    import zigp_oracle_torch as ot
+    from test_gpu_kron import make_kron_problem
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_kron_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    ed, kl, g = q.get(timeout=180)
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    X, Y, p = make_kron_problem(203, 5, 4, seed=8, M0g=4, M1g=6)
+    e1, d1, kl1, g1 = ot.kron_elbo_and_grad(X, Y, p, 1e-5, scale=2.0)
+    assert abs(ed - 2.0 * d1) < 1e-10 * abs(2.0 * d1) and abs(kl - kl1) < 1e-12 * abs(kl1)
+    for k in g1:
+        a, b = g[k], g1[k]
+        for x, y in (zip(a, b) if isinstance(b, (list, tuple)) else ((a, b),)):
+            x, y = np.asarray(x, dtype=float).reshape(-1), np.asarray(y, dtype=float).reshape(-1)
+            assert np.max(np.abs(x - y)) <= 1e-9 * max(np.max(np.abs(y)), 1e-300), k
+
+
 def test_data_parallel_allreduce_gloo_world2_equals_single_process():
     """N>1 path on CPU: 2 ranks (gloo), row shards, one all-reduce; KL counted once (rank 0)."""
     import torch.multiprocessing as mp
     import zigp_oracle_torch as ot
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
@@ -171,6 +238,58 @@ def test_data_parallel_allreduce_gloo_world2_equals_single_process():
     for k in ot.PARAM_KEYS:
         a, b = np.asarray(g[k]).reshape(-1), np.asarray(g1[k]).reshape(-1)
         assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300), k
+
+
+class _LiteralDataSet:
+    """checker: the branch structure of onofftf/main.py:98-133 written out (arrays re-gathered at every shuffle)"""
+
+    def __init__(self, x, y, seed=121):
+        np.random.seed(seed)
+        self.n, self.x, self.y, self.ep, self.i = x.shape[0], x, y, 0, 0
+
+    def next_batch(self, b, shuffle=True):
+        start = self.i
+        if self.ep == 0 and start == 0 and shuffle:
+            perm = np.arange(self.n); np.random.shuffle(perm); self.x, self.y = self.x[perm], self.y[perm]
+        if start + b > self.n:
+            self.ep += 1
+            xr, yr = self.x[start:], self.y[start:]
+            if shuffle:
+                perm = np.arange(self.n); np.random.shuffle(perm); self.x, self.y = self.x[perm], self.y[perm]
+            self.i = b - (self.n - start)
+            return np.concatenate((xr, self.x[:self.i])), np.concatenate((yr, self.y[:self.i]))
+        self.i += b
+        return self.x[start:self.i], self.y[start:self.i]
+
+
+@pytest.mark.parametrize('n,b,shuffle', [(37, 5, True), (40, 8, True), (10, 10, True), (23, 7, False), (105, 100, True)])
+def test_dataset_order_iterator_yields_the_reference_batch_sequence(n, b, shuffle):
+    """DataSet keeps an index ORDER instead of re-gathered copies; its batches -- through next_batch, next_indices and the resident-epoch
+    form next_span -- are those of the reference's iterator, wrap-around batches and epoch counter included."""
+    from onofftf.main import DataSet
+    X = np.arange(n, dtype=float)[:, None] * np.array([[1.0, -1.0]])
+    Y = np.arange(n, dtype=float)[:, None] + 0.5
+    ref = _LiteralDataSet(X, Y)
+    seq = [ref.next_batch(b, shuffle) for _ in range(4 * n // b + 3)]
+    ds = DataSet(X, Y)
+    for xb, yb in seq:
+        x2, y2 = ds.next_batch(b, shuffle)
+        assert np.array_equal(x2, xb) and np.array_equal(y2, yb)
+    assert ds.epochs_completed == ref.ep
+    ds = DataSet(X, Y)
+    for xb, yb in seq:
+        idx = ds.next_indices(b, shuffle)
+        assert np.array_equal(X[idx], xb)
+    ds, uploads, last = DataSet(X, Y), 0, None
+    for xb, yb in seq:
+        gen, lo, hi, wrap = ds.next_span(b, shuffle)
+        if wrap is None:
+            if gen != last:
+                resident, last, uploads = (ds.xtrain.copy(), ds.ytrain.copy()), gen, uploads + 1     # what onoff() sends to the GPU
+            assert np.array_equal(resident[0][lo:hi], xb) and np.array_equal(resident[1][lo:hi], yb)
+        else:
+            assert np.array_equal(wrap[0], xb) and np.array_equal(wrap[1], yb)
+    assert uploads <= ds.epochs_completed + 1        # one upload per epoch, not one per batch
 
 
 def test_dataset_iterator_semantics():

@@ -33,7 +33,7 @@ def test_bench_self_launches_two_ranks_weak(engine):
     assert res['config']['rows_total'] == 2 * 65536
     # the same two shards through the engine directly, one rank each
     tot, kl = 0.0, None
-    engine.set_chunk(32768)
+    engine.set_chunk(32768)          # as bench.py's library rule at M = 256 would not: pin it for both sides
     for r in range(2):
         X, Y, p = bench.synth(65536, 256, 3, rank=r)
         engine.set_data(X, Y)
@@ -56,13 +56,43 @@ def test_bench_self_launches_two_ranks_strong(engine):
     assert abs(res['elbo_data'] - ed) <= 1e-11 * abs(ed) and abs(res['kl'] - kl) <= 1e-12 * abs(kl)
 
 
-def test_rccl_single_rank_exchange():
-    """The RCCL leg of the N > 1 path on the one-GPU box: process group 'nccl' with one rank, the packed vector through ShardedELBO's
-    pinned staging -> all_reduce on the GPU -> pinned -> unpack, barrier and MAX reduce (tools/nccl_selftest.py, own process)."""
+def test_rccl_single_rank_exchange_through_the_library():
+    """The RCCL leg of the N > 1 path on the one-GPU box (tools/nccl_selftest.py, own process): zigp_comm_unique_id / zigp_comm_init with
+    one rank, then every kind of step (dense, Kronecker fused / larger grid / panels, a head) through ncclAllReduce on the packed DEVICE
+    vector -- bit-identical to the same call without a communicator; a Cholesky failure surfaces after the exchange."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    env['MASTER_ADDR'] = '127.0.0.1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'nccl_selftest.py')], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and 'single-rank exchange ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_cfg4_per_rank_workload_two_ranks_through_the_launcher(engine):
+    """BASELINE cfg4 is 8 ranks x (1e6 rows, M = 1024); this is its PER-RANK workload through the same entry point with 2 ranks (gloo,
+    both on the box's one GPU): `bench.py --gpus 2 --rows 1000000 --M 1024`, one step.  The 2-rank ELBO must be the sum of the two
+    1-rank shard ELBOs (KL once), computed here with the engine directly on the same seeded shards."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--rows', '1000000', '--M', '1024', '--steps', '1',
+           '--warmup', '0', '--no-cpu-baseline', '--no-other-configs', '--profile-steps', '0']
     env = dict(os.environ)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
-    env['MASTER_ADDR'] = '127.0.0.1'
-    env['MASTER_PORT'] = '29671'
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'nccl_selftest.py')], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and 'single-rank exchange ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert res['n_gpus'] == 2 and res['n_ranks_seen'] == 2 and res['config']['rows_total'] == 2000000 and res['config']['M'] == 1024
+    assert res['config']['chunk_rows'] == 32768 and res['scaling'] == 'weak'
+    tot, kl = 0.0, None
+    engine.set_chunk(32768)          # the library's own rule at M = 1024 (other tests leave the shared engine on small chunks)
+    for rk in range(2):
+        X, Y, p = bench.synth(1000000, 1024, 3, rank=rk)
+        engine.set_data(X, Y)
+        ed, k, _ = engine.elbo(p, jitter=1e-6, include_kl=(rk == 0), need_grad=False)
+        tot += ed
+        kl = k if rk == 0 else kl
+    print('cfg4 per-rank workload x 2 ranks: elbo_data %.12e (sum of shards %.12e), kl %.10e, %.1f ms/step with two ranks on one GPU'
+          % (res['elbo_data'], tot, res['kl'], res['ms_per_step']))
+    assert abs(res['elbo_data'] - tot) <= 1e-11 * abs(tot), (res['elbo_data'], tot)
+    assert abs(res['kl'] - kl) <= 1e-12 * abs(kl)

@@ -1,30 +1,62 @@
-"""Single-rank RCCL rehearsal of the N > 1 exchange on a one-GPU box: init_process_group('nccl', world_size=1), then the
-packed [elbo_data, kl, grads] vector goes through the same copy -> all_reduce(SUM) -> copy path ShardedELBO uses for N > 1,
-plus the barrier / MAX-reduce bench.py brackets its timed region with."""
+"""Single-rank RCCL rehearsal of the N > 1 exchange on a one-GPU box, through the library's own communicator:
+zigp_comm_unique_id -> (torch.distributed 'nccl' broadcast of the id, world_size 1) -> zigp_comm_init -> every step's packed device
+vector goes through ncclAllReduce(sum, f64) on the engine's stream.  The sum over ONE rank is the identity, so every result must be
+bit-identical to the same call without a communicator: dense step, value-only step, Kronecker step (fused 32 x 32 and 10 x 100, and
+the panel path), a single-latent head.  Plus the barrier / MAX reduce bench.py brackets its timed region with."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'zero-inflated-gp_amd'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'zero-inflated-gp_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch, torch.distributed as dist
 import bench, zigp
-from zigp.parallel import ShardedELBO, pack, unpack
-os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29655')
+from zigp.parallel import ShardedELBO, ShardedKronELBO
+from test_gpu_kron import make_kron_problem
+
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', str(bench.free_port()))
 torch.cuda.set_device(0)
 dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+
+
+def same(a, b):
+    if isinstance(a, dict):
+        return set(a) == set(b) and all(same(a[k], b[k]) for k in a)
+    if isinstance(a, (list, tuple)):
+        return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+    return np.array_equal(np.asarray(a), np.asarray(b))
+
+
 X, Y, p = bench.synth(50000, 256, 3)
+Xk, Yk, pk = make_kron_problem(3000, 32, 32, seed=5)
+Xl, Yl, pl = make_kron_problem(1500, 10, 100, seed=6)
+Xp, Yp, pp = make_kron_problem(900, 40, 9, seed=7)            # beyond the fused kernels: panel path (host-side exchange)
+ph = {k: pk[k] for k in ('Zf', 'ell_f', 'var_f', 'u_fm', 'u_fs_sqrt', 'noise')}
 eng = zigp.DenseEngine(0); eng.set_data(X, Y)
-sh = ShardedELBO(eng, dist, device='cuda:0')
-ed, kl, g = sh.elbo(p)                      # world == 1: returns the local result
-vec, shapes = pack(ed, kl, g)
-buf = torch.empty(vec.size, dtype=torch.float64, device='cuda:0'); buf.copy_(torch.from_numpy(vec))
-dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-ed2, kl2, g2 = unpack(buf.cpu().numpy(), shapes)
-assert ed2 == ed and kl2 == kl and all(np.array_equal(np.asarray(g[k]), np.asarray(g2[k])) for k in g)
-sh.world = 2                                 # force the N > 1 branch (pinned staging -> all_reduce on the GPU -> pinned -> unpack); the sum over ONE rank is the identity
-ed3, kl3, g3 = sh.elbo(p)
-assert ed3 == ed and kl3 == kl and all(np.array_equal(np.asarray(g[k]), np.asarray(g3[k])) for k in g)
-assert sh._buf.is_cuda and sh._host.is_pinned()
+ref = dict(dense=eng.elbo(p), dense_value=eng.elbo(p, need_grad=False), dense_nokl=eng.elbo(p, include_kl=False),
+           kron=eng.kron_elbo(pk, Xk, Yk, scale=3.0, f_mu=0.25), kron_value=eng.kron_elbo(pk, Xk, Yk, need_grad=False),
+           kron_nokl=eng.kron_elbo(pk, Xk, Yk, include_kl=False), kron_large=eng.kron_elbo(pl, Xl, Yl),
+           kron_panel=eng.kron_elbo(pp, Xp, Yp), head=eng.kron_head_elbo(ph, Xk, (Yk > 0).astype(float), 'bernoulli', f_mu=0.1))
+assert eng.comm_info()['nranks'] == 0
+sh = ShardedELBO(eng, dist, device='cuda:0')              # backend nccl -> library communicator
+shk = ShardedKronELBO(eng, dist, device='cuda:0')        # same engine: shares the communicator
+assert sh.library_comm and shk.library_comm and eng.comm_info() == dict(rank=0, nranks=1, allreduce_calls=0)
+got = dict(dense=sh.elbo(p), dense_value=eng.elbo(p, need_grad=False), dense_nokl=eng.elbo(p, include_kl=False),
+           kron=eng.kron_elbo(pk, Xk, Yk, scale=3.0, f_mu=0.25), kron_value=eng.kron_elbo(pk, Xk, Yk, need_grad=False),
+           kron_nokl=eng.kron_elbo(pk, Xk, Yk, include_kl=False), kron_large=shk.kron_elbo(pl, Xl, Yl),
+           kron_panel=eng.kron_elbo(pp, Xp, Yp), head=eng.kron_head_elbo(ph, Xk, (Yk > 0).astype(float), 'bernoulli', f_mu=0.1))
+for k in ref:
+    assert same(ref[k], got[k]), k
+n = eng.comm_info()['allreduce_calls']
+assert n == len(ref), n                                    # one all-reduce per step, no more
+# a non-PD Kuu is reported after the exchange, and the communicator keeps working
+bad = dict(p, Zf=p['Zf'].copy()); bad['Zf'][1] = bad['Zf'][0]
+try:
+    eng.elbo(bad, jitter=0.0); raise SystemExit('expected NotPositiveDefiniteError')
+except zigp.NotPositiveDefiniteError:
+    pass
+assert same(eng.elbo(p), ref['dense'])
 t = torch.tensor([1.25], dtype=torch.float64, device='cuda:0'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
 assert float(t.item()) == 1.25
+sh.close()
+assert eng.comm_info()['nranks'] == 0 and same(eng.elbo(p), ref['dense'])
 dist.destroy_process_group()
-print('nccl (RCCL) single-rank exchange ok: %d doubles' % vec.size)
+print('RCCL single-rank exchange ok: %d all-reduces through zigp_comm_init' % n)

@@ -8,6 +8,7 @@
 #include <vector>
 #include <map>
 #include "../../include/zigp.h"
+#include "../../include/zigp_diag.h"
 #include "zigp_gemm.h"
 
 namespace zigp {
@@ -95,9 +96,7 @@ struct zigp_ctx {
   zigp::Latent lat[2];
   zigp::DevBuf pw_part;                 // pointwise block partials
   // mean function of f, m(x) = mean_b + mean_a . x (zigp_set_mean_function), and its gradient from the last zigp_elbo
-  bool capturing = false;               // diagnostic (zigp_test_kron_graph): enqueue only, no synchronisation or host post-processing
-  int overlap = 0;                      // zigp_set_overlap: 1 = HBM-bound side kernels of a chunk on stream2 under its SYRKs; 2 = the chunk chains of f and g on two streams
-  hipEvent_t ev_g = nullptr, ev_pw = nullptr, ev_gdone = nullptr;   // mode 2: g chain done / point-wise done / g's rank-N update done
+  int overlap = 0;                      // zigp_set_overlap: 1 = HBM-bound side kernels of a chunk on stream2 under its SYRKs
   bool mean_on = false;
   double mean_a[8] = {0}, mean_b = 0.0, mean_da[8] = {0}, mean_db = 0.0;   // 8 = zigp::MAXD (zigp_kernels.h)
   zigp::DevBuf out9;                    // predict outputs (9,Nc)
@@ -108,9 +107,12 @@ struct zigp_ctx {
   void (*kron_free)(zigp::KronState*) = nullptr;
   zigp::KfState* kronf = nullptr;
   void (*kronf_free)(zigp::KfState*) = nullptr;
-  bool kron_legacy = false;             // zigp_test_kron_graph: force the panel (GEMM-core) Kronecker path for its duration
-  bool kron_panels = false;             // zigp_set_kron_panels: the same, set by the caller
+  bool kron_panels = false;             // zigp_set_kron_panels: force the panel (GEMM-core) Kronecker path
   std::map<std::string, zigp::TileList> tiles;
+  // data-parallel exchange (zigp_comm_init): RCCL communicator, one rank per context / GPU
+  void* comm = nullptr; int comm_rank = 0, comm_nranks = 1; int64_t comm_calls = 0;
+  zigp::DevBuf packed;                  // result vector of the dense path (k_dense_pack)
+  double pivot_rtol = 8.0;              // zigp_set_pivot_rtol: a Cholesky pivot <= pivot_rtol * eps * (variance + jitter) is ZIGP_ENOTPD
   // profiling
   bool prof_on = false;
   int prof_every = 8;                    // chunk-loop launches are timed on every prof_every-th chunk (event pairs cost ~10 us)

@@ -17,6 +17,7 @@
 #include "zigp_ctx.h"
 #include "zigp_kernels.h"
 #include "zigp_host.h"
+#include "zigp_comm.h"
 #include <algorithm>
 #include <cmath>
 
@@ -50,7 +51,7 @@ int latent_upload(zigp_ctx* c, Latent& lt, const HostLatent& h, int D) {
 }
 
 // MxM forward for one latent (kernels only): Kuu, L, W.
-int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double jitter, bool want_W) {
+int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double jitter, bool want_W, double pivot_rtol) {
   ProfScope ps(c, PC_MXM);
   const int Mp = lt.Mp;
   hipLaunchKernelGGL(k_square, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.s.p, lt.s2.p, Mp);
@@ -59,7 +60,7 @@ int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double j
                      (int64_t)h.M, hyp, jitter, lt.Kuu.p, (int64_t)Mp, (int64_t)Mp, (int64_t)Mp);
   ZIGP_HIP(c, hipGetLastError());
   ZIGP_HIP(c, hipMemcpyAsync(lt.L.p, lt.Kuu.p, sizeof(double) * Mp * Mp, hipMemcpyDeviceToDevice, c->stream));
-  ZIGP_TRY(potrf_trtri(c, lt.L.p, lt.W.p, lt.T1.p, Mp, want_W, lt.M, pivot_tol(h.var, jitter)));
+  ZIGP_TRY(potrf_trtri(c, lt.L.p, lt.W.p, lt.T1.p, Mp, want_W, lt.M, pivot_tol(h.var, jitter, pivot_rtol)));
   return 0;
 }
 
@@ -143,8 +144,9 @@ int syr_slices(int nbm) {
 }
 
 // Kuf-cotangent reductions of one latent and chunk (HBM-read bound; runs on the side stream under the chunk's SYRKs)
-int latent_chunk_kgrad(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D) {
+int latent_chunk_kgrad(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D, const double* ell_host) {
   const int Mp = lt.Mp;
+  const KernHyp hyp = make_hyp(ell_host, lt.var, D);
   double* alpha = lt.vec.p + Mp;
   {
     ProfScope ps(c, PC_RED);
@@ -153,7 +155,7 @@ int latent_chunk_kgrad(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows,
 #define ZIGP_KGRAD(DD)                                                                                                            \
   case DD:                                                                                                                        \
     hipLaunchKernelGGL(k_kgrad<DD>, gk, bk, 0, c->stream, lt.Jp.p, lt.K.p, alpha, lt.gm.p, lt.gv.p, dX, Nrows, n0, lt.Z.p, lt.M, Nc, \
-                       slab, lt.krow.p);                                                                                                \
+                       slab, hyp, lt.krow.p);                                                                                                \
     break;
     switch (D) {
       ZIGP_KGRAD(1) ZIGP_KGRAD(2) ZIGP_KGRAD(3) ZIGP_KGRAD(4) ZIGP_KGRAD(5) ZIGP_KGRAD(6) ZIGP_KGRAD(7) ZIGP_KGRAD(8)
@@ -260,63 +262,69 @@ int validate_params(zigp_ctx* c, const zigp_params* p) {
   return 0;
 }
 
-// shared driver for zigp_elbo / zigp_predict
-int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double* dY, int64_t Nrows, int D, double jitter,
-              double scale, double g_offset, int64_t row_begin, int64_t row_end, int include_kl, bool predict, double* d_out9,
-              double* elbo_data, double* kl, zigp_grads* grads) {
-  const bool need_grad = (grads != nullptr) && !predict;
-  const bool has_rows = row_end > row_begin;
-  HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
-  const double* ell_h[2] = {p->ell_f, p->ell_g};
+// ---- one call of the dense path (zigp_elbo / zigp_predict), in four stages: MxM forward, chunk loop, MxM backward, gather ----
+struct DenseCall {
+  const zigp_params* p; const double* dX; const double* dY; int64_t Nrows; int D;
+  double jitter, scale, g_offset; int64_t row_begin, row_end; int include_kl; bool predict; double* d_out9;
+  bool need_grad, has_rows;
+  HostLatent hl[2]; const double* ell_h[2];
+  int64_t Nc = 0;         // rows per full chunk
+  int pw_blocks = 0;
+  int* hinfo = nullptr;   // Cholesky status, staged with the other results
+};
+
+// Parameters to the device, then the MxM forward of f on the main stream and of g on stream2 (dozens of small dependent launches each)
+int dense_mxm_forward(zigp_ctx* c, DenseCall& k) {
   ZIGP_TRY(begin_staged_call(c));
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
-  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_upload(c, c->lat[h], hl[h], D));
+  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_upload(c, c->lat[h], k.hl[h], k.D));
   {
-    // MxM forward of f on the main stream and of g on stream2 (dozens of small dependent launches each)
     TwoStream ts(c);
     ZIGP_TRY(ts.fork());
     for (int h = 0; h < 2; ++h) {
       if (h == 1) ts.second();
-      ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], D, jitter, true));
-      // v = W u and alpha = W^T v are needed by the KL value AND by the rank-1 parts of the data-term gradient
-      ZIGP_TRY(latent_kl(c, c->lat[h]));   // v = W u feeds the fused mean (v^T A1) in every mode
-      if (need_grad) ZIGP_TRY(latent_forward_grad(c, c->lat[h]));
+      ZIGP_TRY(latent_forward(c, c->lat[h], k.hl[h], k.D, k.jitter, true, c->pivot_rtol));
+      // v = W u and alpha = W^T v are needed by the KL value, by the fused mean (v^T A1) and by the rank-1 parts of the data-term gradient
+      ZIGP_TRY(latent_kl(c, c->lat[h]));
+      if (k.need_grad) ZIGP_TRY(latent_forward_grad(c, c->lat[h]));
     }
     ZIGP_TRY(ts.join());
   }
-  int* hinfo = nullptr;
-  ZIGP_TRY(request_info(c, &hinfo));   // read after the final synchronisation
+  return request_info(c, &k.hinfo);   // read after the final synchronisation
+}
 
-  // chunk rows: the row range is cut into ceil(span / chunk) chunks of (nearly) equal size, a multiple of 1024, so that the
-  // last chunk is not a sliver whose GEMMs leave most of the 512 workgroup slots empty (N = 1e5, chunk 32768: 4 x 25600)
-  // Unless the caller fixed it (zigp_set_chunk), the chunk scales with 1 / M so that a launch keeps its ~2000 tiles (4 waves of the 512
-  // workgroup slots) and the panels their size: 32768 rows at M = 1024, 65536 at M = 512 (cfg2: 2 chunks instead of 4, 8.05 -> 7.6 ms)
-  int64_t chunk = c->chunk;
-  if (c->chunk_auto) {
-    const int64_t Mmax = std::max(c->lat[0].Mp, c->lat[1].Mp);
-    chunk = std::min<int64_t>(131072, std::max<int64_t>(32768, round_up(32768 * 1024 / std::max<int64_t>(Mmax, 128), 1024)));
-  }
-  int64_t Nc = chunk;
-  const int64_t span = has_rows ? (row_end - row_begin) : 0;
+// Chunk size and per-call buffers.  The row range is cut into ceil(span / chunk) chunks of (nearly) equal size, a multiple of 1024, so
+// that the last chunk is not a sliver whose GEMMs leave most of the 512 workgroup slots empty (N = 1e5, chunk 32768: 4 x 25600).
+// Unless the caller fixed it (zigp_set_chunk), the chunk scales with 1 / M so that a launch keeps its ~2000 tiles (4 waves of the 512
+// workgroup slots) and the panels their size: 32768 rows at M = 1024, 65536 at M = 512 (cfg2: 2 chunks instead of 4, 8.05 -> 7.6 ms)
+int64_t auto_chunk(const zigp_ctx* c) {
+  if (!c->chunk_auto) return c->chunk;
+  const int64_t Mmax = std::max(c->lat[0].Mp, c->lat[1].Mp);
+  return std::min<int64_t>(131072, std::max<int64_t>(32768, round_up(32768 * 1024 / std::max<int64_t>(Mmax, 128), 1024)));
+}
+int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
+  const int64_t chunk = auto_chunk(c);
+  const int64_t span = k.has_rows ? (k.row_end - k.row_begin) : 0;
+  k.Nc = 1024;
   if (span > 0) {
     const int64_t nchunks = (span + chunk - 1) / chunk;
-    Nc = std::max<int64_t>(1024, round_up((span + nchunks - 1) / nchunks, 1024));
-  } else {
-    Nc = 1024;
+    k.Nc = std::max<int64_t>(1024, round_up((span + nchunks - 1) / nchunks, 1024));
   }
-  const int pw_blocks = (int)(Nc / PW_PTS);
-  ZIGP_ENSURE(c, c->pw_part, (size_t)pw_blocks * PW_ACC);
-  ZIGP_HIP(c, hipMemsetAsync(c->pw_part.p, 0, sizeof(double) * pw_blocks * PW_ACC, c->stream));
+  const int64_t Nc = k.Nc;
+  const int D = k.D;
+  k.pw_blocks = (int)(Nc / PW_PTS);
+  ZIGP_ENSURE(c, c->pw_part, (size_t)k.pw_blocks * PW_ACC);
+  ZIGP_HIP(c, hipMemsetAsync(c->pw_part.p, 0, sizeof(double) * k.pw_blocks * PW_ACC, c->stream));
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
     const int Mp = lt.Mp;
     ZIGP_ENSURE(c, lt.gm, Nc); ZIGP_ENSURE(c, lt.gv, Nc);
-    if (has_rows) {
+    if (k.has_rows) {
       ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A2, (size_t)Mp * Nc);
       ZIGP_ENSURE(c, lt.part, (size_t)3 * (Mp / 32) * Nc);
-      if (need_grad) { ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc); }
+      if (k.need_grad) { ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc); }
     }
-    if (need_grad) {
+    if (k.need_grad) {
       ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)KG_SPLIT * Mp * (2 + 2 * D));
       const int S = syr_slices(Mp / BM);
       ZIGP_ENSURE(c, lt.dLpart, (size_t)S * Mp * Mp);
@@ -325,17 +333,46 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
       ZIGP_HIP(c, hipMemsetAsync(lt.du.p, 0, sizeof(double) * Mp, c->stream));
       ZIGP_HIP(c, hipMemsetAsync(lt.dsq.p, 0, sizeof(double) * Mp, c->stream));
       ZIGP_HIP(c, hipMemsetAsync(lt.krow.p, 0, sizeof(double) * KG_SPLIT * Mp * (2 + 2 * D), c->stream));
-      if (has_rows) ZIGP_HIP(c, hipMemsetAsync(lt.dLpart.p, 0, sizeof(double) * S * Mp * Mp, c->stream));
+      if (k.has_rows) ZIGP_HIP(c, hipMemsetAsync(lt.dLpart.p, 0, sizeof(double) * S * Mp * Mp, c->stream));
     }
   }
-  // ---- chunk loop.  The MFMA-bound GEMMs stay on the main stream; the HBM-bound kernels of a chunk -- the two Kuf-cotangent
-  // reductions and the two Kuf panels of the NEXT chunk -- run on the side stream underneath the chunk's two SYRKs:
-  //   main:  [wait side]  A1 A2 H J' (f, g)  point-wise  (record)  SYRK f  SYRK g
-  //   side:                                              (wait)    kgrad f  kgrad g  Kuf f'  Kuf g'  (record)
-  // K is only read by A1 and kgrad, J' / gm only by kgrad: the next chunk's GEMMs wait for the side stream, nothing else is
-  // shared.  A chunk whose kernels are being timed (profiling samples every prof_every-th chunk) runs everything on the main
-  // stream, so the per-kernel durations bench.py reports are those of kernels running alone.
-  const int64_t Nc_full = Nc;
+  return 0;
+}
+
+// point-wise stage of the chunk starting at row n0 (probit moments, expected log-likelihood, reverse pass to gm / gv)
+int dense_pointwise(zigp_ctx* c, const DenseCall& k, int64_t n0, int64_t Nc) {
+  ProfScope ps(c, PC_POINT);
+  PwArgs a;
+  a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32;
+  {
+    constexpr int RW1 = Shape<WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false>::value>::RW, RW2 = Shape<WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false>::value>::RW;
+    static_assert(RW1 >= 32 && RW2 >= 32, "partial-row planes are allocated for 32-row wave tiles");
+    a.np1_f = c->lat[0].Mp / RW1; a.np2_f = c->lat[0].Mp / RW2; a.np1_g = c->lat[1].Mp / RW1; a.np2_g = c->lat[1].Mp / RW2;
+  }
+  a.Y = k.dY; a.n0 = n0; a.row_end = k.row_end; a.Nc = Nc;
+  a.var_f = k.p->var_f; a.var_g = k.p->var_g; a.noise = k.p->noise; a.g_offset = k.g_offset; a.scale = k.scale;
+  a.gm_f = k.need_grad ? c->lat[0].gm.p : nullptr; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
+  a.X = k.dX; a.D = k.D; a.mean_on = c->mean_on ? 1 : 0; a.mean_b = c->mean_b;
+  for (int d = 0; d < MAXD; ++d) a.mean_a[d] = (d < k.D) ? c->mean_a[d] : 0.0;
+  a.acc = c->pw_part.p; a.out9 = k.d_out9 ? k.d_out9 - k.row_begin : nullptr; a.ld9 = k.row_end - k.row_begin;
+  const int nblk = (int)(Nc / PW_PTS);
+  if (k.predict) hipLaunchKernelGGL(k_pointwise<true>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_pointwise<false>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+
+// ---- chunk loop.  The MFMA-bound GEMMs stay on the main stream; with zigp_set_overlap(1) the HBM-bound kernels of a chunk -- the two
+// Kuf-cotangent reductions and the two Kuf panels of the NEXT chunk -- run on the side stream underneath the chunk's two SYRKs:
+//   main:  [wait side]  A1 A2 H J' (f, g)  point-wise  (record)  SYRK f  SYRK g
+//   side:                                              (wait)    kgrad f  kgrad g  Kuf f'  Kuf g'  (record)
+// K is only read by A1 (and its rows' x, z by kgrad), J' / gm only by kgrad: the next chunk's GEMMs wait for the side stream, nothing
+// else is shared.  A chunk whose kernels are being timed (profiling samples every prof_every-th chunk) runs everything on the main
+// stream, so the per-kernel durations bench.py reports are those of kernels running alone.
+int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
+  if (!k.has_rows) return 0;
+  const int64_t Nc_full = k.Nc, row_begin = k.row_begin, row_end = k.row_end;
+  const int D = k.D;
   auto chunk_rows = [&](int64_t n0) { return std::min<int64_t>(Nc_full, round_up(row_end - n0, 1024)); };
   auto sampled = [&](int64_t n0) {   // kernel timing (HIP events) covers FULL chunks only, so the averages describe full-size launches
     if (!c->prof_on) return false;
@@ -344,198 +381,122 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   };
   struct SideGuard { zigp_ctx* c; ~SideGuard() { c->stream = c->stream_main; c->prof_skip = false; } } side_guard{c};
   bool side_busy = false;
-  // ---- mode 2 (zigp_set_overlap(ctx, 2), gradient steps without kernel timing): the chunk chains of the two latents are independent
-  // until the point-wise stage, so f runs on the main stream and g on stream2:
-  //   main:   Kuf_f A1 A2 H J' (f)   [wait g]  point-wise  (ev_pw)  kgrad_f  SYRK_f
-  //   side:   Kuf_g A1 A2 H J' (g)   (ev_g)    [wait pw]            kgrad_g  SYRK_g  (ev_gdone)
-  // The next point-wise kernel (main) rewrites gm_g / gv_g, which SYRK_g of this chunk (side) still reads: it waits for ev_gdone.
-  // Two full-chip GEMMs in flight fill each other's tails; the kernels and every reduction order are unchanged (bit-identical results).
-  bool chains_done = false;
-  if (c->overlap == 2 && need_grad && has_rows && !c->prof_on) {
-    ZIGP_HIP(c, hipEventRecord(c->ev_fork, c->stream_main));              // everything enqueued so far (uploads, MxM forward, memsets)
-    ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    bool g_busy = false;
-    for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc_full) {
-      Nc = chunk_rows(n0);
-      for (int h = 0; h < 2; ++h) {
-        c->stream = h == 0 ? c->stream_main : c->stream2;
-        ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], dX, Nrows, n0, Nc, D, ell_h[h]));
-        ZIGP_TRY(latent_chunk_forward(c, c->lat[h], Nc, true));
-      }
-      ZIGP_HIP(c, hipEventRecord(c->ev_g, c->stream2));
-      c->stream = c->stream_main;
-      ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_g, 0));
-      if (g_busy) ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_gdone, 0));
-      {
-        PwArgs a;
-        a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32;
-        constexpr int RW1 = Shape<WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false>::value>::RW, RW2 = Shape<WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false>::value>::RW;
-        a.np1_f = c->lat[0].Mp / RW1; a.np2_f = c->lat[0].Mp / RW2; a.np1_g = c->lat[1].Mp / RW1; a.np2_g = c->lat[1].Mp / RW2;
-        a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
-        a.var_f = p->var_f; a.var_g = p->var_g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
-        a.gm_f = c->lat[0].gm.p; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
-        a.X = dX; a.D = D; a.mean_on = c->mean_on ? 1 : 0; a.mean_b = c->mean_b;
-        for (int d = 0; d < MAXD; ++d) a.mean_a[d] = (d < D) ? c->mean_a[d] : 0.0;
-        a.acc = c->pw_part.p; a.out9 = nullptr; a.ld9 = row_end - row_begin;
-        hipLaunchKernelGGL(k_pointwise<false>, dim3((unsigned)(Nc / PW_PTS)), dim3(PW_THREADS), 0, c->stream_main, a);
-        ZIGP_HIP(c, hipGetLastError());
-      }
-      ZIGP_HIP(c, hipEventRecord(c->ev_pw, c->stream_main));
-      ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_pw, 0));
-      for (int h = 0; h < 2; ++h) {
-        c->stream = h == 0 ? c->stream_main : c->stream2;
-        ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], dX, Nrows, n0, Nc, D));
-        ZIGP_TRY(latent_chunk_syrk(c, c->lat[h], Nc));
-      }
-      ZIGP_HIP(c, hipEventRecord(c->ev_gdone, c->stream2));
-      g_busy = true;
-      c->stream = c->stream_main;
-    }
-    if (g_busy) ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_gdone, 0));
-    row_begin = row_end;   // the single-stream loop below has nothing left to do
-    chains_done = true;
-  }
-  if (has_rows && !chains_done) {
-    c->prof_skip = c->prof_on && !sampled(row_begin);
-    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], dX, Nrows, row_begin, chunk_rows(row_begin), D, ell_h[h]));
-  }
+  c->prof_skip = c->prof_on && !sampled(row_begin);
+  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, row_begin, chunk_rows(row_begin), D, k.ell_h[h]));
   for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc_full) {
-    Nc = chunk_rows(n0);   // the last (partial) chunk shrinks to the next multiple of 1024 rows
+    const int64_t Nc = chunk_rows(n0);   // the last (partial) chunk shrinks to the next multiple of 1024 rows
     const int64_t n1 = n0 + Nc_full;
     const bool has_next = n1 < row_end;
     const bool timed = sampled(n0), timed_next = has_next && sampled(n1);
     c->prof_skip = c->prof_on && !timed;
     if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
-    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], Nc, need_grad));
-    {
-      ProfScope ps(c, PC_POINT);
-      PwArgs a;
-      a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32;
-      {
-        constexpr int RW1 = Shape<WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false>::value>::RW, RW2 = Shape<WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false>::value>::RW;
-        static_assert(RW1 >= 32 && RW2 >= 32, "partial-row planes are allocated for 32-row wave tiles");
-        a.np1_f = c->lat[0].Mp / RW1; a.np2_f = c->lat[0].Mp / RW2; a.np1_g = c->lat[1].Mp / RW1; a.np2_g = c->lat[1].Mp / RW2;
-      }
-      a.Y = dY; a.n0 = n0; a.row_end = row_end; a.Nc = Nc;
-      a.var_f = p->var_f; a.var_g = p->var_g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
-      a.gm_f = need_grad ? c->lat[0].gm.p : nullptr; a.gv_f = c->lat[0].gv.p; a.gm_g = c->lat[1].gm.p; a.gv_g = c->lat[1].gv.p;
-      a.X = dX; a.D = D; a.mean_on = c->mean_on ? 1 : 0; a.mean_b = c->mean_b;
-      for (int d = 0; d < MAXD; ++d) a.mean_a[d] = (d < D) ? c->mean_a[d] : 0.0;
-      a.acc = c->pw_part.p; a.out9 = d_out9 ? d_out9 - row_begin : nullptr; a.ld9 = row_end - row_begin;
-      const int nblk = (int)(Nc / PW_PTS);
-      if (predict) hipLaunchKernelGGL(k_pointwise<true>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
-      else hipLaunchKernelGGL(k_pointwise<false>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
-      ZIGP_HIP(c, hipGetLastError());
-    }
+    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], Nc, k.need_grad));
+    ZIGP_TRY(dense_pointwise(c, k, n0, Nc));
     // side work of this chunk: its kgrads and the next chunk's Kuf panels (gradient mode only: without the SYRKs there is
     // nothing on the main stream to hide them under)
-    const bool kgrad_side = c->overlap == 1 && need_grad && !timed;
+    const bool kgrad_side = c->overlap == 1 && k.need_grad && !timed;
     const bool kuf_side = kgrad_side && has_next && !timed_next;
     if (kgrad_side) {
       ZIGP_HIP(c, hipEventRecord(c->ev_fork, c->stream_main));
       ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
       c->stream = c->stream2;
-      for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], dX, Nrows, n0, Nc, D));
+      for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], k.dX, k.Nrows, n0, Nc, D, k.ell_h[h]));
       if (kuf_side)
-        for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], dX, Nrows, n1, chunk_rows(n1), D, ell_h[h]));
+        for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]));
       ZIGP_HIP(c, hipEventRecord(c->ev_join, c->stream2));
       side_busy = true;
       c->stream = c->stream_main;
     }
-    if (need_grad) {
+    if (k.need_grad) {
       if (!kgrad_side)
-        for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], dX, Nrows, n0, Nc, D));
+        for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], k.dX, k.Nrows, n0, Nc, D, k.ell_h[h]));
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_syrk(c, c->lat[h], Nc));
     }
     if (has_next && !kuf_side) {   // a timed next chunk gets its panels from the main stream, with the side stream drained
       if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
       c->prof_skip = c->prof_on && !timed_next;
-      for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], dX, Nrows, n1, chunk_rows(n1), D, ell_h[h]));
+      for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]));
     }
   }
   if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
   c->prof_skip = false;
-  if (predict) { ZIGP_HIP(c, hipStreamSynchronize(c->stream)); prof_collect(c); return info_result(c, hinfo, "Kuu"); }
-  if (need_grad)
-  {
-    TwoStream ts(c);
-    ZIGP_TRY(ts.fork());
-    for (int h = 0; h < 2; ++h) {
-      if (h == 1) ts.second();
-      ZIGP_TRY(latent_mxm_backward(c, c->lat[h], D, jitter, has_rows, include_kl != 0));
-    }
-    ZIGP_TRY(ts.join());
-  }
+  return 0;
+}
 
-  // ---- gather results on the host (fixed-order final sums) ----
-  double* hpw = nullptr;
-  ZIGP_TRY(download(c, c->pw_part.p, (size_t)pw_blocks * PW_ACC, &hpw));
-  double *hvec[2] = {nullptr, nullptr}, *hdu[2] = {nullptr, nullptr}, *hdsq[2] = {nullptr, nullptr}, *hkrow[2] = {nullptr, nullptr};
+// The call's result vector (layout: k_dense_pack) is assembled on the device, summed over the ranks of a data-parallel run where it
+// lies (zigp_comm_init; no-op otherwise), downloaded once and unpacked: the call's single synchronisation.
+int dense_gather(zigp_ctx* c, DenseCall& k, double* elbo_data, double* kl, zigp_grads* grads) {
+  const int D = k.D;
+  size_t n = DP_HDR;
+  DensePackArgs a;
+  memset(&a, 0, sizeof(a));
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
-    if (include_kl || need_grad) ZIGP_TRY(download(c, lt.vec.p, (size_t)3 * lt.Mp + 8, &hvec[h]));
-    if (need_grad) {
-      ZIGP_TRY(download(c, lt.du.p, lt.Mp, &hdu[h]));
-      ZIGP_TRY(download(c, lt.dsq.p, lt.Mp, &hdsq[h]));
-      ZIGP_TRY(download(c, lt.krow.p, (size_t)KG_SPLIT * lt.Mp * (2 + 2 * D), &hkrow[h]));
-    }
+    DensePackLat& L = a.lat[h];
+    L.krow = lt.krow.p; L.du = lt.du.p; L.dsq = lt.dsq.p; L.vec = lt.vec.p; L.s = lt.s.p; L.ell = lt.ell.p;
+    L.M = lt.M; L.Mp = lt.Mp; L.var = lt.var; L.out_off = (int64_t)n;
+    if (k.need_grad) n += (size_t)lt.M * D + 2 * (size_t)lt.M + D;
   }
+  a.pw = c->pw_part.p; a.pw_blocks = k.pw_blocks; a.D = D; a.need_grad = k.need_grad ? 1 : 0; a.include_kl = k.include_kl ? 1 : 0;
+  a.mean_on = c->mean_on ? 1 : 0;
+  ZIGP_ENSURE(c, c->packed, n);
+  a.out = c->packed.p;
+  hipLaunchKernelGGL(k_dense_pack, dim3(2), dim3(256), 0, c->stream, a);
+  ZIGP_HIP(c, hipGetLastError());
+  ZIGP_TRY(comm_allreduce(c, c->packed.p, n));
+  double* hv = nullptr;
+  ZIGP_TRY(download(c, c->packed.p, n, &hv));
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
-  ZIGP_TRY(info_result(c, hinfo, "Kuu"));
-  double s_ve = 0, s_dn = 0, s_gvf = 0, s_gvg = 0;
-  for (int b = 0; b < pw_blocks; ++b) { s_ve += hpw[PW_ACC * b]; s_dn += hpw[PW_ACC * b + 1]; s_gvf += hpw[PW_ACC * b + 2]; s_gvg += hpw[PW_ACC * b + 3]; }
-  c->mean_db = 0.0;
-  for (int d = 0; d < MAXD; ++d) c->mean_da[d] = 0.0;
-  if (c->mean_on)
-    for (int b = 0; b < pw_blocks; ++b) {
-      c->mean_db += hpw[PW_ACC * b + 4];
-      for (int d = 0; d < D; ++d) c->mean_da[d] += hpw[PW_ACC * b + 5 + d];
-    }
-  if (elbo_data) *elbo_data = s_ve;
-  double klsum = 0.0;
-  if (include_kl) klsum = hvec[0][3 * c->lat[0].Mp] + hvec[1][3 * c->lat[1].Mp];
-  if (kl) *kl = klsum;
-  if (need_grad) {
+  ZIGP_TRY(info_result(c, k.hinfo, "Kuu"));
+  if (elbo_data) *elbo_data = hv[0];
+  if (kl) *kl = hv[1];
+  c->mean_db = hv[5];
+  for (int d = 0; d < MAXD; ++d) c->mean_da[d] = hv[6 + d];
+  if (k.need_grad) {
     double* gZ[2] = {grads->Zf, grads->Zg};
     double* gu[2] = {grads->u_fm, grads->u_gm};
     double* gs[2] = {grads->u_fs_sqrt, grads->u_gs_sqrt};
     double* gl[2] = {grads->ell_f, grads->ell_g};
-    double gvar[2];
-    const double sgv[2] = {s_gvf, s_gvg};
     for (int h = 0; h < 2; ++h) {
-      Latent& lt = c->lat[h];
-      const int M = lt.M, W = 2 + 2 * D;
-      const double* ell = ell_h[h];
-      double dv = 0.0;
-      std::vector<double> dl(D, 0.0);
-      for (int m = 0; m < M; ++m) {
-        double r[2 + 2 * MAXD];
-        for (int q = 0; q < W; ++q) {   // column splits summed in fixed order
-          double a = 0.0;
-          for (int sp = 0; sp < KG_SPLIT; ++sp) a += hkrow[h][((size_t)sp * lt.Mp + m) * W + q];
-          r[q] = a;
-        }
-        dv += r[0];
-        for (int d = 0; d < D; ++d) {
-          if (gZ[h]) gZ[h][m * D + d] = r[1 + d] / (ell[d] * ell[d]);
-          dl[d] += r[1 + D + d];
-        }
-        double dum = hdu[h][m], dsm = 2.0 * hl[h].s[m] * hdsq[h][m];
-        if (include_kl) {
-          dum -= hvec[h][lt.Mp + m];
-          dsm -= (-1.0 / hl[h].s[m] + hvec[h][2 * lt.Mp + m] * hl[h].s[m]);
-        }
-        if (gu[h]) gu[h][m] = dum;
-        if (gs[h]) gs[h][m] = dsm;
-      }
-      for (int d = 0; d < D; ++d)
-        if (gl[h]) gl[h][d] = dl[d] / (ell[d] * ell[d] * ell[d]);
-      gvar[h] = dv / lt.var + sgv[h];
+      const size_t M = (size_t)c->lat[h].M;
+      const double* o = hv + a.lat[h].out_off;
+      if (gZ[h]) memcpy(gZ[h], o, sizeof(double) * M * D);
+      if (gu[h]) memcpy(gu[h], o + M * D, sizeof(double) * M);
+      if (gs[h]) memcpy(gs[h], o + M * D + M, sizeof(double) * M);
+      if (gl[h]) memcpy(gl[h], o + M * D + 2 * M, sizeof(double) * D);
     }
-    grads->var_f = gvar[0]; grads->var_g = gvar[1]; grads->noise = s_dn;
+    grads->var_f = hv[2]; grads->var_g = hv[3]; grads->noise = hv[4];
   }
   return 0;
+}
+
+// shared driver for zigp_elbo / zigp_predict
+int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double* dY, int64_t Nrows, int D, double jitter,
+              double scale, double g_offset, int64_t row_begin, int64_t row_end, int include_kl, bool predict, double* d_out9,
+              double* elbo_data, double* kl, zigp_grads* grads) {
+  DenseCall k;
+  k.p = p; k.dX = dX; k.dY = dY; k.Nrows = Nrows; k.D = D; k.jitter = jitter; k.scale = scale; k.g_offset = g_offset;
+  k.row_begin = row_begin; k.row_end = row_end; k.include_kl = include_kl; k.predict = predict; k.d_out9 = d_out9;
+  k.need_grad = (grads != nullptr) && !predict;
+  k.has_rows = row_end > row_begin;
+  k.hl[0] = HostLatent{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f};
+  k.hl[1] = HostLatent{p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g};
+  k.ell_h[0] = p->ell_f; k.ell_h[1] = p->ell_g;
+  ZIGP_TRY(dense_mxm_forward(c, k));
+  ZIGP_TRY(dense_prepare_buffers(c, k));
+  ZIGP_TRY(dense_chunk_loop(c, k));
+  if (predict) { ZIGP_HIP(c, hipStreamSynchronize(c->stream)); prof_collect(c); return info_result(c, k.hinfo, "Kuu"); }
+  if (k.need_grad) {
+    TwoStream ts(c);
+    ZIGP_TRY(ts.fork());
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1) ts.second();
+      ZIGP_TRY(latent_mxm_backward(c, c->lat[h], D, jitter, k.has_rows, include_kl != 0));
+    }
+    ZIGP_TRY(ts.join());
+  }
+  return dense_gather(c, k, elbo_data, kl, grads);
 }
 
 }  // namespace
@@ -559,9 +520,7 @@ int zigp_create(zigp_ctx** out, int device_id) {
   c->stream_main = c->stream;
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_g, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_pw, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_gdone, hipEventDisableTiming) != hipSuccess) { delete c; return ZIGP_EHIP; }
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipMalloc((void**)&c->d_info, sizeof(int)) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(sizeof(double) * PB * PBLD)) != hipSuccess) { delete c; return ZIGP_EHIP; }
@@ -574,13 +533,14 @@ int zigp_destroy(zigp_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream_main);
   (void)hipStreamSynchronize(c->stream2);
+  if (c->comm) { RcclApi* api = rccl_api(nullptr); if (api) (void)api->CommDestroy(static_cast<ncclComm_t>(c->comm)); c->comm = nullptr; }
   for (int h = 0; h < 2; ++h) {
     Latent& l = c->lat[h];
     DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.H, &l.Jp, &l.Wp, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
                     &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec, &l.sk};
     for (DevBuf* b : bs) b->release();
   }
-  DevBuf* bs[] = {&c->ownX, &c->ownY, &c->pw_part, &c->out9, &c->scratch, &c->scratch2};
+  DevBuf* bs[] = {&c->ownX, &c->ownY, &c->pw_part, &c->out9, &c->scratch, &c->scratch2, &c->packed};
   for (DevBuf* b : bs) b->release();
   if (c->kron && c->kron_free) c->kron_free(c->kron);
   if (c->kronf && c->kronf_free) c->kronf_free(c->kronf);
@@ -590,9 +550,6 @@ int zigp_destroy(zigp_ctx* c) {
   c->pinned.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  if (c->ev_g) (void)hipEventDestroy(c->ev_g);
-  if (c->ev_pw) (void)hipEventDestroy(c->ev_pw);
-  if (c->ev_gdone) (void)hipEventDestroy(c->ev_gdone);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream_main) (void)hipStreamDestroy(c->stream_main);
   delete c;
@@ -604,7 +561,7 @@ int zigp_last_info(zigp_ctx* c) { return c ? c->info : 0; }
 
 int zigp_set_overlap(zigp_ctx* c, int32_t on) {
   if (!c) return ZIGP_EARG;
-  if (on < 0 || on > 2) return fail_arg(c, "zigp_set_overlap: mode must be 0, 1 or 2");
+  if (on < 0 || on > 1) return fail_arg(c, "zigp_set_overlap: mode must be 0 or 1");
   c->overlap = on;
   return ZIGP_OK;
 }
@@ -615,6 +572,69 @@ int zigp_set_chunk(zigp_ctx* c, int64_t chunk_rows) {
   if (chunk_rows > (1 << 20)) return fail_arg(c, "chunk must be <= 1048576 rows (32-bit staging offsets; 5 panels of 8*M*chunk bytes per latent)");
   c->chunk = chunk_rows;
   c->chunk_auto = false;
+  return ZIGP_OK;
+}
+
+int zigp_set_pivot_rtol(zigp_ctx* c, double rtol) {
+  if (!c) return ZIGP_EARG;
+  if (!(rtol >= 0) || !std::isfinite(rtol)) return fail_arg(c, "zigp_set_pivot_rtol: rtol must be finite and >= 0");
+  c->pivot_rtol = rtol;
+  return ZIGP_OK;
+}
+
+int64_t zigp_get_chunk(zigp_ctx* c, int32_t M) {
+  if (!c || M <= 0) return ZIGP_EARG;
+  if (!c->chunk_auto) return c->chunk;
+  const int64_t Mp = round_up(M, BM);
+  return std::min<int64_t>(131072, std::max<int64_t>(32768, round_up(32768 * 1024 / std::max<int64_t>(Mp, 128), 1024)));
+}
+
+// ---- data-parallel exchange ----
+int zigp_comm_unique_id(void* id128) {
+  if (!id128) return ZIGP_EARG;
+  RcclApi* api = rccl_api(nullptr);
+  if (!api) return ZIGP_ECOMM;
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return ZIGP_ECOMM;
+  static_assert(sizeof(ncclUniqueId) == ZIGP_COMM_ID_BYTES, "zigp.h promises a 128-byte id");
+  memcpy(id128, &id, sizeof(id));
+  return ZIGP_OK;
+}
+
+int zigp_comm_init(zigp_ctx* c, int32_t rank, int32_t nranks, const void* id128) {
+  if (!c) return ZIGP_EARG;
+  if (!id128 || nranks <= 0 || rank < 0 || rank >= nranks) return fail_arg(c, "zigp_comm_init: need 0 <= rank < nranks and the 128-byte id of zigp_comm_unique_id");
+  if (c->comm) return fail_arg(c, "zigp_comm_init: this context already has a communicator (zigp_comm_destroy first)");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  RcclApi* api = rccl_api(&c->err);
+  if (!api) return ZIGP_ECOMM;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = api->CommInitRank(&comm, nranks, id, rank);
+  if (r != ncclSuccess) return fail_comm(c, api, "ncclCommInitRank", r);
+  c->comm = comm; c->comm_rank = rank; c->comm_nranks = nranks; c->comm_calls = 0;
+  return ZIGP_OK;
+}
+
+int zigp_comm_destroy(zigp_ctx* c) {
+  if (!c) return ZIGP_EARG;
+  if (!c->comm) return ZIGP_OK;
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream_main));
+  RcclApi* api = rccl_api(&c->err);
+  if (!api) return ZIGP_ECOMM;
+  const ncclResult_t r = api->CommDestroy(static_cast<ncclComm_t>(c->comm));
+  c->comm = nullptr; c->comm_rank = 0; c->comm_nranks = 1;
+  if (r != ncclSuccess) return fail_comm(c, api, "ncclCommDestroy", r);
+  return ZIGP_OK;
+}
+
+int zigp_comm_info(zigp_ctx* c, int32_t* rank, int32_t* nranks, int64_t* allreduce_calls) {
+  if (!c) return ZIGP_EARG;
+  if (rank) *rank = c->comm ? c->comm_rank : 0;
+  if (nranks) *nranks = c->comm ? c->comm_nranks : 0;
+  if (allreduce_calls) *allreduce_calls = c->comm_calls;
   return ZIGP_OK;
 }
 
@@ -702,7 +722,7 @@ int zigp_prior_kl(zigp_ctx* c, const zigp_params* p, double jitter, double* kl2)
   ZIGP_TRY(begin_staged_call(c));
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
   for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_upload(c, c->lat[h], hl[h], p->D));
-  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], p->D, jitter, true));
+  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], p->D, jitter, true, c->pivot_rtol));
   ZIGP_TRY(check_info(c, "Kuu"));
   for (int h = 0; h < 2; ++h) {
     ZIGP_TRY(latent_kl(c, c->lat[h]));

@@ -199,13 +199,6 @@ __device__ __forceinline__ void glds_lane_offsets(uint32_t (&off)[16 / WAVES], i
 #ifndef ZIGP_BPAD
 #define ZIGP_BPAD 1
 #endif
-// ZIGP_TRI16 = 1 / 2: triangular skipping at 16- / 32-row granularity through compile-time specialised loop bodies (no runtime
-// predicates).  Measured (round 2, same box): with more than one unrolled body in the kernel the register allocator spills (the
-// 4-wave kernels sit at 255-256 VGPRs with ONE body): 84-504 B/lane of scratch, step 310 ms (=2) / 379 ms (=1) against 196 ms -- also with
-// per-body opaque address registers (no load hoisting across the branch).  Off.
-#ifndef ZIGP_TRI16
-#define ZIGP_TRI16 0
-#endif
 template <int LAY, int WAVES, bool PAD = false>
 __device__ __forceinline__ void glds_tile(double* tile, const char* __restrict__ base, const uint32_t (&off)[16 / WAVES], int wave) {
 #pragma unroll
@@ -327,21 +320,11 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
     // triangular A, or whose whole 64x64 output lies above the diagonal of a lower-triangular C, issues no MFMAs
     // (it still takes part in staging and barriers; the co-resident workgroup gets the matrix pipe).
     const int krel = (kb0 + (int)kd * it) * BK - tl.bi * BM;   // k offset of this step relative to the row block
-    // One BK step for the 16-row sub-tiles tm in [LO, HI] of this wave and, if CDIAG, only the 16-column sub-tiles tn <= tm.  The
-    // bounds are COMPILE-TIME (the caller switches between fully unrolled bodies): runtime predicates inside the unrolled nest
-    // spilled and ran 5x slower (round 1).
-    auto body = [&](auto LO_, auto HI_, auto CD_) {
-      constexpr int LO = decltype(LO_)::value, HI = decltype(HI_)::value;
-      constexpr bool CDIAG = decltype(CD_)::value;
-#if ZIGP_TRI16
-      // every body reads through its OWN opaque copy of the address registers: otherwise the compiler hoists the LDS reads that
-      // sibling bodies have in common above the branch and keeps all of them live (spills)
-      int a_base[4], b_base[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) { a_base[x] = a_base_[x]; b_base[x] = b_base_[x]; asm volatile("" : "+v"(a_base[x]), "+v"(b_base[x])); }
-#else
+    // One BK step of this wave's RW x 64 sub-tile, fully unrolled with compile-time bounds (runtime predicates inside the unrolled
+    // nest, and more than one unrolled body per kernel, spill: the 4-wave kernels sit at 255-256 VGPRs; rounds 1 and 2).
+    auto body = [&]() {
+      constexpr int LO = 0, HI = TMW - 1;
       const int (&a_base)[4] = a_base_; const int (&b_base)[4] = b_base_;
-#endif
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {
         const int k = ks * 4 + kq;
@@ -366,11 +349,9 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
           for (int tm = LO; tm <= HI; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TNW; ++tn)
-              if (!CDIAG || tn <= tm) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
-              }
+              for (int r = 0; r < 4; ++r)
+                acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
         } else {
           // 4 waves/SIMD hide LDS latency across waves: fragments are read 4 at a time to stay within 128 VGPRs
 #pragma unroll
@@ -381,64 +362,18 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
               af[r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
 #pragma unroll
             for (int tn = 0; tn < TNW; ++tn)
-              if (!CDIAG || tn <= tm) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[r], bf[tn], acc[tm][tn][r], 0, 0, 0);
-              }
+              for (int r = 0; r < 4; ++r)
+                acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[r], bf[tn], acc[tm][tn][r], 0, 0, 0);
           }
         }
       }
     };
-    using std::integral_constant;
-    typedef integral_constant<bool, false> NoDiag;
-    typedef integral_constant<int, TMW - 1> Last;
-    typedef integral_constant<int, 0> First;
-#if ZIGP_TRI16
-    // Triangular structure at 16-ROW granularity (scalar, wave-uniform decisions): sub-tile tm of a triangular A takes part in this
-    // BK step only if its rows reach the step's k range; a wave on the diagonal of a lower-triangular C needs the sub-tiles tn <= tm.
-    if (TRI == TRI_A_LOWER) {            // A(i,k) = 0 for k > i: rows wm*RW + 16 tm + 15 >= krel
-      const int lo = (krel - wm * RW) >> 4;                        // first sub-tile that still reaches krel (floor: negative -> all)
-      constexpr int HALF = TMW / 2;                                // ZIGP_TRI16 == 2: one extra body (half the wave tile), 32-row steps
-      if (ZIGP_TRI16 == 2) {
-        if (lo < HALF) body(First(), Last(), NoDiag());
-        else if (lo < TMW) body(integral_constant<int, HALF>(), Last(), NoDiag());
-      } else {
-        if (lo <= 0) body(First(), Last(), NoDiag());
-        else if (lo == 1 && TMW > 1) body(integral_constant<int, (TMW > 1 ? 1 : 0)>(), Last(), NoDiag());
-        else if (lo == 2 && TMW > 2) body(integral_constant<int, (TMW > 2 ? 2 : 0)>(), Last(), NoDiag());
-        else if (lo == 3 && TMW > 3) body(integral_constant<int, (TMW > 3 ? 3 : 0)>(), Last(), NoDiag());
-      }
-    } else if (TRI == TRI_A_UPPER) {     // A(i,k) = 0 for k < i: rows wm*RW + 16 tm <= krel + 15
-      const int d = krel + BK - 1 - wm * RW;
-      const int hi = d < 0 ? -1 : (d >> 4);
-      constexpr int HALF = TMW / 2;
-      if (ZIGP_TRI16 == 2) {
-        if (hi >= HALF) body(First(), Last(), NoDiag());
-        else if (hi >= 0) body(First(), integral_constant<int, (HALF > 0 ? HALF - 1 : 0)>(), NoDiag());
-      } else {
-        if (hi >= TMW - 1) body(First(), Last(), NoDiag());
-        else if (hi == 0) body(First(), First(), NoDiag());
-        else if (hi == 1 && TMW > 2) body(First(), integral_constant<int, (TMW > 2 ? 1 : 0)>(), NoDiag());
-        else if (hi == 2 && TMW > 3) body(First(), integral_constant<int, (TMW > 3 ? 2 : 0)>(), NoDiag());
-      }
-    } else if (TRI == TRI_C_LOWER) {
-      const bool diag_tile = tl.bi == tl.bj;
-      if (!diag_tile || wn * WTN + WTN - 1 <= wm * RW) body(First(), Last(), NoDiag());                     // wave tile entirely on / below the diagonal
-      else if (wn * WTN <= wm * RW + RW - 1) {                                                               // wave tile crosses the diagonal
-        if (RW == WTN && wn * WTN == wm * RW) body(First(), Last(), integral_constant<bool, true>());        // square diagonal wave tile: tn <= tm
-        else body(First(), Last(), NoDiag());
-      }
-    } else {
-      body(First(), Last(), NoDiag());
-    }
-#else
     bool skip = false;
     if (TRI == TRI_A_LOWER) skip = krel > wm * RW + RW - 1;
     if (TRI == TRI_A_UPPER) skip = krel + BK - 1 < wm * RW;
     if (TRI == TRI_C_LOWER) skip = (tl.bi == tl.bj) && (wn * WTN > wm * RW + RW - 1);
-    if (!skip) body(First(), Last(), NoDiag());
-#endif
+    if (!skip) body();
   }
 
   EpiCtx e;

@@ -187,7 +187,8 @@ static int check_info(zigp_ctx* c, const char* what) {
 }
 
 // smallest pivot accepted in a Cholesky of an RBF Kuu (constant diagonal variance + jitter): see potrf_diag_lds
-static inline double pivot_tol(double var, double jitter) { return 8.0 * 2.220446049250313e-16 * (var + jitter); }
+// (rtol = 8 by default; zigp_set_pivot_rtol(ctx, 0) gives the bare `pivot > 0` test of LAPACK / Eigen / tf.cholesky)
+static inline double pivot_tol(double var, double jitter, double rtol = 8.0) { return rtol * 2.220446049250313e-16 * (var + jitter); }
 
 // ------------------------------------------------------------------------------------------------
 // L = chol(A) in place in `Lb` (which holds a copy of A on entry), W = L^-1.  Mp multiple of 128.
@@ -264,7 +265,10 @@ k_sk_finish(const double* __restrict__ planes, int S, int64_t Mp, double alpha, 
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= Mp * Mp) return;
   const int64_t i = idx / Mp, j = idx - i * Mp;
-  if (lower_only && (j / BN > i / BM)) return;      // tiles above the diagonal were not computed (and are never read)
+  if (lower_only && (j / BN > i / BM)) {            // tiles above the diagonal were not computed: their value is DEFINED as zero
+    if (POST != SK_ACCUM) out[idx] = 0.0;           // (what the empty-k tiles of a plain GEMM launch would have stored)
+    return;
+  }
   double v = 0.0;
   for (int s = 0; s < S; ++s) v += planes[(int64_t)s * Mp * Mp + idx];
   v *= alpha;

@@ -245,23 +245,29 @@ k_pointwise(PwArgs p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int KG_ROWS = 4;
 constexpr int KG_SPLIT = 4;   // column splits (blockIdx.y); each split accumulates into its own krow slab [KG_SPLIT][Mp][W]
+// ZIGP_KGRAD_RECOMPUTE (default): K[m,n] is recomputed from x_n and z_m (the expression of k_kuf_build, bit for bit) instead of read
+// back -- the kernel is HBM-bound on its two panel reads (J' and K, 0.54 GB per chunk and latent), the fp64 exp costs less than the
+// 0.27 GB it replaces.
+#ifndef ZIGP_KGRAD_RECOMPUTE
+#define ZIGP_KGRAD_RECOMPUTE 1
+#endif
 template <int D>
 __global__ void __launch_bounds__(256)
 k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const double* __restrict__ alpha,
         const double* __restrict__ gm, const double* __restrict__ gv, const double* __restrict__ X, int64_t N, int64_t n0,
-        const double* __restrict__ Z, int M, int64_t Nc, int64_t slab, double* __restrict__ krow) {
+        const double* __restrict__ Z, int M, int64_t Nc, int64_t slab, KernHyp hyp, double* __restrict__ krow) {
   constexpr int W = 2 + 2 * D;
   __shared__ double sh[4][KG_ROWS * W];
   krow += (int64_t)blockIdx.y * slab;
   const int m0 = blockIdx.x * KG_ROWS;
   if (m0 >= M) return;
-  double zz[KG_ROWS][D], am[KG_ROWS], acc[KG_ROWS][W];
+  double zz[KG_ROWS][D], zs[KG_ROWS][D], am[KG_ROWS], acc[KG_ROWS][W];
 #pragma unroll
   for (int r = 0; r < KG_ROWS; ++r) {
     const int m = min(m0 + r, M - 1);
     am[r] = alpha[m];
 #pragma unroll
-    for (int d = 0; d < D; ++d) zz[r][d] = Z[m * D + d];
+    for (int d = 0; d < D; ++d) { zz[r][d] = Z[m * D + d]; zs[r][d] = zz[r][d] * hyp.inv_ell[d]; }
 #pragma unroll
     for (int q = 0; q < W; ++q) acc[r][q] = 0.0;
   }
@@ -275,7 +281,14 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
 #pragma unroll
     for (int r = 0; r < KG_ROWS; ++r) {
       const int64_t o = (int64_t)(m0 + r) * Nc + n;     // rows beyond M are zero-padded panels (inside the allocation)
+#if ZIGP_KGRAD_RECOMPUTE
+      double r2 = 0.0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) { const double t_ = zs[r][d] - x[d] * hyp.inv_ell[d]; r2 = fma(t_, t_, r2); }
+      const double kk = (m0 + r < M) ? hyp.var * exp(-0.5 * r2) : 0.0;
+#else
       const double kk = K[o];
+#endif
       const double t = fma(gv2, Jp[o], am[r] * gmn) * kk;
       acc[r][0] += t;
       acc[r][1 + 2 * D] = fma(kk, gmn, acc[r][1 + 2 * D]);
@@ -470,6 +483,86 @@ k_kl_value(const double* __restrict__ v, const double* __restrict__ L, const dou
   }
   mah = block_sum<4>(mah, sh); lq = block_sum<4>(lq, sh); tr = block_sum<4>(tr, sh); lp = block_sum<4>(lp, sh);
   if (threadIdx.x == 0) out[0] = 0.5 * (mah - (double)M - lq + tr + lp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Result vector of one dense ELBO call, assembled on the device so that a data-parallel run can sum it over ranks where it
+// lies (ncclAllReduce on the library's stream, zigp_comm_init) and one download brings everything back:
+//   out[0] elbo_data  [1] kl  [2] d var_f  [3] d var_g  [4] d noise  [5] d mean_b  [6..13] d mean_a   (header: DP_HDR doubles)
+//   then per latent h = f, g (only when a gradient was asked for):  dZ (M_h x D)  du (M_h)  ds (M_h)  dell (D)
+// Block h assembles latent h; block 0 also writes the header scalars.  Every sum has a fixed order (strided partial per thread,
+// xor tree over lanes, waves in index order): bit-stable run to run.
+// ---------------------------------------------------------------------------------------------
+constexpr int DP_HDR = 16;
+struct DensePackLat {
+  const double* krow; const double* du; const double* dsq; const double* vec; const double* s; const double* ell;
+  int M, Mp; double var; int64_t out_off;
+};
+struct DensePackArgs {
+  DensePackLat lat[2];
+  const double* pw; int pw_blocks; int D; int need_grad, include_kl, mean_on;
+  double* out;
+};
+__global__ void __launch_bounds__(256)
+k_dense_pack(DensePackArgs a) {
+  __shared__ double sh[4];
+  const int h = blockIdx.x, t = threadIdx.x;
+  const DensePackLat& L = a.lat[h];
+  const int D = a.D, W = 2 + 2 * D;
+  // sums over the point-wise blocks: var_exp, d noise, sum gv_f, sum gv_g, (mean function) sum gm_f, sum gm_f x_d
+  double pws[PW_ACC];
+#pragma unroll
+  for (int q = 0; q < PW_ACC; ++q) {
+    double v = 0.0;
+    if (q < 4 || (a.mean_on && q < 5 + D))
+      for (int b = t; b < a.pw_blocks; b += 256) v += a.pw[(int64_t)PW_ACC * b + q];
+    pws[q] = block_sum<4>(v, sh);
+  }
+  if (h == 0 && t == 0) {
+    a.out[0] = pws[0];
+    a.out[1] = a.include_kl ? a.lat[0].vec[3 * a.lat[0].Mp] + a.lat[1].vec[3 * a.lat[1].Mp] : 0.0;
+    a.out[4] = pws[1];
+    a.out[5] = a.mean_on ? pws[4] : 0.0;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) a.out[6 + d] = (a.mean_on && d < D) ? pws[5 + d] : 0.0;
+    a.out[14] = 0.0; a.out[15] = 0.0;
+    if (!a.need_grad) { a.out[2] = 0.0; a.out[3] = 0.0; }
+  }
+  if (!a.need_grad) return;
+  double* o = a.out + L.out_off;
+  const int M = L.M, Mp = L.Mp;
+  const int64_t slab = (int64_t)Mp * W;
+  auto ksum = [&](int m, int q) {   // column splits of the Kuf-cotangent reductions, in split order
+    double r = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < KG_SPLIT; ++sp) r += L.krow[sp * slab + (int64_t)m * W + q];
+    return r;
+  };
+  for (int idx = t; idx < M * D; idx += 256) {
+    const int m = idx / D, d = idx - m * D;
+    const double e = L.ell[d];
+    o[idx] = ksum(m, 1 + d) / (e * e);
+  }
+  double* ou = o + (int64_t)M * D; double* os = ou + M; double* ol = os + M;
+  for (int m = t; m < M; m += 256) {
+    const double sm = L.s[m];
+    double dum = L.du[m], dsm = 2.0 * sm * L.dsq[m];
+    if (a.include_kl) {   // - dKL/du = -alpha ; - dKL/ds = -(-1/s + diag(K^-1) s)
+      dum -= L.vec[Mp + m];
+      dsm -= (-1.0 / sm + L.vec[2 * Mp + m] * sm);
+    }
+    ou[m] = dum; os[m] = dsm;
+  }
+  double dv = 0.0;
+  for (int m = t; m < M; m += 256) dv += ksum(m, 0);
+  dv = block_sum<4>(dv, sh);
+  for (int d = 0; d < D; ++d) {
+    double v = 0.0;
+    for (int m = t; m < M; m += 256) v += ksum(m, 1 + D + d);
+    v = block_sum<4>(v, sh);
+    if (t == 0) { const double e = L.ell[d]; ol[d] = v / (e * e * e); }
+  }
+  if (t == 0) a.out[2 + h] = dv / L.var + pws[2 + h];
 }
 
 // s2 = s*s

@@ -11,8 +11,8 @@
 // K_p^-1 comes from the blocked Cholesky + triangular inverse of the dense path (the reference uses an LU inverse,
 // tf.matrix_inverse :192; the two agree to O(cond * eps)).  All O(M_p^2 N) / O(M0 M1 N) products and every reduction over N run
 // on the fp64 MFMA GEMM core (operands padded to 128); the reverse pass is hand-derived.
-#include <chrono>
 #include "zigp_host.h"
+#include "zigp_comm.h"
 
 using namespace zigp;
 
@@ -109,11 +109,12 @@ k_kron_colsum(const double* __restrict__ K0, const double* __restrict__ A0, cons
   part[0 * Nc + n] = q0; part[1 * Nc + n] = q1; part[2 * Nc + n] = mu; part[3 * Nc + n] = st;
 }
 
+constexpr int KPW_ACC = 5;
 struct KronPwArgs {
   const double* part_f; const double* part_g; const double* Y; int64_t N, Nc;
-  double knn_f, knn_g, noise, g_offset, scale;
+  double knn_f, knn_g, noise, g_offset, f_offset, scale;   // f_offset: the constant f_mu added to fmean (scripts/onoff.py:168-169, classifier.py:136-137)
   double *gm_f, *gv_f, *gm_g, *gv_g, *dq0_f, *dq1_f, *dq0_g, *dq1_g;
-  double* acc;   // [blocks][4]
+  double* acc;   // [blocks][KPW_ACC]: var_exp, d noise, sum gv_f, sum gv_g, sum gm_f (= d / d f_mu)
   double* out9; int64_t ld9;
 };
 
@@ -123,7 +124,7 @@ k_kron_pointwise(KronPwArgs p) {
   __shared__ double sh[4];
   const int64_t n = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
   const double q0f = p.part_f[n], q1f = p.part_f[p.Nc + n], q0g = p.part_g[n], q1g = p.part_g[p.Nc + n];
-  const double fm = p.part_f[2 * p.Nc + n], fv = p.knn_f - q0f * q1f + p.part_f[3 * p.Nc + n];
+  const double fm = p.part_f[2 * p.Nc + n] + p.f_offset, fv = p.knn_f - q0f * q1f + p.part_f[3 * p.Nc + n];
   const double gmn = p.part_g[2 * p.Nc + n] + p.g_offset, gvr = p.knn_g - q0g * q1g + p.part_g[3 * p.Nc + n];
   const bool valid = n < p.N;
   const double y = (valid && p.Y) ? p.Y[n] : 0.0;
@@ -146,13 +147,14 @@ k_kron_pointwise(KronPwArgs p) {
   double s1 = block_sum<4>(sc * o.dnoise, sh);
   double s2 = block_sum<4>(sc * o.dfv, sh);
   double s3 = block_sum<4>(sc * o.dgv, sh);
-  if (threadIdx.x == 0) { double* a = p.acc + (int64_t)blockIdx.x * 4; a[0] = s0; a[1] = s1; a[2] = s2; a[3] = s3; }
+  double s4 = block_sum<4>(sc * o.dfm, sh);
+  if (threadIdx.x == 0) { double* a = p.acc + (int64_t)blockIdx.x * KPW_ACC; a[0] = s0; a[1] = s1; a[2] = s2; a[3] = s3; a[4] = s4; }
 }
 
 // Single-latent heads on the same kron_inf (the reference's baselines):
 //   lik 1, Gaussian  (scripts/svgp.py:198-200, hurdle.py:217-219):  ve = -1/2 log 2pi - 1/2 log s2 - 1/2 ((y - fm)^2 + fv) / s2
 //   lik 2, Bernoulli (scripts/classifier.py:139-140,210-217):       p = probit(fm / sqrt(1 + fv)),  ve = log(y == 1 ? p : 1 - p)
-// with fm = kron mean + f_mu (classifier.py:136-137).  acc[b] = {ve, d noise, sum gv, sum gm (= d f_mu)}.
+// with fm = kron mean + f_mu (classifier.py:136-137).  acc[b] = {ve, d noise, sum gv, 0, sum gm (= d f_mu)}.
 // Predict rows (ld = N): fmean, fvar, pfmean, pfvar -- Gaussian: pfmean = fm, pfvar = fv + s2 (density of y);
 // Bernoulli: pfmean = p, pfvar = p - p^2 (classifier.py:140).
 template <bool PREDICT>
@@ -161,7 +163,7 @@ k_kron_head_pointwise(KronPwArgs p, int lik) {
   __shared__ double sh[4];
   const int64_t n = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
   const double q0 = p.part_f[n], q1 = p.part_f[p.Nc + n];
-  const double fm = p.part_f[2 * p.Nc + n] + p.g_offset, fv = p.knn_f - q0 * q1 + p.part_f[3 * p.Nc + n];
+  const double fm = p.part_f[2 * p.Nc + n] + p.f_offset, fv = p.knn_f - q0 * q1 + p.part_f[3 * p.Nc + n];
   const bool valid = n < p.N;
   const double y = (valid && p.Y) ? p.Y[n] : 0.0;
   double ve, dfm, dfv, dnoise = 0.0, pm, pv;
@@ -193,8 +195,8 @@ k_kron_head_pointwise(KronPwArgs p, int lik) {
   double s0 = block_sum<4>(sc * ve, sh);
   double s1 = block_sum<4>(sc * dnoise, sh);
   double s2 = block_sum<4>(sc * dfv, sh);
-  double s3 = block_sum<4>(sc * dfm, sh);
-  if (threadIdx.x == 0) { double* a = p.acc + (int64_t)blockIdx.x * 4; a[0] = s0; a[1] = s1; a[2] = s2; a[3] = s3; }
+  double s4 = block_sum<4>(sc * dfm, sh);
+  if (threadIdx.x == 0) { double* a = p.acc + (int64_t)blockIdx.x * KPW_ACC; a[0] = s0; a[1] = s1; a[2] = s2; a[3] = 0.0; a[4] = s4; }
 }
 
 // dA[i][n] = 2 A[i][n] gv[n] C[i][n] ; E[i][n] = dq[n] K[i][n] + dA[i][n]
@@ -384,7 +386,7 @@ int factor_forward(zigp_ctx* c, KronFactor& f, int M, int D, int col0, const dou
                      f.K.p, (int64_t)Mq, (int64_t)Mq, (int64_t)Mq);
   ZIGP_HIP(c, hipGetLastError());
   ZIGP_HIP(c, hipMemcpyAsync(f.L.p, f.K.p, sizeof(double) * mm_, hipMemcpyDeviceToDevice, c->stream));
-  ZIGP_TRY(potrf_trtri(c, f.L.p, f.W.p, f.T.p, Mq, true, M, pivot_tol(var, jitter)));
+  ZIGP_TRY(potrf_trtri(c, f.L.p, f.W.p, f.T.p, Mq, true, M, pivot_tol(var, jitter, c->pivot_rtol)));
   TileList t;
   ZIGP_TRY(get_tiles(c, "bw_s:" + std::to_string(nb), [&](std::vector<GemmTile>& v) {
     for (int bi = 0; bi < nb; ++bi)
@@ -528,26 +530,72 @@ int latent_backward(zigp_ctx* c, KronLatent& lt, const double* dX, int64_t N, in
 namespace {
 
 int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
-                    double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
+                    double g_offset, double f_mu, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
                     int lik, double* d_offset, bool dev_xy);
 
+// Data-parallel exchange of the PANEL path (grids beyond the fused kernels' capacity): its results reach the host piecewise, so with a
+// communicator (zigp_comm_init) the assembled outputs take one more round trip -- packed, summed over ranks on the device, unpacked.
+// (The fused path reduces its device result block in place before its single download.)
+int kron_exchange_host(zigp_ctx* c, const zigp_kron_params* p, int nlat, double* elbo_data, double* kl, zigp_kron_grads* g, double* d_offset) {
+  if (!c->comm) return 0;
+  struct Piece { double* p; size_t n; };
+  std::vector<Piece> pc;
+  double scal[11] = {elbo_data ? *elbo_data : 0.0, kl ? *kl : 0.0, d_offset ? *d_offset : 0.0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (g) { scal[3] = g->var0f; scal[4] = g->var1f; scal[5] = g->var0g; scal[6] = g->var1g; scal[7] = g->noise; }
+  pc.push_back({scal, 11});
+  if (g) {
+    const int M0[2] = {p->M0f, p->M0g}, M1[2] = {p->M1f, p->M1g};
+    double* Z0[2] = {g->Z0f, g->Z0g}; double* Z1[2] = {g->Z1f, g->Z1g}; double* l0[2] = {g->ell0f, g->ell0g}; double* l1[2] = {g->ell1f, g->ell1g};
+    double* um[2] = {g->u_fm, g->u_gm}; double* us[2] = {g->u_fs_sqrt, g->u_gs_sqrt};
+    for (int h = 0; h < nlat; ++h) {
+      if (Z0[h]) pc.push_back({Z0[h], (size_t)M0[h] * p->D0});
+      if (Z1[h]) pc.push_back({Z1[h], (size_t)M1[h] * p->D1});
+      if (l0[h]) pc.push_back({l0[h], (size_t)p->D0});
+      if (l1[h]) pc.push_back({l1[h], (size_t)p->D1});
+      if (um[h]) pc.push_back({um[h], (size_t)M0[h] * M1[h]});
+      if (us[h]) pc.push_back({us[h], (size_t)M0[h] * M1[h]});
+    }
+  }
+  size_t n = 0;
+  for (auto& q : pc) n += q.n;
+  ZIGP_TRY(begin_staged_call(c));
+  ZIGP_ENSURE(c, c->packed, n);
+  ZIGP_PINNED(c, hin, n);
+  size_t o = 0;
+  for (auto& q : pc) { memcpy(hin + o, q.p, sizeof(double) * q.n); o += q.n; }
+  ZIGP_HIP(c, hipMemcpyAsync(c->packed.p, hin, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  ZIGP_TRY(comm_allreduce(c, c->packed.p, n));
+  double* hout = nullptr;
+  ZIGP_TRY(download(c, c->packed.p, n, &hout));
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+  o = 0;
+  for (auto& q : pc) { memcpy(q.p, hout + o, sizeof(double) * q.n); o += q.n; }
+  if (elbo_data) *elbo_data = scal[0];
+  if (kl) *kl = scal[1];
+  if (d_offset) *d_offset = scal[2];
+  if (g) { g->var0f = scal[3]; g->var1f = scal[4]; g->var0g = scal[5]; g->var1g = scal[6]; g->noise = scal[7]; }
+  return 0;
+}
+
 // small grids go through the fused register-resident kernels (zigp_kronf.hip); larger factors through the panel path below
+// g_offset: added to gmean before the probit moments (onofftf/onoffpred.py:141); f_mu: constant added to fmean (scripts/onoff.py:168-169,
+// classifier.py:136-137), its gradient (sum of the fmean cotangents) goes to *d_offset
 int kron_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
-             double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
+             double g_offset, double f_mu, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
              int lik = ZIGP_LIK_ONOFF, double* d_offset = nullptr, bool dev_xy = false) {
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;
-  if (!c->capturing && !c->kron_legacy && !c->kron_panels && kf_eligible(p, nlat))
-    return kronf_run(c, p, X, Y, N, jitter, scale, g_offset, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset, dev_xy);
-  return kron_run_panels(c, p, X, Y, N, jitter, scale, g_offset, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset, dev_xy);
+  if (!c->kron_panels && kf_eligible(p, nlat))
+    return kronf_run(c, p, X, Y, N, jitter, scale, g_offset, f_mu, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset, dev_xy);
+  return kron_run_panels(c, p, X, Y, N, jitter, scale, g_offset, f_mu, include_kl, predict, out9, elbo_data, kl, grads, lik, d_offset, dev_xy);
 }
 
 int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
-                    double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
+                    double g_offset, double f_mu, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
                     int lik, double* d_offset, bool dev_xy) {
-  const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;   // single-latent heads use the f latent only; g_offset is then f_mu
+  const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;   // single-latent heads use the f latent only
   if (!c->kron) { c->kron = new (std::nothrow) KronState(); c->kron_free = kron_free; if (!c->kron) { c->err = "out of memory"; return ZIGP_EHIP; } }
   KronState& ks = *c->kron;
-  if (!c->capturing) ZIGP_TRY(begin_staged_call(c));
+  ZIGP_TRY(begin_staged_call(c));
   const bool need_grad = grads != nullptr && !predict;
   const int D0 = p->D0, D1 = p->D1, ldx = D0 + D1;
   const int64_t Nc = std::max<int64_t>(1024, round_up(N, 1024));
@@ -597,11 +645,11 @@ int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, con
     ZIGP_TRY(ts.join());
   }
   const int blocks = (int)(Nc / PW_THREADS);
-  ZIGP_ENSURE(c, ks.acc, (size_t)blocks * 4);
+  ZIGP_ENSURE(c, ks.acc, (size_t)blocks * KPW_ACC);
   KronPwArgs a;
   const int gl_ = nlat - 1;   // latent whose buffers stand in for g (unused by the single-latent kernels)
   a.part_f = ks.lat[0].part.p; a.part_g = ks.lat[gl_].part.p; a.Y = Y ? ks.Y.p : nullptr; a.N = N; a.Nc = Nc;
-  a.knn_f = p->var0f * p->var1f; a.knn_g = p->var0g * p->var1g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
+  a.knn_f = p->var0f * p->var1f; a.knn_g = p->var0g * p->var1g; a.noise = p->noise; a.g_offset = g_offset; a.f_offset = f_mu; a.scale = scale;
   a.gm_f = need_grad ? ks.lat[0].gm.p : nullptr; a.gv_f = ks.lat[0].gv.p; a.gm_g = ks.lat[gl_].gm.p; a.gv_g = ks.lat[gl_].gv.p;
   a.dq0_f = ks.lat[0].dq0.p; a.dq1_f = ks.lat[0].dq1.p; a.dq0_g = ks.lat[gl_].dq0.p; a.dq1_g = ks.lat[gl_].dq1.p;
   a.acc = ks.acc.p; a.out9 = nullptr; a.ld9 = N;
@@ -620,7 +668,7 @@ int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, con
   else hipLaunchKernelGGL(k_kron_head_pointwise<false>, dim3(blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
   ZIGP_HIP(c, hipGetLastError());
   double* hacc = nullptr;
-  ZIGP_TRY(download(c, ks.acc.p, (size_t)blocks * 4, &hacc));
+  ZIGP_TRY(download(c, ks.acc.p, (size_t)blocks * KPW_ACC, &hacc));
 
   double *hkrow[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *hgu[2] = {nullptr, nullptr}, *hgs[2] = {nullptr, nullptr};
   if (need_grad) {
@@ -650,13 +698,15 @@ int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, con
     }
     ZIGP_TRY(ts.join());
   }
-  if (c->capturing) return 0;
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   ZIGP_TRY(info_result(c, hinfo, "a Kronecker factor of Kuu"));
-  double s_ve = 0, s_dn = 0, s_gv[2] = {0, 0};
-  for (int b = 0; b < blocks; ++b) { s_ve += hacc[4 * b]; s_dn += hacc[4 * b + 1]; s_gv[0] += hacc[4 * b + 2]; s_gv[1] += hacc[4 * b + 3]; }
+  double s_ve = 0, s_dn = 0, s_gv[2] = {0, 0}, s_gm = 0;
+  for (int b = 0; b < blocks; ++b) {
+    const double* r = hacc + (size_t)KPW_ACC * b;
+    s_ve += r[0]; s_dn += r[1]; s_gv[0] += r[2]; s_gv[1] += r[3]; s_gm += r[4];
+  }
   if (elbo_data) *elbo_data = s_ve;
-  if (nlat == 1) { if (d_offset) *d_offset = s_gv[1]; s_gv[1] = 0.0; }   // acc[3] of the head kernel is sum gm = d ve / d f_mu
+  if (d_offset) *d_offset = s_gm;
   double klsum = 0.0;
   if (include_kl) {
     for (int h = 0; h < nlat; ++h) {
@@ -698,7 +748,7 @@ int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, con
     grads->var0g = nlat == 2 ? gvar[1][0] : 0.0; grads->var1g = nlat == 2 ? gvar[1][1] : 0.0;
     grads->noise = s_dn;
   }
-  return 0;
+  return kron_exchange_host(c, p, nlat, elbo_data, kl, need_grad ? grads : nullptr, d_offset);
 }
 
 }  // namespace
@@ -707,14 +757,14 @@ namespace {
 // Prediction sets can be much larger than a training minibatch (predict_onoff runs over the full Xtrain / Xtest): rows go through
 // the path in chunks, so device panels and the pinned staging arena stay bounded; the factor stage is recomputed per chunk (microseconds).
 constexpr int64_t KRON_PREDICT_CHUNK = 131072;
-int kron_predict_chunked(zigp_ctx* c, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter, double offset, double* out,
-                         int lik, int rows) {
-  if (N <= KRON_PREDICT_CHUNK) return kron_run(c, p, Xnew, nullptr, N, jitter, 1.0, offset, 0, true, out, nullptr, nullptr, nullptr, lik, nullptr);
+int kron_predict_chunked(zigp_ctx* c, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter, double g_offset, double f_mu,
+                         double* out, int lik, int rows) {
+  if (N <= KRON_PREDICT_CHUNK) return kron_run(c, p, Xnew, nullptr, N, jitter, 1.0, g_offset, f_mu, 0, true, out, nullptr, nullptr, nullptr, lik, nullptr);
   const int ldx = p->D0 + p->D1;
   std::vector<double> tmp((size_t)rows * KRON_PREDICT_CHUNK);
   for (int64_t n0 = 0; n0 < N; n0 += KRON_PREDICT_CHUNK) {
     const int64_t nc = std::min(KRON_PREDICT_CHUNK, N - n0);
-    ZIGP_TRY(kron_run(c, p, Xnew + n0 * ldx, nullptr, nc, jitter, 1.0, offset, 0, true, tmp.data(), nullptr, nullptr, nullptr, lik, nullptr));
+    ZIGP_TRY(kron_run(c, p, Xnew + n0 * ldx, nullptr, nc, jitter, 1.0, g_offset, f_mu, 0, true, tmp.data(), nullptr, nullptr, nullptr, lik, nullptr));
     for (int r = 0; r < rows; ++r) memcpy(out + (size_t)r * N + n0, tmp.data() + (size_t)r * nc, sizeof(double) * nc);
   }
   return ZIGP_OK;
@@ -724,17 +774,17 @@ int kron_predict_chunked(zigp_ctx* c, const zigp_kron_params* p, const double* X
 extern "C" {
 
 int zigp_kron_elbo(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
-                   double g_offset, int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads) {
+                   double g_offset, double f_mu, int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads, double* d_f_mu) {
   if (!c) return ZIGP_EARG;
   ZIGP_TRY(validate_kron(c, p));
   if (!X || !Y || N <= 0) return fail_arg(c, "zigp_kron_elbo: need X, Y and N > 0");
   if (!(jitter >= 0)) return fail_arg(c, "zigp_kron_elbo: jitter must be >= 0");
   ZIGP_HIP(c, hipSetDevice(c->device));
-  return kron_run(c, p, X, Y, N, jitter, scale, g_offset, include_kl, false, nullptr, elbo_data, kl, grads);
+  return kron_run(c, p, X, Y, N, jitter, scale, g_offset, f_mu, include_kl, false, nullptr, elbo_data, kl, grads, ZIGP_LIK_ONOFF, d_f_mu);
 }
 
 int zigp_kron_elbo_rows(zigp_ctx* c, const zigp_kron_params* p, int64_t row_begin, int64_t row_end, double jitter, double scale, double g_offset,
-                        int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads) {
+                        double f_mu, int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads, double* d_f_mu) {
   if (!c) return ZIGP_EARG;
   ZIGP_TRY(validate_kron(c, p));
   if (!c->dX) return fail_arg(c, "zigp_kron_elbo_rows: no data set (call zigp_set_data first)");
@@ -742,17 +792,17 @@ int zigp_kron_elbo_rows(zigp_ctx* c, const zigp_kron_params* p, int64_t row_begi
   if (row_begin < 0 || row_end > c->N || row_begin >= row_end) return fail_arg(c, "zigp_kron_elbo_rows: bad row range");
   if (!(jitter >= 0)) return fail_arg(c, "zigp_kron_elbo_rows: jitter must be >= 0");
   ZIGP_HIP(c, hipSetDevice(c->device));
-  return kron_run(c, p, c->dX + row_begin * c->D, c->dY + row_begin, row_end - row_begin, jitter, scale, g_offset, include_kl, false, nullptr,
-                  elbo_data, kl, grads, ZIGP_LIK_ONOFF, nullptr, true);
+  return kron_run(c, p, c->dX + row_begin * c->D, c->dY + row_begin, row_end - row_begin, jitter, scale, g_offset, f_mu, include_kl, false, nullptr,
+                  elbo_data, kl, grads, ZIGP_LIK_ONOFF, d_f_mu, true);
 }
 
-int zigp_kron_predict(zigp_ctx* c, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter, double g_offset, double* out9) {
+int zigp_kron_predict(zigp_ctx* c, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter, double g_offset, double f_mu, double* out9) {
   if (!c) return ZIGP_EARG;
   ZIGP_TRY(validate_kron(c, p));
   if (N < 0 || (N > 0 && (!Xnew || !out9))) return fail_arg(c, "zigp_kron_predict: bad arguments");
   if (N == 0) return ZIGP_OK;
   ZIGP_HIP(c, hipSetDevice(c->device));
-  return kron_predict_chunked(c, p, Xnew, N, jitter, g_offset, out9, ZIGP_LIK_ONOFF, 9);
+  return kron_predict_chunked(c, p, Xnew, N, jitter, g_offset, f_mu, out9, ZIGP_LIK_ONOFF, 9);
 }
 
 int zigp_kron_head_elbo(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, const double* X, const double* Y, int64_t N, double jitter,
@@ -763,7 +813,7 @@ int zigp_kron_head_elbo(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, con
   if (!X || !Y || N <= 0) return fail_arg(c, "zigp_kron_head_elbo: need X, Y and N > 0");
   if (!(jitter >= 0)) return fail_arg(c, "zigp_kron_head_elbo: jitter must be >= 0");
   ZIGP_HIP(c, hipSetDevice(c->device));
-  return kron_run(c, p, X, Y, N, jitter, scale, f_mu, include_kl, false, nullptr, elbo_data, kl, grads, lik, d_f_mu);
+  return kron_run(c, p, X, Y, N, jitter, scale, 0.0, f_mu, include_kl, false, nullptr, elbo_data, kl, grads, lik, d_f_mu);
 }
 
 int zigp_kron_head_predict(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, const double* Xnew, int64_t N, double jitter, double f_mu,
@@ -774,50 +824,13 @@ int zigp_kron_head_predict(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, 
   if (N < 0 || (N > 0 && (!Xnew || !out4))) return fail_arg(c, "zigp_kron_head_predict: bad arguments");
   if (N == 0) return ZIGP_OK;
   ZIGP_HIP(c, hipSetDevice(c->device));
-  return kron_predict_chunked(c, p, Xnew, N, jitter, f_mu, out4, lik, 4);
+  return kron_predict_chunked(c, p, Xnew, N, jitter, 0.0, f_mu, out4, lik, 4);
 }
 
 
 int zigp_set_kron_panels(zigp_ctx* c, int32_t on) {
   if (!c) return ZIGP_EARG;
   c->kron_panels = on != 0;
-  return ZIGP_OK;
-}
-
-// Diagnostic: what replaying the minibatch step as a hipGraph would buy.  Runs the step eagerly (allocations, tile lists and
-// kernel attributes settle), captures the same enqueue sequence from both streams into a graph, and times `iters` replays
-// against `iters` eager steps.  The captured scalars (hyperparameters are kernel arguments today) are those of `p`, so the
-// replays recompute the same step; out_ms = {eager ms/step, graph ms/step}.
-int zigp_test_kron_graph(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
-                         int32_t iters, double* out_ms) {
-  if (!c || !out_ms || iters <= 0) return ZIGP_EARG;
-  ZIGP_TRY(validate_kron(c, p));
-  ZIGP_HIP(c, hipSetDevice(c->device));
-  struct LegacyGuard { zigp_ctx* c; ~LegacyGuard() { c->kron_legacy = false; } } legacy_guard{c};
-  c->kron_legacy = true;   // the diagnostic compares eager vs graph replay of the SAME (panel) launch sequence
-  double ed = 0, kl = 0;
-  zigp_kron_grads g;
-  memset(&g, 0, sizeof(g));   // NULL outputs: gradients are computed and downloaded, not copied out
-  for (int w = 0; w < 3; ++w) ZIGP_TRY(kron_run(c, p, X, Y, N, jitter, scale, 0.0, 1, false, nullptr, &ed, &kl, &g));
-  auto t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < iters; ++i) ZIGP_TRY(kron_run(c, p, X, Y, N, jitter, scale, 0.0, 1, false, nullptr, &ed, &kl, &g));
-  out_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
-  ZIGP_TRY(begin_staged_call(c));
-  hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-  ZIGP_HIP(c, hipStreamBeginCapture(c->stream_main, hipStreamCaptureModeGlobal));
-  c->capturing = true;
-  const int rc = kron_run(c, p, X, Y, N, jitter, scale, 0.0, 1, false, nullptr, &ed, &kl, &g);
-  c->capturing = false;
-  c->stream = c->stream_main;
-  hipError_t e = hipStreamEndCapture(c->stream_main, &graph);
-  if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-  ZIGP_HIP(c, e);
-  ZIGP_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-  for (int w = 0; w < 3; ++w) { ZIGP_HIP(c, hipGraphLaunch(exec, c->stream_main)); ZIGP_HIP(c, hipStreamSynchronize(c->stream_main)); }
-  t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < iters; ++i) { ZIGP_HIP(c, hipGraphLaunch(exec, c->stream_main)); ZIGP_HIP(c, hipStreamSynchronize(c->stream_main)); }
-  out_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
-  (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
   return ZIGP_OK;
 }
 

@@ -465,16 +465,27 @@ constexpr int KF_W_AL = 0, KF_W_S2 = KF_MQ * KF_MQ, KF_W_P0 = 2 * KF_MQ * KF_MQ,
 constexpr int KF_RED_GROUPS = 16;
 __global__ void __launch_bounds__(256)
 k_kf_reduce(const double* __restrict__ acc0, const double* __restrict__ acc1, int nparts, double* __restrict__ work0, double* __restrict__ work1,
-            int nb0c, int nb1c) {
+            int nb0c, int nb1c, int nb0_f, int nb1_f, int nb0_g, int nb1_g) {
   __shared__ double sh[KF_RED_GROUPS][16];
   const double* acc = blockIdx.y == 0 ? acc0 : acc1;
   double* work = blockIdx.y == 0 ? work0 : work1;
+  const int nb0 = blockIdx.y == 0 ? nb0_f : nb0_g, nb1 = blockIdx.y == 0 ? nb1_f : nb1_g;   // this latent's own block counts (<= capacity)
   const int64_t accd = (int64_t)kf_nblocks(nb0c, nb1c) * 256;
   const int e = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
   const int per = (nparts + KF_RED_GROUPS - 1) / KF_RED_GROUPS;
   const int w0 = grp * per, w1 = min(w0 + per, nparts);
+  // the point kernels write the accumulator blocks of the latent's OWN grid only: capacity blocks beyond it are never written (and
+  // the buffer is never cleared), so they are not read either -- their sums are defined as zero
+  bool live;
+  {
+    const KfBlock b0 = kf_block_decode(e >> 8, nb0c, nb1c);
+    const int nr = (b0.kind == 0 || b0.kind == 1 || b0.kind == 2 || b0.kind == 4) ? nb0 : nb1;
+    const int nc = (b0.kind == 0 || b0.kind == 1 || b0.kind == 3) ? nb1 : (b0.kind == 2 ? nb0 : 1);
+    live = b0.rb < nr && b0.cb < nc;
+  }
   double s = 0.0;
-  for (int w = w0; w < w1; ++w) s += acc[(int64_t)w * accd + e];
+  if (live)
+    for (int w = w0; w < w1; ++w) s += acc[(int64_t)w * accd + e];
   sh[grp][threadIdx.x & 15] = s;
   __syncthreads();
   if (grp != 0) return;
@@ -505,7 +516,7 @@ struct KfFactorJob {
 // info: Cholesky status word(s).  own_slots = 0: one word shared by every factor, zeroed by the host (predict).  own_slots = 1: word
 // info + 2 * job (an 8-byte slot each, inside the result block that is downloaded anyway); the job's workgroup zeroes its own slot, so
 // a step needs neither a memset launch nor a separate status copy.
-struct KfFactorArgs { KfFactorJob job[4]; double jitter; int* info; int own_slots; };
+struct KfFactorArgs { KfFactorJob job[4]; double jitter; double piv_rtol; int* info; int own_slots; };
 
 // fragment image of a row-major matrix: F[((rb * ksn + ks) * 16 + slot) * 4 + r] = A(16 rb + 4 r + slot % 4, 4 ks + slot / 4)
 __device__ __forceinline__ void kf_write_frag(double* __restrict__ F, int nbr, int ksn, int t, int nthreads, const double* __restrict__ A, int64_t lda,
@@ -558,7 +569,7 @@ k_kf_factor(KfFactorArgs a) {
     if (i != j) { jb.K[j * PB + i] = v; S[j * PBLD + i] = 0.0; }
   }
   __syncthreads();
-  if (!potrf_diag_lds(S, psh, 1000 * (int)blockIdx.x, info, (M + PNB - 1) / PNB, true, 8.0 * 2.220446049250313e-16 * (jb.var + a.jitter))) return;
+  if (!potrf_diag_lds(S, psh, 0, info, (M + PNB - 1) / PNB, true, a.piv_rtol * 2.220446049250313e-16 * (jb.var + a.jitter))) return;   // info = plain 1-based pivot, as on the panel path; the slot says which factor
   // logdet K = sum log L_ii^2 (fixed order: strided partials, then 16 wave sums in order)
   {
     double ld = 0.0;
@@ -925,11 +936,26 @@ static int kf_launch_small_latents(zigp_ctx* c, const int (*Mq)[2], int nlat, bo
   return 0;
 }
 
+constexpr size_t KF_SPILL_MAX_DOUBLES = (size_t)8 << 30;   // 64 GB of the 288 GB: the larger-grid backward spills its per-tile operands
 struct KfHostLatent { int M[2]; const double* Z[2]; const double* ell[2]; double var[2]; const double* u; const double* s; };
 constexpr int KF_KROW_W = 2 + 2 * MAXD;
 
+// Fixed-order sums of the point-wise block partials -> pws[0..KPW_ACC): the result block of a step has a size that depends on the
+// inducing grid only (never on the shard), so a data-parallel run can sum it over ranks in place (comm_allreduce).
+__global__ void __launch_bounds__(256)
+k_kron_pw_reduce(const double* __restrict__ acc, int blocks, double* __restrict__ pws) {
+  __shared__ double sh[4];
+#pragma unroll
+  for (int q = 0; q < KPW_ACC; ++q) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 256) v += acc[(int64_t)KPW_ACC * b + q];
+    v = block_sum<4>(v, sh);
+    if (threadIdx.x == 0) pws[q] = v;
+  }
+}
+
 static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
-                     double g_offset, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
+                     double g_offset, double f_mu, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
                      int lik, double* d_offset, bool dev_xy) {
   // dev_xy: X / Y are DEVICE pointers into the resident data set (zigp_set_data): nothing but the parameters is staged
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;
@@ -953,7 +979,9 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   const size_t FAC_P = (size_t)PB * PB, FAC_PF = FAC_P + rmax, FAC_DV = FAC_PF + rmax, FAC_ZS = FAC_DV + wl.ldw + 8, FAC_SIZE = FAC_ZS + (size_t)wl.ldw * MAXD;
   const size_t LAT_U = 0, LAT_S2 = r01, LAT_T0 = 2 * r01, LAT_T1 = 3 * r01, LAT_AL = 4 * r01, LAT_ALF = 5 * r01, LAT_S2F = 6 * r01, LAT_ALTF = 7 * r01,
                LAT_S2TF = 8 * r01, LAT_WORK = 9 * r01, LAT_SCR = LAT_WORK + wl.total, SCR_SET = 3 * rmax + r01 + wl.ldw, LAT_SIZE = LAT_SCR + 2 * SCR_SET;
-  const size_t RES_KLV = 0, RES_INFO = 8 /* 4 status slots (first latent's block) */, RES_KROW0 = 16, RES_KROW1 = RES_KROW0 + (size_t)R0 * KF_KROW_W, RES_GU = RES_KROW1 + (size_t)R1 * KF_KROW_W,
+  // result block: [latent f][latent g][pws: 8 sums over points][4 Cholesky status slots (8 doubles)]; everything in front of the status
+  // slots is summed over ranks in a data-parallel run; behind them, not downloaded: the point-wise block partials
+  const size_t RES_KLV = 0, RES_KROW0 = 8, RES_KROW1 = RES_KROW0 + (size_t)R0 * KF_KROW_W, RES_GU = RES_KROW1 + (size_t)R1 * KF_KROW_W,
                RES_GS = RES_GU + r01, RES_SIZE = RES_GS + r01;
   // ---- one staged host -> device copy: X, Y, per latent Z0, Z1, u, s
   size_t off_x = 0, off_y = dev_xy ? 0 : (size_t)N * ldx, off = dev_xy ? 0 : off_y + (size_t)N;
@@ -985,13 +1013,14 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   const int pw_blocks = (int)(Npad / PW_THREADS);
   const size_t pts_lat = (size_t)8 * Npad;   // part[4], gm, gv, dq0, dq1
   ZIGP_ENSURE(c, ks.pts, 2 * pts_lat);
-  const size_t n_res = (size_t)2 * RES_SIZE + (size_t)pw_blocks * 4;
-  ZIGP_ENSURE(c, ks.res, n_res);
+  const size_t RES_PWS = (size_t)2 * RES_SIZE, RES_INFO = RES_PWS + 8, n_res = RES_INFO + 8;
+  ZIGP_ENSURE(c, ks.res, n_res + (size_t)pw_blocks * KPW_ACC);
   auto fac = [&](int h, int q) { return ks.mat.p + (size_t)(2 * h + q) * FAC_SIZE; };
   auto lat = [&](int h) { return ks.mat.p + (size_t)4 * FAC_SIZE + (size_t)h * LAT_SIZE; };
   auto pts = [&](int h) { return ks.pts.p + (size_t)h * pts_lat; };
   auto res = [&](int h) { return ks.res.p + (size_t)h * RES_SIZE; };
-  double* d_pwacc = ks.res.p + (size_t)2 * RES_SIZE;
+  double* d_pwacc = ks.res.p + n_res;
+  if (c->comm && !predict) ZIGP_HIP(c, hipMemsetAsync(ks.res.p, 0, sizeof(double) * RES_INFO, c->stream));   // parts a value-only / single-latent step leaves unwritten
 
   int Mq[2][2];
   for (int h = 0; h < nlat; ++h)
@@ -1037,9 +1066,9 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
           zc[h][q][d] = 0.5 * (lo + hi);
         }
       }
-    fa.jitter = jitter;
+    fa.jitter = jitter; fa.piv_rtol = c->pivot_rtol;
     if (predict) { fa.info = c->d_info; fa.own_slots = 0; }
-    else { fa.info = reinterpret_cast<int*>(res(0) + RES_INFO); fa.own_slots = 1; }
+    else { fa.info = reinterpret_cast<int*>(ks.res.p + RES_INFO); fa.own_slots = 1; }
     hipLaunchKernelGGL(k_kf_factor, dim3(2 * nlat), dim3(1024), sizeof(double) * PB * PBLD, c->stream, fa);
     ZIGP_HIP(c, hipGetLastError());
   }
@@ -1096,7 +1125,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   KronPwArgs a;
   const int gl_ = nlat - 1;   // latent whose buffers stand in for g (unused by the single-latent kernels)
   a.part_f = pts(0); a.part_g = pts(gl_); a.Y = Y ? (dev_xy ? Y : ks.in.p + off_y) : nullptr; a.N = N; a.Nc = Npad;
-  a.knn_f = p->var0f * p->var1f; a.knn_g = p->var0g * p->var1g; a.noise = p->noise; a.g_offset = g_offset; a.scale = scale;
+  a.knn_f = p->var0f * p->var1f; a.knn_g = p->var0g * p->var1g; a.noise = p->noise; a.g_offset = g_offset; a.f_offset = f_mu; a.scale = scale;
   a.gm_f = need_grad ? pts(0) + 4 * Npad : nullptr; a.gv_f = pts(0) + 5 * Npad; a.gm_g = pts(gl_) + 4 * Npad; a.gv_g = pts(gl_) + 5 * Npad;
   a.dq0_f = pts(0) + 6 * Npad; a.dq1_f = pts(0) + 7 * Npad; a.dq0_g = pts(gl_) + 6 * Npad; a.dq1_g = pts(gl_) + 7 * Npad;
   a.acc = d_pwacc; a.out9 = nullptr; a.ld9 = N;
@@ -1113,6 +1142,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   }
   if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
   else hipLaunchKernelGGL(k_kron_head_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
+  hipLaunchKernelGGL(k_kron_pw_reduce, dim3(1), dim3(256), 0, c->stream, d_pwacc, pw_blocks, ks.res.p + RES_PWS);
   ZIGP_HIP(c, hipGetLastError());
   if (need_grad) {
     const int waves = std::min(ka.ntiles, 1024 / nlat);   // one wave per SIMD of the chip: the kernels hold ~400-500 registers per lane
@@ -1128,6 +1158,16 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     } else {
       size_t rec[2] = {0, 0}, spill_total = 0;
       for (int h = 0; h < nlat; ++h) { rec[h] = (size_t)64 * (Mq[h][0] + Mq[h][1]); spill_total += rec[h] * ka.ntiles; }
+      // ~4 KB per point and latent at 10 x 100 (0.86 GB for the 105 280-row pptr full batch): bounded, with a message that says what to do
+      // -- the data term and its gradient are sums over rows, so a caller adds up zigp_kron_elbo_rows over sub-ranges (include_kl once)
+      if (spill_total > KF_SPILL_MAX_DOUBLES) {
+        char b[320];
+        snprintf(b, sizeof(b), "Kronecker gradient step on a %d x %d grid over %lld rows needs %.1f GB of per-point operands (limit %.0f GB): "
+                 "split the rows over several calls (the data term is additive; include_kl on one of them)", hl[0].M[0], hl[0].M[1], (long long)N,
+                 spill_total * 8.0 / 1e9, KF_SPILL_MAX_DOUBLES * 8.0 / 1e9);
+        c->err = b;
+        return ZIGP_EARG;
+      }
       ZIGP_ENSURE(c, ks.spill, spill_total);
       ka.lat[0].spill = ks.spill.p;
       if (nlat == 2) ka.lat[1].spill = ks.spill.p + rec[0] * ka.ntiles;
@@ -1153,7 +1193,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       ZIGP_HIP(c, hipGetLastError());
     }
     hipLaunchKernelGGL(k_kf_reduce, dim3(nblk * 256 / 16, nlat), dim3(256), 0, c->stream, ka.lat[0].acc, ka.lat[gl_].acc, nparts,
-                       lat(0) + LAT_WORK, lat(gl_) + LAT_WORK, pl.nb0c, pl.nb1c);
+                       lat(0) + LAT_WORK, lat(gl_) + LAT_WORK, pl.nb0c, pl.nb1c, Mq[0][0] / 16, Mq[0][1] / 16, Mq[gl_][0] / 16, Mq[gl_][1] / 16);
     ZIGP_HIP(c, hipGetLastError());
     KflFinishArgs fa;
     memset(&fa, 0, sizeof(fa));
@@ -1187,19 +1227,23 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     }
     ZIGP_HIP(c, hipGetLastError());
   }
+  if (c->comm) {   // data-parallel run: the block (cleared at the start of the call) is summed over ranks where it lies
+    // a rank that does not count the KL (include_kl = 0) must not add its scalars, which the latent kernel writes regardless
+    if (!include_kl) for (int h = 0; h < nlat; ++h) ZIGP_HIP(c, hipMemsetAsync(res(h) + RES_KLV, 0, sizeof(double) * 8, c->stream));
+    ZIGP_TRY(comm_allreduce(c, ks.res.p, RES_INFO));
+  }
   double* hres = nullptr;
   ZIGP_TRY(download(c, ks.res.p, n_res, &hres));
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   {
-    int first = 0;
-    for (int j = 0; j < 2 * nlat && !first; ++j) first = reinterpret_cast<const int*>(hres + RES_INFO)[2 * j];
-    ZIGP_TRY(info_result(c, &first, "a Kronecker factor of Kuu"));
+    static const char* const names[4] = {"Kronecker factor 0 of Kuu (latent f)", "Kronecker factor 1 of Kuu (latent f)",
+                                         "Kronecker factor 0 of Kuu (latent g)", "Kronecker factor 1 of Kuu (latent g)"};
+    for (int j = 0; j < 2 * nlat; ++j) ZIGP_TRY(info_result(c, reinterpret_cast<const int*>(hres + RES_INFO) + 2 * j, names[j]));
   }
-  const double* hacc = hres + (size_t)2 * RES_SIZE;
-  double s_ve = 0, s_dn = 0, s_gv[2] = {0, 0};
-  for (int b = 0; b < pw_blocks; ++b) { s_ve += hacc[4 * b]; s_dn += hacc[4 * b + 1]; s_gv[0] += hacc[4 * b + 2]; s_gv[1] += hacc[4 * b + 3]; }
+  const double* pws = hres + RES_PWS;   // var_exp, d noise, sum gv_f, sum gv_g, sum gm_f (= d / d f_mu)
+  const double s_ve = pws[0], s_dn = pws[1], s_gv[2] = {pws[2], pws[3]};
   if (elbo_data) *elbo_data = s_ve;
-  if (nlat == 1) { if (d_offset) *d_offset = s_gv[1]; s_gv[1] = 0.0; }   // acc[3] of the head kernel is sum gm = d ve / d f_mu
+  if (d_offset) *d_offset = pws[4];
   double klsum = 0.0;
   if (include_kl) {
     for (int h = 0; h < nlat; ++h) {

@@ -31,11 +31,20 @@ def onoff(Xtrain, Ytrain, Xtest, Ytest, dir, num_iter=50000, num_inducing_f=(10,
     opt = AdamGroups(pset)                                                           # :325-350 (one Adam per learning rate)
     scale = float(num_data) / float(num_minibatch)                                   # :311
     logger.info('*******  started optimization at ' + time.strftime('%Y%m%d-%H%M') + ' *******')
+    resident = None     # generation of the epoch order whose arrays are resident in HBM
     for i in range(num_iter):                                                        # :375-431
         t0 = time.time()
-        xb, yb = train_data.next_batch(num_minibatch)
+        # DataSet.next_batch shuffles once per epoch and then slices (onofftf/main.py:98-133): the permuted epoch goes to the GPU once,
+        # every batch but the one wrap-around per epoch is a row range of it (zigp_kron_elbo_rows: nothing is staged per step)
+        gen, lo, hi, wrap = train_data.next_span(num_minibatch)
         try:
-            ed, kl, g = eng.kron_elbo(engine_params(pset), xb, yb, jitter=jitter_level, scale=scale)
+            if wrap is None:
+                if gen != resident:
+                    eng.set_data(train_data.xtrain, train_data.ytrain)
+                    resident = gen
+                ed, kl, g = eng.kron_elbo(engine_params(pset), rows=(lo, hi), jitter=jitter_level, scale=scale)
+            else:
+                ed, kl, g = eng.kron_elbo(engine_params(pset), wrap[0], wrap[1], jitter=jitter_level, scale=scale)
             opt.step(named_grads(g))                                                 # minimises cost = -(var_exp*scale - kl), :318
             if history is not None:
                 history.append(-(ed - kl))

@@ -7,7 +7,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get('ZIGP_LIB') or os.path.join(ROOT, 'lib', 'libzigp.so')   # ZIGP_LIB: A/B builds on one GPU box
 
-ZIGP_OK, ZIGP_EARG, ZIGP_EHIP, ZIGP_ENOTPD = 0, -1, -2, -3
+ZIGP_OK, ZIGP_EARG, ZIGP_EHIP, ZIGP_ENOTPD, ZIGP_ECOMM = 0, -1, -2, -3, -4
+COMM_ID_BYTES = 128
 NCLASS = 10
 LIK_ONOFF, LIK_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2   # include/zigp.h ZIGP_LIK_*
 PROF_CLASSES = ('gemm_A1', 'gemm_A2', 'gemm_H', 'gemm_J', 'syrk', 'kuf_build', 'pointwise', 'kgrad', 'mxm_stage', 'other')
@@ -57,7 +58,7 @@ class zigp_kron_grads(C.Structure):
                 ('u_fm', dp), ('u_gm', dp), ('u_fs_sqrt', dp), ('u_gs_sqrt', dp), ('noise', C.c_double)]
 
 
-# name -> (restype, argtypes); mirrors include/zigp.h exactly (tests check every symbol resolves)
+# name -> (restype, argtypes); mirrors include/zigp.h and include/zigp_diag.h exactly (tests check every declared symbol resolves)
 SIGNATURES = {
     'zigp_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     'zigp_destroy': (C.c_int, [C.c_void_p]),
@@ -71,12 +72,17 @@ SIGNATURES = {
     'zigp_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), dp, C.c_int64, C.c_double, C.c_double, dp]),
     'zigp_prior_kl': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), C.c_double, dp]),
     'zigp_rbf_K': (C.c_int, [C.c_void_p, dp, C.c_int64, dp, C.c_int64, C.c_int32, dp, C.c_double, dp]),
-    'zigp_kron_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, dp, C.c_int64, C.c_double, C.c_double, C.c_double,
-                                 C.c_int32, dp, dp, C.POINTER(zigp_kron_grads)]),
+    'zigp_kron_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_int32, dp, dp, C.POINTER(zigp_kron_grads), dp]),
     'zigp_kron_elbo_rows': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
-                                      C.c_int32, dp, dp, C.POINTER(zigp_kron_grads)]),
-    'zigp_kron_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, C.c_int64, C.c_double, C.c_double, dp]),
-    'zigp_test_kron_graph': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, dp, C.c_int64, C.c_double, C.c_double, C.c_int32, dp]),
+                                      C.c_double, C.c_int32, dp, dp, C.POINTER(zigp_kron_grads), dp]),
+    'zigp_kron_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, C.c_int64, C.c_double, C.c_double, C.c_double, dp]),
+    'zigp_get_chunk': (C.c_int64, [C.c_void_p, C.c_int32]),
+    'zigp_set_pivot_rtol': (C.c_int, [C.c_void_p, C.c_double]),
+    'zigp_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'zigp_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    'zigp_comm_destroy': (C.c_int, [C.c_void_p]),
+    'zigp_comm_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     'zigp_set_overlap': (C.c_int, [C.c_void_p, C.c_int32]),
     'zigp_set_kron_panels': (C.c_int, [C.c_void_p, C.c_int32]),
     'zigp_set_mean_function': (C.c_int, [C.c_void_p, dp, C.c_int32, C.c_double]),

@@ -8,7 +8,7 @@ CSRC = os.path.join(ROOT, 'csrc')
 LIBDIR = os.path.join(ROOT, 'lib')
 LIB = os.path.join(LIBDIR, 'libzigp.so')
 SOURCES = ['zigp_lib.hip']
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(('.h', '.hip')) and f not in SOURCES) + ['../../include/zigp.h']
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(('.h', '.hip')) and f not in SOURCES) + ['../../include/zigp.h', '../../include/zigp_diag.h']
 
 
 HASHFILE = LIB + '.srchash'

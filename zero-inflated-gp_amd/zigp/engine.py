@@ -89,6 +89,41 @@ class DenseEngine:
     def set_chunk(self, rows):
         _check(self.lib, self.ctx, self.lib.zigp_set_chunk(self.ctx, int(rows)))
 
+    def get_chunk(self, M):
+        """rows per pass of the dense path at M inducing points per latent (the set_chunk value, else the library's rule)"""
+        r = int(self.lib.zigp_get_chunk(self.ctx, int(M)))
+        if r < 0:
+            raise ValueError('zigp_get_chunk: bad M')
+        return r
+
+    def set_pivot_rtol(self, rtol):
+        """smallest accepted Cholesky pivot = rtol * eps * (variance + jitter); default 8, 0 = tf.cholesky's bare pivot > 0 test"""
+        _check(self.lib, self.ctx, self.lib.zigp_set_pivot_rtol(self.ctx, float(rtol)))
+
+    # ---- data-parallel exchange inside the library (RCCL; include/zigp.h 'data-parallel exchange') ----
+    def comm_unique_id(self):
+        """rank 0: the 128-byte id every rank hands to comm_init"""
+        buf = (C.c_char * _lib.COMM_ID_BYTES)()
+        rc = self.lib.zigp_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise ZigpError('zigp_comm_unique_id failed (rc=%d): librccl.so.1 not loadable?' % rc)
+        return bytes(buf.raw)
+
+    def comm_init(self, rank, nranks, unique_id):
+        """collective; afterwards elbo() / kron_elbo() / kron_head_elbo() return sums over ranks (pass include_kl on rank 0 only)"""
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError('unique_id must have %d bytes' % _lib.COMM_ID_BYTES)
+        buf = C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
+        _check(self.lib, self.ctx, self.lib.zigp_comm_init(self.ctx, int(rank), int(nranks), C.cast(buf, C.c_void_p)))
+
+    def comm_destroy(self):
+        _check(self.lib, self.ctx, self.lib.zigp_comm_destroy(self.ctx))
+
+    def comm_info(self):
+        r, n, k = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        _check(self.lib, self.ctx, self.lib.zigp_comm_info(self.ctx, C.byref(r), C.byref(n), C.byref(k)))
+        return dict(rank=r.value, nranks=n.value, allreduce_calls=k.value)
+
     def set_data(self, X, Y):
         X = as_f64(X)
         if X.ndim != 2:
@@ -223,9 +258,10 @@ class DenseEngine:
         s.noise = _scalar(p.get('noise', 1.0))
         return s, keep, dims
 
-    def kron_elbo(self, p, X=None, Y=None, jitter=1e-5, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True, rows=None):
+    def kron_elbo(self, p, X=None, Y=None, jitter=1e-5, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True, rows=None, f_mu=None):
         """One Kronecker ELBO (step); returns (elbo_data, kl, grads or None).  Either an explicit host minibatch (X, Y), as
-        scripts/onoff.py:377-381 feeds it, or rows=(lo, hi) of the resident data set (set_data / set_data_device)."""
+        scripts/onoff.py:377-381 feeds it, or rows=(lo, hi) of the resident data set (set_data / set_data_device).
+        f_mu: the optional constant added to fmean (scripts/onoff.py:161,168-169); when given, grads['f_mu'] is its gradient."""
         s, keep, dims = self._pack_kron(p)
         if rows is None:
             X = as_f64(X)
@@ -236,7 +272,8 @@ class DenseEngine:
                 raise ValueError('Y must have N entries')
         elif X is not None or Y is not None:
             raise ValueError('pass either (X, Y) or rows=(lo, hi), not both')
-        ed, kl = C.c_double(0), C.c_double(0)
+        ed, kl, dmu = C.c_double(0), C.c_double(0), C.c_double(0)
+        fmu = 0.0 if f_mu is None else _scalar(f_mu)
         g, gs = None, None
         if need_grad:
             g = {}
@@ -256,15 +293,17 @@ class DenseEngine:
                 setattr(gs, 'u_%sm' % tag, ptr(arrs['um'])); setattr(gs, 'u_%ss_sqrt' % tag, ptr(arrs['us']))
         gref = C.byref(gs) if gs is not None else None
         if rows is None:
-            rc = self.lib.zigp_kron_elbo(self.ctx, C.byref(s), ptr(X), ptr(Y), X.shape[0], float(jitter), float(scale), float(g_offset),
-                                         1 if include_kl else 0, C.byref(ed), C.byref(kl), gref)
+            rc = self.lib.zigp_kron_elbo(self.ctx, C.byref(s), ptr(X), ptr(Y), X.shape[0], float(jitter), float(scale), float(g_offset), fmu,
+                                         1 if include_kl else 0, C.byref(ed), C.byref(kl), gref, C.byref(dmu))
         else:
-            rc = self.lib.zigp_kron_elbo_rows(self.ctx, C.byref(s), int(rows[0]), int(rows[1]), float(jitter), float(scale), float(g_offset),
-                                              1 if include_kl else 0, C.byref(ed), C.byref(kl), gref)
+            rc = self.lib.zigp_kron_elbo_rows(self.ctx, C.byref(s), int(rows[0]), int(rows[1]), float(jitter), float(scale), float(g_offset), fmu,
+                                              1 if include_kl else 0, C.byref(ed), C.byref(kl), gref, C.byref(dmu))
         _check(self.lib, self.ctx, rc)
         out = None
         if need_grad:
             out = dict(noise=gs.noise)
+            if f_mu is not None:
+                out['f_mu'] = dmu.value
             for tag in ('f', 'g'):
                 a = g[tag]
                 out['Z' + tag] = [a['Z0'], a['Z1']]
@@ -274,7 +313,7 @@ class DenseEngine:
                 out['u_%ss_sqrt' % tag] = a['us']
         return ed.value, kl.value, out
 
-    def kron_predict(self, p, Xnew, jitter=1e-6, g_offset=0.0):
+    def kron_predict(self, p, Xnew, jitter=1e-6, g_offset=0.0, f_mu=None):
         """(9,N) in the order of build_predict (scripts/onoff.py:184); onofftf/onoffpred.py uses jitter 1e-6, g_offset -1."""
         s, keep, dims = self._pack_kron(p)
         Xnew = as_f64(Xnew)
@@ -282,7 +321,7 @@ class DenseEngine:
             raise ValueError('Xnew must be (N,%d)' % (dims[0] + dims[1]))
         out = np.zeros((9, Xnew.shape[0]))
         _check(self.lib, self.ctx, self.lib.zigp_kron_predict(self.ctx, C.byref(s), ptr(Xnew), Xnew.shape[0], float(jitter),
-                                                               float(g_offset), ptr(out)))
+                                                               float(g_offset), 0.0 if f_mu is None else _scalar(f_mu), ptr(out)))
         return out
 
     LIK = {'gaussian': _lib.LIK_GAUSSIAN, 'bernoulli': _lib.LIK_BERNOULLI}
@@ -330,8 +369,8 @@ class DenseEngine:
 
     # ---- measurement ----
     def set_overlap(self, on=True):
-        """stream overlap inside elbo(): False/0 off (default), True/1 HBM-bound side kernels under the rank-N updates (~0.5 %),
-        2 the chunk chains of f and g on two streams (measured 1.5 % slower on cfg3); results are bit-identical in every mode"""
+        """stream overlap inside elbo(): False/0 off (default), True/1 the HBM-bound side kernels of a chunk on a second stream under
+        its rank-N updates; results are bit-identical either way"""
         _check(self.lib, self.ctx, self.lib.zigp_set_overlap(self.ctx, int(on)))
 
     def set_kron_panels(self, on=True):

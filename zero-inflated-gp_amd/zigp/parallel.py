@@ -3,8 +3,10 @@
 The ELBO data term is a plain sum over points (tf.reduce_sum(var_exp), onoffgpf/OnOffSVGP.py:122;
 scripts/onoff.py:307), so rank r evaluates rows [lo_r, hi_r) of its resident shard with the replicated
 O(M^2) state and the packed vector [elbo_data, kl, d/d(params)...] (~82 KB at M=1024, D=3) is summed
-with ONE torch.distributed all_reduce (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
-tests).  KL and its gradient are added on rank 0 only.  The reference has no distributed code; this is new.
+with ONE all-reduce: on a GPU run inside libzigp.so (ncclAllReduce on the packed DEVICE vector, zigp_comm_init --
+RCCL over xGMI; torch.distributed only carries the 128-byte communicator id), in the "gloo" rehearsals / CPU tests
+through torch.distributed on the packed host vector.  KL and its gradient are added on rank 0 only.  The reference
+has no distributed code; this is new.
 """
 import numpy as np
 
@@ -41,37 +43,104 @@ def unpack(vec, shapes):
     return elbo_data, kl, g
 
 
-class ShardedELBO:
-    """engine: anything with .elbo(p, jitter=, scale=, g_offset=, rows=, include_kl=, need_grad=True)
-    evaluating rows of ITS OWN resident shard; dist: torch.distributed (initialised) or None for 1 process."""
+def _flatten_kron(g):
+    """Kronecker gradient dict (lists per factor, scalars) -> (vector, spec) and back; used by the host-side exchange only"""
+    parts, spec = [], []
+    for k in sorted(g):
+        v = g[k]
+        items = v if isinstance(v, (list, tuple)) else [v]
+        shapes = []
+        for it in items:
+            a = np.asarray(it, dtype=np.float64)
+            shapes.append(a.shape)
+            parts.append(a.reshape(-1))
+        spec.append((k, isinstance(v, (list, tuple)), shapes))
+    return (np.concatenate(parts) if parts else np.zeros(0)), spec
 
-    def __init__(self, engine, dist=None, device=None):
+
+def _unflatten_kron(vec, spec):
+    g, o = {}, 0
+    for k, is_list, shapes in spec:
+        items = []
+        for sh in shapes:
+            n = int(np.prod(sh)) if len(sh) else 1
+            items.append(vec[o:o + n].reshape(sh) if len(sh) else float(vec[o]))
+            o += n
+        g[k] = items if is_list else items[0]
+    return g
+
+
+class _Sharded:
+    """Common part of the data-parallel wrappers: who am I, and where does the exchange run.
+
+    library_comm=True (the default on a GPU run with the 'nccl' backend): the exchange is ONE ncclAllReduce inside libzigp.so, on the
+    device, on the engine's stream (zigp_comm_init; the 128-byte id is broadcast over `dist`) -- engine calls then return the sums.
+    library_comm=False ('gloo' rehearsals, the CPU tests' fake engines): the packed host vector goes through torch.distributed."""
+
+    def __init__(self, engine, dist=None, device=None, library_comm=None):
         self.engine, self.dist, self.device = engine, dist, device
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self._buf = None
         self._host = None
+        if library_comm is None:
+            library_comm = dist is not None and self.world >= 1 and dist.get_backend() == 'nccl' and hasattr(engine, 'comm_init')
+        self.library_comm = bool(library_comm) and dist is not None
+        self._owns_comm = False
+        if self.library_comm:
+            info = engine.comm_info()
+            if info['nranks'] == 0:
+                obj = [engine.comm_unique_id() if self.rank == 0 else None]
+                dist.broadcast_object_list(obj, src=0)
+                engine.comm_init(self.rank, self.world, obj[0])
+                self._owns_comm = True
+            elif (info['rank'], info['nranks']) != (self.rank, self.world):       # another wrapper of this engine set it up
+                raise ValueError('engine already has a communicator for rank %d of %d' % (info['rank'], info['nranks']))
 
-    def elbo(self, p, jitter=1e-6, scale=1.0, g_offset=0.0, rows=None):
-        ed, kl, g = self.engine.elbo(p, jitter=jitter, scale=scale, g_offset=g_offset, rows=rows,
-                                     include_kl=(self.rank == 0), need_grad=True)
-        if self.world == 1:
-            return ed, kl, g
+    def close(self):
+        if self._owns_comm:
+            self.engine.comm_destroy()
+        self.library_comm = self._owns_comm = False
+
+    def _allreduce_host(self, vec):
+        """sum a host float64 vector over ranks through torch.distributed (pinned staging when the exchange runs on the GPU)"""
         import torch
-        vec, shapes = pack(ed, kl, g)
         if self._buf is None or self._buf.numel() != vec.size:
             self._buf = torch.empty(vec.size, dtype=torch.float64, device=self.device or 'cpu')
-            # page-locked staging for the packed vector when the exchange runs on the GPU (RCCL): no pageable copies per step
-            on_gpu = self._buf.is_cuda
-            self._host = torch.empty(vec.size, dtype=torch.float64, pin_memory=on_gpu)
+            self._host = torch.empty(vec.size, dtype=torch.float64, pin_memory=self._buf.is_cuda)
         self._host.numpy()[:] = vec
         if self._buf.is_cuda:
             self._buf.copy_(self._host, non_blocking=True)
             self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
             self._host.copy_(self._buf)           # synchronises with the all-reduce on the current stream
-            out = self._host.numpy().copy()
-        else:
-            self._buf.copy_(self._host)
-            self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
-            out = self._buf.numpy().copy()
-        return unpack(out, shapes)
+            return self._host.numpy().copy()
+        self._buf.copy_(self._host)
+        self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
+        return self._buf.numpy().copy()
+
+
+class ShardedELBO(_Sharded):
+    """engine: anything with .elbo(p, jitter=, scale=, g_offset=, rows=, include_kl=, need_grad=True)
+    evaluating rows of ITS OWN resident shard; dist: torch.distributed (initialised) or None for 1 process."""
+
+    def elbo(self, p, jitter=1e-6, scale=1.0, g_offset=0.0, rows=None):
+        ed, kl, g = self.engine.elbo(p, jitter=jitter, scale=scale, g_offset=g_offset, rows=rows,
+                                     include_kl=(self.rank == 0), need_grad=True)
+        if self.world == 1 or self.library_comm:      # library_comm: already summed over ranks on the device (zigp_comm_init)
+            return ed, kl, g
+        vec, shapes = pack(ed, kl, g)
+        return unpack(self._allreduce_host(vec), shapes)
+
+
+class ShardedKronELBO(_Sharded):
+    """The same for the Kronecker step (cfg5): rank r evaluates rows (lo, hi) of its own resident shard, or its own host minibatch,
+    with the minibatch scale of the WHOLE job (scripts/onoff.py:311: num_data / num_minibatch over all ranks' rows)."""
+
+    def kron_elbo(self, p, X=None, Y=None, jitter=1e-5, scale=1.0, g_offset=0.0, rows=None, f_mu=None):
+        ed, kl, g = self.engine.kron_elbo(p, X, Y, jitter=jitter, scale=scale, g_offset=g_offset, rows=rows, f_mu=f_mu,
+                                          include_kl=(self.rank == 0), need_grad=True)
+        if self.world == 1 or self.library_comm:
+            return ed, kl, g
+        gv, spec = _flatten_kron(g)
+        out = self._allreduce_host(np.concatenate([np.array([ed, kl]), gv]))
+        return float(out[0]), float(out[1]), _unflatten_kron(out[2:], spec)
