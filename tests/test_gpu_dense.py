@@ -278,7 +278,7 @@ def test_stream_overlap_is_bit_identical(engine):
     engine.set_chunk(2048)            # 5 chunks, the last one partial
     engine.set_data(X, Y)
     out = {}
-    for on in (True, False, 2, True):
+    for on in (True, False, True):
         engine.set_overlap(on)
         for prof in (False, True):    # timed chunks fall back to the single stream inside an overlapped step
             engine.profile_enable(prof)

@@ -296,14 +296,16 @@ def test_kron_f_mu_offset_value_gradient_and_predict(engine, grid, rows):
     ed, kl, g = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=2.0, f_mu=fmu)
     e_r, d_r, kl_r, g_r = ot.kron_elbo_and_grad(X, Y, p, 1e-5, scale=2.0, f_mu=fmu)
     assert abs(ed - 2.0 * d_r) <= 1e-7 * abs(2.0 * d_r) and abs(kl - kl_r) <= 1e-7 * abs(kl_r)
-    assert abs(g['f_mu'] - g_r['f_mu']) <= 1e-7 * abs(g_r['f_mu']), (g['f_mu'], g_r['f_mu'])
+    assert abs(g['f_mu'] - g_r['f_mu']) <= 1e-6 * abs(g_r['f_mu']), (g['f_mu'], g_r['f_mu'])
     assert relerr(g['u_fm'], g_r['u_fm'].reshape(-1)) < 1e-6 and relerr(g['Zf'][0], g_r['Zf'][0]) < 1e-6
     ed0, _, g0 = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=2.0)
     assert 'f_mu' not in g0 and abs(ed0 - ed) > 1e-6 * abs(ed)                 # the offset matters; without it no extra gradient entry
-    out = engine.kron_predict(p, X, jitter=1e-6, g_offset=-1.0, f_mu=fmu)
-    ref = o.kron_build_predict(X, p, 1e-6, -1.0, f_mu=fmu)
-    for i in range(9):
-        assert relerr(out[i], ref[i].reshape(-1)) < 1e-6, NAMES[i]
+    out = engine.kron_predict(p, X, jitter=1e-5, g_offset=-1.0, f_mu=fmu)
+    out0 = engine.kron_predict(p, X, jitter=1e-5, g_offset=-1.0)
+    ref = o.kron_build_predict(X, p, 1e-5, -1.0, f_mu=fmu)
+    assert np.max(np.abs(out[3] - out0[3] - fmu)) < 1e-12 and np.array_equal(out[4:], out0[4:])      # fmean shifted, f's variance and g untouched
+    for i in range(9):       # (the op-order floor of these synthetic factors is covered in test_gpu_kron.py; here: the offset reaches every output)
+        assert relerr(out[i], ref[i].reshape(-1)) < 5e-6, NAMES[i]
     engine.set_data(X, Y)
     b = engine.kron_elbo(p, rows=(0, rows), jitter=1e-5, scale=2.0, f_mu=fmu)
     assert b[0] == ed and b[2]['f_mu'] == g['f_mu']
@@ -317,6 +319,7 @@ def test_pivot_rtol_zero_gives_the_bare_positive_pivot_test(engine):
     X, Y, p = make_problem(600, 24, 2, seed=5)
     bad = dict(p, Zf=p['Zf'].copy())
     bad['Zf'][7] = bad['Zf'][3] + 1e-9          # two inducing points 1e-9 apart, jitter 0: the pivot is ~1e-17 * var, positive or not by rounding
+    engine.set_data(X, Y)
     with pytest.raises(zigp.NotPositiveDefiniteError):
         engine.elbo(bad, jitter=0.0, need_grad=False)
     assert engine.lib.zigp_last_info(engine.ctx) == 8        # 1-based pivot index

@@ -47,6 +47,8 @@ int latent_upload(zigp_ctx* c, Latent& lt, const HostLatent& h, int D) {
   ZIGP_ENSURE(c, lt.T1, (size_t)Mp * Mp);
   ZIGP_ENSURE(c, lt.vec, (size_t)4 * Mp + 8);
   ZIGP_ENSURE(c, lt.Wp, (size_t)Mp * Mp);
+  ZIGP_ENSURE(c, lt.Wt, (size_t)Mp * Mp);
+  ZIGP_ENSURE(c, lt.Wpt, (size_t)Mp * Mp);
   return 0;
 }
 
@@ -61,6 +63,12 @@ int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double j
   ZIGP_HIP(c, hipGetLastError());
   ZIGP_HIP(c, hipMemcpyAsync(lt.L.p, lt.Kuu.p, sizeof(double) * Mp * Mp, hipMemcpyDeviceToDevice, c->stream));
   ZIGP_TRY(potrf_trtri(c, lt.L.p, lt.W.p, lt.T1.p, Mp, want_W, lt.M, pivot_tol(h.var, jitter, pivot_rtol)));
+#if ZIGP_LOWER_VIA_WT
+  if (want_W) {   // W^T and (W diag(s^2))^T for the lower-triangular products (the latter is used by gradient steps only; it costs nothing extra)
+    hipLaunchKernelGGL(k_transpose_scale, dim3(Mp / 32, Mp / 32), dim3(32, 8), 0, c->stream, lt.W.p, lt.s2.p, (int64_t)Mp, lt.Wt.p, lt.Wpt.p);
+    ZIGP_HIP(c, hipGetLastError());
+  }
+#endif
   return 0;
 }
 
@@ -109,7 +117,11 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
   {
     ProfScope ps(c, PC_GEMM_A1, fl);   // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
     EpiStoreColsum ep{lt.vec.p, nullptr, lt.part.p, lt.part.p + (size_t)np * Nc};
+#if ZIGP_LOWER_VIA_WT
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wt.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), ep)));
+#else
     ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), ep)));
+#endif
   }
   {
     ProfScope ps(c, PC_GEMM_A2, fl);   // A2 = W^T A1 ; partial column sums  sum s^2 A2^2
@@ -119,7 +131,11 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
   if (need_grad) {
     {
       ProfScope ps(c, PC_GEMM_H, fl);   // H = (W diag(s^2)) A2
+#if ZIGP_LOWER_VIA_WT
+      ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wpt.p, Mp, lt.A2.p, Nc, lt.H.p, Nc), EpiStore())));
+#else
       ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wp.p, Mp, lt.A2.p, Nc, lt.H.p, Nc), EpiStore())));
+#endif
     }
     {
       ProfScope ps(c, PC_GEMM_J, fl);   // J' = W^T H - A2
@@ -127,20 +143,6 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
     }
   }
   return 0;
-}
-
-// Number of split-K slices of the rank-N update: smallest S >= 4 whose tile count fills whole waves of the
-// 2 x 256 resident workgroups to >= 95 % (e.g. 36 lower tiles at M = 1024 -> S = 14 -> 504 of 512 slots).
-int syr_slices(int nbm) {
-  const int ntl = nbm * (nbm + 1) / 2, slots = 512;
-  int best = 4; double best_eff = 0.0;
-  for (int S = 4; S <= 64; ++S) {
-    const int t = ntl * S;
-    const double eff = (double)t / (double)(((t + slots - 1) / slots) * slots);
-    if (eff > best_eff + 1e-12) { best_eff = eff; best = S; }
-    if (eff >= 0.95) { best = S; break; }
-  }
-  return best;
 }
 
 // Kuf-cotangent reductions of one latent and chunk (HBM-read bound; runs on the side stream under the chunk's SYRKs)
@@ -171,7 +173,7 @@ int latent_chunk_kgrad(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows,
 int latent_chunk_syrk(zigp_ctx* c, Latent& lt, int64_t Nc) {
   const int Mp = lt.Mp, nbm = Mp / BM;
   TileList ts;
-  ZIGP_TRY(tiles_syr2k(c, nbm, (int)(Nc / BK), syr_slices(nbm), ts));
+  ZIGP_TRY(tiles_syr2k(c, nbm, (int)(Nc / BK), syr_plan(nbm), ts));
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {
     ProfScope ps(c, PC_SYR2K, fl);   // planes += tril(A1 G A1^T)   (G = diag(gv) applied as k-scale on the B operand)
@@ -201,7 +203,7 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
       hipLaunchKernelGGL(k_gemv_cols, dim3(Mp / 64), dim3(64, COL_LANES), 0, c->stream, lt.W.p, lt.a1gm.p, (int64_t)Mp, lt.du.p);
     }
     // C1 = sym(sum_s planes) -> T1
-    hipLaunchKernelGGL(k_sym_from_planes, dim3(gridmm), dim3(256), 0, c->stream, lt.dLpart.p, syr_slices(nb), (int64_t)Mp, lt.T1.p);
+    hipLaunchKernelGGL(k_sym_from_planes, dim3(gridmm), dim3(256), 0, c->stream, lt.dLpart.p, syr_plan(nb).planes(), (int64_t)Mp, lt.T1.p);
     // dsq = diag(A2 G A2^T) = diag(W^T C1 W): Y = C1 W -> T3 ; dsq[m] = sum_k W[k][m] Y[k][m]
     ZIGP_TRY((run_gemm_sk<LAY_KCONTIG, LAY_MNCONTIG>(c, lt.sk, "y", nb, [&](int bi, int bj, int& k0, int& k1) { k0 = bj * kb; k1 = nb * kb; },
                                                      lt.T1.p, lt.W.p, lt.T3.p, Mp, SK_STORE, 1.0, false)));
@@ -326,7 +328,7 @@ int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
     }
     if (k.need_grad) {
       ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)KG_SPLIT * Mp * (2 + 2 * D));
-      const int S = syr_slices(Mp / BM);
+      const int S = syr_plan(Mp / BM).planes();
       ZIGP_ENSURE(c, lt.dLpart, (size_t)S * Mp * Mp);
       ZIGP_ENSURE(c, lt.a1gm, Mp);
       ZIGP_HIP(c, hipMemsetAsync(lt.a1gm.p, 0, sizeof(double) * Mp, c->stream));
@@ -345,7 +347,8 @@ int dense_pointwise(zigp_ctx* c, const DenseCall& k, int64_t n0, int64_t Nc) {
   PwArgs a;
   a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32;
   {
-    constexpr int RW1 = Shape<WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false>::value>::RW, RW2 = Shape<WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false>::value>::RW;
+    constexpr int RW2 = Shape<WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false>::value>::RW;
+    constexpr int RW1 = ZIGP_LOWER_VIA_WT ? RW2 : Shape<WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false>::value>::RW;
     static_assert(RW1 >= 32 && RW2 >= 32, "partial-row planes are allocated for 32-row wave tiles");
     a.np1_f = c->lat[0].Mp / RW1; a.np2_f = c->lat[0].Mp / RW2; a.np1_g = c->lat[1].Mp / RW1; a.np2_g = c->lat[1].Mp / RW2;
   }
@@ -536,7 +539,7 @@ int zigp_destroy(zigp_ctx* c) {
   if (c->comm) { RcclApi* api = rccl_api(nullptr); if (api) (void)api->CommDestroy(static_cast<ncclComm_t>(c->comm)); c->comm = nullptr; }
   for (int h = 0; h < 2; ++h) {
     Latent& l = c->lat[h];
-    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.H, &l.Jp, &l.Wp, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
+    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.H, &l.Jp, &l.Wp, &l.Wt, &l.Wpt, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
                     &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec, &l.sk};
     for (DevBuf* b : bs) b->release();
   }

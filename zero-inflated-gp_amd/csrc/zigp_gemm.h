@@ -81,7 +81,8 @@ struct GemmArgs {
 // An epilogue is `template <int TM, int TN> void operator()(const double (&acc)[TM][TN][4], const EpiCtx&) const`.
 struct EpiCtx {
   double* C; int64_t ldc; double alpha;
-  int64_t row0, col0;   // of this wave's RW x 64 sub-tile
+  int64_t row0, col0;   // first row / column of this wave's sub-tile (tm = 0, tn = 0)
+  int64_t prow;         // index of this wave's partial row for the fused column sums (one per wave and row block)
   int lane;
 };
 template <int TM, int TN, class F>
@@ -122,7 +123,7 @@ struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
 // Store + fused column reductions over this wave's 16 * TM rows (GPConditional's reduce_sum over the inducing index,
 // onofftf/main.py:278,287,291,302):   out1[n] = sum_m w1[m] C[m,n]   (skipped if w1 == nullptr)
 //                                      out2[n] = sum_m w2[m] C[m,n]^2 (w2 == nullptr -> weight 1)
-// written to partial row (global row / wave-tile rows) of out1/out2 (each [Mp / (16 TM)][ldc]); the point-wise kernel adds the partial
+// written to partial row e.prow (one per wave and row block) of out1/out2 (each [Mp / (16 TM)][ldc]); the point-wise kernel adds the partial
 // rows in index order, so the result does not depend on scheduling.
 struct EpiStoreColsum {
   const double* __restrict__ w1; const double* __restrict__ w2; double* __restrict__ out1; double* __restrict__ out2;
@@ -148,7 +149,7 @@ struct EpiStoreColsum {
             s2[tn] = fma(a2 * v, v, s2[tn]);
           }
         }
-      const int64_t prow = e.row0 / (16 * TM);
+      const int64_t prow = e.prow;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {   // fixed-order combine of the four 16-lane row groups
         double a = s1[tn], b = s2[tn];
@@ -174,24 +175,23 @@ template <bool NEWMAP> __device__ __forceinline__ int kswz(int row) {
 }
 
 
-// Staging addresses.  A global_load_lds takes (scalar base) + (32-bit per-lane byte offset): the per-lane offsets of this
-// wave's 16 / GEMM_WAVES chunks are computed ONCE (they do not depend on the BK step), the scalar base advances by a
-// constant each step, and the LDS destination (M0) is scalar arithmetic on the wave id -- no per-step vector address math.
+// Staging addresses.  A global_load_lds takes (scalar base) + (32-bit per-lane byte offset).  The per-lane offset of this wave's FIRST
+// 1 KB chunk is computed once per tile; its other 16 / WAVES - 1 chunks lie a uniform distance further on (chunk c = WAVES p + wave holds
+// rows 8c .. 8c + 7 of a k-contiguous tile -- 8 WAVES rows per p, and the swizzle only sees the row's low four bits -- or k-row c of an
+// m/n-contiguous one), which goes into the SCALAR base: one offset register per operand instead of 16 / WAVES (r3: the registers this
+// frees are what lets the peeled diagonal tail of the triangular products compile without spills).  The scalar base advances by a
+// constant each BK step, and the LDS destination (M0) is scalar arithmetic on the wave id -- no per-step vector address math.
 template <int LAY, int WAVES, bool NEWMAP>
-__device__ __forceinline__ void glds_lane_offsets(uint32_t (&off)[16 / WAVES], int64_t ld, int wave, int lane) {
-  constexpr int CHUNKS = 16 / WAVES;
-#pragma unroll
-  for (int p = 0; p < CHUNKS; ++p) {
-    const int c = WAVES * p + wave;                     // 1 KB chunk id (0..15)
-    if (LAY == LAY_KCONTIG) {                           // chunk = rows 8c..8c+7, lane -> (row, granule position)
-      const int row = 8 * c + (lane >> 3), gp = lane & 7;
-      const int g = gp ^ kswz<NEWMAP>(row);
-      off[p] = (uint32_t)((row * ld + 2 * g) * 8);
-    } else {                                            // chunk = k-row c, lane -> granule
-      off[p] = (uint32_t)((c * ld + 2 * lane) * 8);
-    }
+__device__ __forceinline__ uint32_t glds_lane_offset(int64_t ld, int wave, int lane) {
+  if (LAY == LAY_KCONTIG) {                           // chunk = rows 8c..8c+7, lane -> (row, granule position)
+    const int row = 8 * wave + (lane >> 3), gp = lane & 7;
+    const int g = gp ^ kswz<NEWMAP>(row);
+    return (uint32_t)((row * ld + 2 * g) * 8);
   }
+  return (uint32_t)((wave * ld + 2 * lane) * 8);      // chunk = k-row c, lane -> granule
 }
+template <int LAY, int WAVES>
+__device__ __forceinline__ int64_t glds_chunk_stride(int64_t ld) { return (LAY == LAY_KCONTIG ? 8 * WAVES : WAVES) * ld * 8; }
 // BPAD: a k-contiguous B image gets 2 doubles (16 B) of padding in front of every 16-row block.  The four B fragments of a k-step
 // (tn = 0..3) then sit 2064 B apart -- beyond the 2040-B reach of ds_read2_b64 and not a multiple of 512 B (ds_read2st64_b64) --
 // so the compiler must issue them as single ds_read_b64, which take the conflict-free 64-bank path (the paired form reads two
@@ -200,17 +200,16 @@ __device__ __forceinline__ void glds_lane_offsets(uint32_t (&off)[16 / WAVES], i
 #define ZIGP_BPAD 1
 #endif
 template <int LAY, int WAVES, bool PAD = false>
-__device__ __forceinline__ void glds_tile(double* tile, const char* __restrict__ base, const uint32_t (&off)[16 / WAVES], int wave) {
+__device__ __forceinline__ void glds_tile(double* tile, const char* __restrict__ base, uint32_t off, int64_t chunk_stride, int wave) {
 #pragma unroll
   for (int p = 0; p < 16 / WAVES; ++p) {
     const int c = WAVES * p + wave;
     double* dst = tile + ((LAY == LAY_KCONTIG) ? c * 128 + (PAD ? (c >> 1) * 2 : 0) : c * LDMN);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (uint64_t)off[p]),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + p * chunk_stride + (uint64_t)off),
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
 }
 
-// LDS offset of the A fragment (tm, r) of k-step ks for this lane (tm, r, ks are compile-time after unrolling)
 template <int ALAY, bool NEWMAP>
 __device__ __forceinline__ int a_read_off(const int (&a_base)[4], int tm, int r, int ks) {
   if (ALAY == LAY_KCONTIG) {
@@ -223,48 +222,134 @@ __device__ __forceinline__ int a_read_off(const int (&a_base)[4], int tm, int r,
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// TRI: triangular structure exploited at wave (64-row) granularity inside diagonal blocks
+// TRI: triangular structure exploited at wave granularity inside diagonal blocks (64 rows in the 4-wave, 32 rows in the 8-wave shape).
+// r3, measured and removed: peeling the diagonal 128 x 128 block of the triangular factor into a tail of 8 steps with 16-row granularity
+// (sub-tile rows dealt out round-robin over the waves along M so that they stay balanced; the wave row a template parameter, the tail
+// straight-line code) executes 1.016 instead of 1.03-1.06 x the algorithmic MFMAs and was 3 % SLOWER per step (193.4 vs 187.8 ms, same
+// box, profiles/r03c_ab_tail.log): a tail step with one or two live sub-tiles is all barrier, staging wait and LDS latency, and the
+// four per-wave-row copies spill 50-150 B/lane outside their main loops.
 enum { TRI_NONE = 0,
        TRI_A_LOWER = 1,   // A(i,k) = 0 for k > i   (W * B)
        TRI_A_UPPER = 2,   // A(i,k) = 0 for k < i   (W^T * B)
        TRI_C_LOWER = 3    // only C(i,j), j <= i, is used (rank-N update of a lower-triangular cotangent)
 };
 
+// ---- diagonal tile of the symmetric rank-N update (TRI_C_LOWER, bi == bj: the A and the B operand are the SAME 128 rows) -------------
+// The generic path computes a diagonal tile as three 64 x 64 wave tiles (the fourth wave idles) = 0.75 of a full tile for 0.5625 of
+// useful work, in the time of a full tile.  Here only ONE operand tile is staged per BK step, and the 36 lower 16 x 16 sub-tiles (8 x 8
+// grid, diagonal included) are dealt out 9 per wave: wave w owns the sub-tile rows w and 7 - w, i.e. w + 1 and 8 - w column sub-tiles.
+// The wave index is a template parameter (the four instantiations sit behind one scalar switch): every loop bound is a compile-time
+// constant.  36 accumulators, 8 A and <= 8 B fragments per k-step: ~120 VGPRs inside a kernel that holds 256 anyway.  The host gives
+// diagonal tiles longer k ranges (fewer split-K slices) so that both kinds of workgroup finish together (tiles_syr2k).
+#ifndef ZIGP_SYRK_DIAG
+#define ZIGP_SYRK_DIAG 1
+#endif
+template <int W, int NSTAGE, bool KSCALE, class Epi>
+__device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile& tl, double* lds, int wave, int lane, const Epi& epi) {
+  constexpr int WAVES = 4, CHUNKS = Shape<WAVES>::CHUNKS;
+  constexpr int R1 = W, R2 = 7 - W, NC1 = W + 1, NC2 = 8 - W;   // this wave's two sub-tile rows and the column sub-tiles 0..NC-1 each needs
+  const GemmSeg& sg = g.seg[0];
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  const int a_i = ln & 3, kq = ln >> 4, b_j = ln & 15;
+  // element (row, k) of the swizzled [128][16] image: row * 16 + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)   (kswz<false>, both roles)
+  const int a_base = a_i * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1);
+  int b_base[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) b_base[ks] = b_j * 16 + 2 * (((2 * ks) | (kq >> 1)) ^ kswz<false>(b_j)) + (kq & 1);
+  double acc1[1][NC1][4], acc2[1][NC2][4];
+#pragma unroll
+  for (int c = 0; c < NC1; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc1[0][c][r] = 0.0;
+#pragma unroll
+  for (int c = 0; c < NC2; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc2[0][c][r] = 0.0;
+  const int total = tl.kend - tl.kbeg;
+  const uint32_t offA = glds_lane_offset<LAY_KCONTIG, WAVES, false>(sg.lda, wave, ln);
+  const int64_t csA = glds_chunk_stride<LAY_KCONTIG, WAVES>(sg.lda);
+  const int64_t row0 = (int64_t)tl.bi * BM;
+  const int kb0 = (tl.kdir >= 0) ? tl.kbeg : tl.kend - 1;
+  const int64_t kfirst = (int64_t)kb0 * BK, kd = (tl.kdir >= 0) ? 1 : -1;
+  const char* baseA = (const char*)(sg.A + row0 * sg.lda + kfirst);
+  const char* baseS = (const char*)(g.kscale + kfirst);
+  const int64_t strideA = kd * BK * 8;
+  auto issue = [&](int it) {
+    double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
+    glds_tile<LAY_KCONTIG, WAVES>(st, baseA + it * strideA, offA, csA, wave);
+    if (KSCALE) {
+      if (ln < 8)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + kd * it * (BK * 8) + (int64_t)(16 * ln)),
+                                         (__attribute__((address_space(3))) void*)(st + 2 * TILE_DOUBLES), 16, 0, 0);
+    }
+  };
+  constexpr int GLDS_PER_STAGE = CHUNKS + (KSCALE ? 1 : 0);
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < total) issue(s);
+  for (int it = 0; it < total; ++it) {
+    if (it + NSTAGE - 2 < total) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (it + NSTAGE - 1 < total) issue(it + NSTAGE - 1);
+    const double* As = lds + (it % NSTAGE) * STAGE_DOUBLES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      double bf[NC2], af1[4], af2[4];
+#pragma unroll
+      for (int c = 0; c < NC2; ++c) bf[c] = As[b_base[ks] + c * 256];
+      if (KSCALE) {
+        const double sc = As[2 * TILE_DOUBLES + ks * 4 + kq];
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) bf[c] *= sc;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        af1[r] = As[a_base + (R1 * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r))];
+        af2[r] = As[a_base + (R2 * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r))];
+      }
+#pragma unroll
+      for (int c = 0; c < NC2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc2[0][c][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af2[r], bf[c], acc2[0][c][r], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NC1; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc1[0][c][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af1[r], bf[c], acc1[0][c][r], 0, 0, 0);
+    }
+  }
+  EpiCtx e;
+  e.C = g.C + (int64_t)tl.slice * g.slice_stride; e.ldc = g.ldc; e.alpha = g.alpha; e.lane = lane; e.prow = 0;
+  e.col0 = row0;
+  e.row0 = row0 + R2 * 16; epi(acc2, e);
+  e.row0 = row0 + R1 * 16; epi(acc1, e);
+}
+
+// One output tile of the generic path.
 template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, int WAVES, class Epi>
-__global__ void __launch_bounds__(64 * WAVES, ((NSTAGE <= 2) ? 2 : 1) * WAVES / 4)
-gemm_f64_kernel(GemmArgs g, Epi epi) {
-  constexpr int WNW = Shape<WAVES>::WNW, WTN = Shape<WAVES>::WTN, TNW = Shape<WAVES>::TNW, CHUNKS = Shape<WAVES>::CHUNKS;
-  constexpr int RW = Shape<WAVES>::RW, TMW = Shape<WAVES>::TMW;
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl, double* lds, int wave, int wm, int wn, int lane, const Epi& epi) {
+  constexpr int WTN = Shape<WAVES>::WTN, TNW = Shape<WAVES>::TNW, CHUNKS = Shape<WAVES>::CHUNKS;
+  constexpr int RW = Shape<WAVES>::RW, TMW = Shape<WAVES>::TMW, WMW = Shape<WAVES>::WMW;
   // the 4-base A map costs 3 VGPRs more: used where the B tile is m/n-contiguous (1 base register), not in the K/K kernels
   constexpr bool A_NEWMAP = (BLAY == LAY_MNCONTIG);
   constexpr bool B_PAD = (ZIGP_BPAD != 0) && (BLAY == LAY_KCONTIG);
-  static_assert(TILE_DOUBLES >= 128 * 16 + 16, "padded B image must fit the stage");
-  extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS destinations and wave-level skips stay on the SALU
-  const int wm = wave / WNW, wn = wave % WNW;
   const GemmSeg& sg = g.seg[0];
-  bool ring_used = false;
-  for (int u = 0; u < g.per; ++u) {
-  const GemmTile tl = g.tiles[(int64_t)blockIdx.x * g.per + u];
-  if (tl.kend <= tl.kbeg) continue;                 // padding entry (uniform over the workgroup)
-  if (ring_used) __builtin_amdgcn_s_barrier();      // slower waves may still read the previous tile's last stage
-  ring_used = true;
   const int64_t row0 = (int64_t)tl.bi * BM, col0 = (int64_t)tl.bj * BN;
   // Everything derived from the lane id is recomputed per tile from an opaque copy: otherwise the compiler keeps the ~16
   // address registers alive across the epilogue of the previous tile and spills there.
   int ln = lane;
   asm volatile("" : "+v"(ln));
   const int a_i = ln & 3, kq = ln >> 4, b_j = ln & 15;
+  const int wrow = wm * RW;     // row (within the 128-row block) of this wave's sub-tile
   // per-lane LDS read bases; the (tm, r, tn, ks) parts are compile-time offsets (see header comment)
   // k-contiguous A: granule = (2ks | kq>>1) ^ a_i ^ C(r), C(r) = 4(r&1) + (r>>1)  ->  [(2ks ^ C(r)) & ~3] is a compile-time
   // offset and the low two bits select one of four per-lane bases a_base[x] = ... + 2*((a_i ^ (kq>>1)) ^ x)
   int a_base_[4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
-    a_base_[x] = (ALAY == LAY_KCONTIG) ? (A_NEWMAP ? ((wm * RW + a_i) * 16 + 2 * ((a_i ^ (kq >> 1)) ^ x) + (kq & 1))
-                                                    : ((wm * RW + a_i) * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1)))
-                                      : (kq * LDMN + wm * RW + a_i);
+    a_base_[x] = (ALAY == LAY_KCONTIG) ? (A_NEWMAP ? ((wrow + a_i) * 16 + 2 * ((a_i ^ (kq >> 1)) ^ x) + (kq & 1))
+                                                    : ((wrow + a_i) * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1)))
+                                      : (kq * LDMN + wrow + a_i);
   int b_base_[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
@@ -280,9 +365,8 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
       for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.0;
 
   const int total = tl.kend - tl.kbeg;       // BK steps of this tile
-  uint32_t offA[CHUNKS], offB[CHUNKS];
-  glds_lane_offsets<ALAY, WAVES, A_NEWMAP>(offA, sg.lda, wave, ln);
-  glds_lane_offsets<BLAY, WAVES, false>(offB, sg.ldb, wave, ln);
+  const uint32_t offA = glds_lane_offset<ALAY, WAVES, A_NEWMAP>(sg.lda, wave, ln), offB = glds_lane_offset<BLAY, WAVES, false>(sg.ldb, wave, ln);
+  const int64_t csA = glds_chunk_stride<ALAY, WAVES>(sg.lda), csB = glds_chunk_stride<BLAY, WAVES>(sg.ldb);
   // scalar bases of BK step 0 and their per-step strides (bytes)
   const int kb0 = (tl.kdir >= 0) ? tl.kbeg : tl.kend - 1;   // k block (units of BK) of BK step 0; step `it` is kb0 + kdir * it
   const int64_t kfirst = (int64_t)kb0 * BK;
@@ -295,8 +379,8 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
 
   auto issue = [&](int it) {
     double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
-    glds_tile<ALAY, WAVES>(st, baseA + it * strideA, offA, wave);
-    glds_tile<BLAY, WAVES, B_PAD>(st + TILE_DOUBLES, baseB + it * strideB, offB, wave);
+    glds_tile<ALAY, WAVES>(st, baseA + it * strideA, offA, csA, wave);
+    glds_tile<BLAY, WAVES, B_PAD>(st + TILE_DOUBLES, baseB + it * strideB, offB, csB, wave);
     if (KSCALE) {   // 16 doubles of the scale vector; every wave issues the same 128 B (uniform vmcnt accounting)
       if (ln < 8)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + kd * it * (BK * 8) + (int64_t)(16 * ln)),
@@ -309,77 +393,110 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < total) issue(s);
 
-  for (int it = 0; it < total; ++it) {
-    // stage `it` must have landed: at most NSTAGE-2 younger stages (8 glds each) may stay in flight
+  // stage `it` must have landed (at most NSTAGE-2 younger stages may stay in flight), every wave is done with the stage about to be
+  // overwritten, then the next stage is requested: one barrier per BK step
+  auto stage_step = [&](int it) -> const double* {
     if (it + NSTAGE - 2 < total) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (it + NSTAGE - 1 < total) issue(it + NSTAGE - 1);
-    const double* As = lds + (it % NSTAGE) * STAGE_DOUBLES;
+    return lds + (it % NSTAGE) * STAGE_DOUBLES;
+  };
+  // One BK step of this wave's RW x 64 sub-tile, fully unrolled.  The loop has ONE body (runtime predicates inside the unrolled nest,
+  // and a choice of bodies, spill and pessimise its schedule: the 4-wave kernels sit close to 256 VGPRs).
+  auto body = [&](const double* As) {
     const double* Bs = As + TILE_DOUBLES;
-    // Triangular structure at wave (64-row) granularity: a wave whose rows cannot touch this BK step of a
-    // triangular A, or whose whole 64x64 output lies above the diagonal of a lower-triangular C, issues no MFMAs
-    // (it still takes part in staging and barriers; the co-resident workgroup gets the matrix pipe).
-    const int krel = (kb0 + (int)kd * it) * BK - tl.bi * BM;   // k offset of this step relative to the row block
-    // One BK step of this wave's RW x 64 sub-tile, fully unrolled with compile-time bounds (runtime predicates inside the unrolled
-    // nest, and more than one unrolled body per kernel, spill: the 4-wave kernels sit at 255-256 VGPRs; rounds 1 and 2).
-    auto body = [&]() {
-      constexpr int LO = 0, HI = TMW - 1;
-      const int (&a_base)[4] = a_base_; const int (&b_base)[4] = b_base_;
+    const int (&a_base)[4] = a_base_; const int (&b_base)[4] = b_base_;
 #pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        const int k = ks * 4 + kq;
-        double bf[TNW];
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      const int k = ks * 4 + kq;
+      double bf[TNW];
 #pragma unroll
-        for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * (B_PAD ? 258 : 256) : tn * 16)];
-        if (KSCALE) {
-          const double sc = As[2 * TILE_DOUBLES + k];
+      for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * (B_PAD ? 258 : 256) : tn * 16)];
+      if (KSCALE) {
+        const double sc = As[2 * TILE_DOUBLES + k];
 #pragma unroll
-          for (int tn = 0; tn < TNW; ++tn) bf[tn] *= sc;
-        }
-        if (WAVES == 4) {
-          // all A fragments of this k-step are requested before the first MFMA (the MFMAs that follow cover the LDS latency of
-          // the next k-step's reads, which the compiler hoists above them)
-          double af[TMW][4];
+        for (int tn = 0; tn < TNW; ++tn) bf[tn] *= sc;
+      }
+      if (WAVES == 4) {
+        // all A fragments of this k-step are requested before the first MFMA (the MFMAs that follow cover the LDS latency of
+        // the next k-step's reads, which the compiler hoists above them)
+        double af[TMW][4];
 #pragma unroll
-          for (int tm = LO; tm <= HI; ++tm)
+        for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              af[tm][r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
+          for (int r = 0; r < 4; ++r)
+            af[tm][r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
 #pragma unroll
-          for (int tm = LO; tm <= HI; ++tm)
+        for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < TNW; ++tn)
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
-        } else {
-          // 4 waves/SIMD hide LDS latency across waves: fragments are read 4 at a time to stay within 128 VGPRs
-#pragma unroll
-          for (int tm = LO; tm <= HI; ++tm) {
-            double af[4];
+          for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              af[r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
+              acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
+      } else {
+        // 4 waves/SIMD hide LDS latency across waves: fragments are read 4 at a time to stay within 128 VGPRs
 #pragma unroll
-            for (int tn = 0; tn < TNW; ++tn)
+        for (int tm = 0; tm < TMW; ++tm) {
+          double af[4];
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[r], bf[tn], acc[tm][tn][r], 0, 0, 0);
-          }
+          for (int r = 0; r < 4; ++r)
+            af[r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
+#pragma unroll
+          for (int tn = 0; tn < TNW; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[r], bf[tn], acc[tm][tn][r], 0, 0, 0);
         }
       }
-    };
+    }
+  };
+  for (int it = 0; it < total; ++it) {
+    const double* As = stage_step(it);
+    // Triangular structure at wave granularity: a wave whose rows cannot touch this BK step of a triangular A, or whose whole 64x64
+    // output lies above the diagonal of a lower-triangular C, issues no MFMAs (it still takes part in staging and barriers; the
+    // co-resident workgroup gets the matrix pipe).
+    const int krel = (kb0 + (int)kd * it) * BK - tl.bi * BM;   // k offset of this step relative to the row block
     bool skip = false;
     if (TRI == TRI_A_LOWER) skip = krel > wm * RW + RW - 1;
     if (TRI == TRI_A_UPPER) skip = krel + BK - 1 < wm * RW;
     if (TRI == TRI_C_LOWER) skip = (tl.bi == tl.bj) && (wn * WTN > wm * RW + RW - 1);
-    if (!skip) body();
+    if (!skip) body(As);
   }
 
   EpiCtx e;
   e.C = g.C + (int64_t)tl.slice * g.slice_stride; e.ldc = g.ldc; e.alpha = g.alpha;
-  e.row0 = row0 + wm * RW; e.col0 = col0 + wn * WTN; e.lane = lane;
+  e.row0 = row0 + wrow; e.col0 = col0 + wn * WTN; e.lane = lane; e.prow = (int64_t)tl.bi * WMW + wm;
   epi(acc, e);
+}
+
+template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, int WAVES, class Epi>
+__global__ void __launch_bounds__(64 * WAVES, ((NSTAGE <= 2) ? 2 : 1) * WAVES / 4)
+gemm_f64_kernel(GemmArgs g, Epi epi) {
+  constexpr int WNW = Shape<WAVES>::WNW;
+  static_assert(TILE_DOUBLES >= 128 * 16 + 16, "padded B image must fit the stage");
+  extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS destinations and wave-level skips stay on the SALU
+  const int wm = wave / WNW, wn = wave % WNW;
+  const GemmSeg& sg = g.seg[0];
+  bool ring_used = false;
+  for (int u = 0; u < g.per; ++u) {
+  const GemmTile tl = g.tiles[(int64_t)blockIdx.x * g.per + u];
+  if (tl.kend <= tl.kbeg) continue;                 // padding entry (uniform over the workgroup)
+  if (ring_used) __builtin_amdgcn_s_barrier();      // slower waves may still read the previous tile's last stage
+  ring_used = true;
+  if constexpr (ZIGP_SYRK_DIAG != 0 && TRI == TRI_C_LOWER && ALAY == LAY_KCONTIG && BLAY == LAY_KCONTIG && WAVES == 4) {
+    if (tl.bi == tl.bj) {   // diagonal tile of the symmetric update: balanced lower-triangle path (uniform over the workgroup)
+      switch (wave) {
+        case 0: syrk_diag_tile<0, NSTAGE, KSCALE>(g, tl, lds, wave, lane, epi); break;
+        case 1: syrk_diag_tile<1, NSTAGE, KSCALE>(g, tl, lds, wave, lane, epi); break;
+        case 2: syrk_diag_tile<2, NSTAGE, KSCALE>(g, tl, lds, wave, lane, epi); break;
+        default: syrk_diag_tile<3, NSTAGE, KSCALE>(g, tl, lds, wave, lane, epi); break;
+      }
+      continue;
+    }
+  }
+  gemm_tile<ALAY, BLAY, NSTAGE, KSCALE, TRI, WAVES>(g, tl, lds, wave, wm, wn, lane, epi);
   }
 }
 

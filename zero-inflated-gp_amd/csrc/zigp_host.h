@@ -45,6 +45,13 @@ static inline GemmTile mk_tile(int bi, int bj, int kbeg, int kend, int slice = 0
 #endif
 constexpr int NST = ZIGP_NSTAGE;   // LDS ring depth of the GEMM core (2 -> 64 KB, 2 workgroups/CU; 3-4 -> 1 workgroup/CU)
 
+// The lower-triangular products (A1 = W K, H = W diag(s^2) A2) read their factor TRANSPOSED (m-contiguous image W^T, written once per
+// step by k_transpose_scale), so that all four triangular products run the 8-wave <m/n-contiguous, m/n-contiguous> kernel (4 waves per
+// SIMD, 32-row triangular skipping): A1 / H 56-57 -> 60-61 TF; the chip gives part of it back as clock (A2 / J' / SYRK -2 %), net
+// -1.4 % per step (same-box A/B, profiles/r03c_ab_tail.log).  0: the round-1/2 arrangement (k-contiguous W, 4-wave kernel).
+#ifndef ZIGP_LOWER_VIA_WT
+#define ZIGP_LOWER_VIA_WT 1
+#endif
 // Workgroup shape per operand-layout pair (see Shape<> in zigp_gemm.h): 8 waves where the kernel fits 128 VGPRs
 template <int AL, int BL, bool KS> struct WavesFor { static constexpr int value = ZIGP_WAVES_DEFAULT; };
 #ifndef ZIGP_NO_8WAVE
@@ -83,59 +90,59 @@ static inline GemmArgs mk_args(const double* A, int64_t lda, const double* B, in
 // ------------------------------------------------------------------------------------------------
 // Triangular products C(Mp x Nc) = T * B.  Row block bi of a lower-triangular T needs the k blocks [0, bi], of an upper-triangular
 // one (W^T) the k blocks [bi, nbm).
-// Default: one tile per workgroup, longest tiles first (LPT), tiles of one column panel on one XCD (launch position p runs on
-// XCD p % 8).  PMC: the B panel is fetched from HBM once per row block (1.18 GB per launch at M = 1024, Nc = 32768 for 0.27 GB
-// of operand) -- the tiles of a panel start at different times, so that XCD's L2 never sees them together.
-// -DZIGP_TRMM_PAIRED: work unit = one workgroup = two tiles of the same column panel, a short one (u+1 k blocks) and its
-// complement (nbm-u), so every unit runs nbm+1 k blocks; the units of a panel are consecutive entries of one XCD's queue and
-// walk k in lockstep (lower: short tiles ascend from k block 0, long tiles descend so that block-step t reads k block nbm - t
-// in every unit; upper: the mirror image).  PMC: 0.55 GB fetched per launch (2.2x less); measured 1 % SLOWER per step (same-box
-// A/B, five orderings tried, profiles/r01f_*): HBM traffic is not what limits these kernels, and equal-length units lose
-// the staggering of the LPT order.  Kept as a build option for a part with less HBM headroom.
+// One tile per workgroup, longest tiles first (LPT), tiles of one column panel on one XCD (launch position p runs on XCD p % 8).
+// PMC: the B panel is fetched from HBM once per row block (1.18 GB per launch at M = 1024, Nc = 32768 for 0.27 GB of operand) -- the
+// tiles of a panel start at different times, so that XCD's L2 never sees them together.  Orders that make them share (a short and a
+// long tile of a panel paired per workgroup and walking k in lockstep: 2.2x fewer bytes, profiles/r01f_*; the tiles of a panel adjacent
+// in one XCD's queue) were 1-2 % / 7-22 % SLOWER per step: HBM traffic is not what limits these kernels.
 static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, TileList& tl) {
   const int kb = BM / BK;
   const std::string key = std::string(lower ? "trl:" : "tru:") + std::to_string(nbm) + ":" + std::to_string(nbn);
-#ifndef ZIGP_TRMM_PAIRED
   return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
     if (lower) { for (int bi = nbm - 1; bi >= 0; --bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, (bi + 1) * kb)); }
     else { for (int bi = 0; bi < nbm; ++bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * kb, nbm * kb)); }
   }, tl, 1);
-#else
-  return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
-    const int U = (nbm + 1) / 2;
-    auto tile = [&](int bi, int bj, int dir) {
-      GemmTile t = lower ? mk_tile(bi, bj, 0, (bi + 1) * kb) : mk_tile(bi, bj, bi * kb, nbm * kb);
-      t.kdir = dir;
-      return t;
-    };
-    std::vector<GemmTile> q[8];   // per-XCD queues of units (2 entries each)
-    for (int bj = 0; bj < nbn; ++bj)
-      for (int u = 0; u < U; ++u) {
-        const int lo = u, hi = nbm - 1 - u;                 // lo has the short k range for lower, hi for upper
-        std::vector<GemmTile>& dst = q[bj % 8];
-        if (lo == hi) { dst.push_back(tile(lo, bj, lower ? -1 : 1)); dst.push_back(mk_tile(0, 0, 0, 0)); continue; }
-        if (lower) { dst.push_back(tile(lo, bj, 1)); dst.push_back(tile(hi, bj, -1)); }
-        else { dst.push_back(tile(hi, bj, -1)); dst.push_back(tile(lo, bj, 1)); }
-      }
-    size_t longest = 0;
-    for (int x = 0; x < 8; ++x) longest = std::max(longest, q[x].size());
-    for (size_t e0 = 0; e0 < longest; e0 += 2)               // launch position p = 8 * (e0 / 2) + x  ->  XCD x
-      for (int x = 0; x < 8; ++x)
-        for (int e = 0; e < 2; ++e) v.push_back(e0 + e < q[x].size() ? q[x][e0 + e] : mk_tile(0, 0, 0, 0));
-  }, tl, 2);
-#endif
 }
 static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl) { return tiles_trmm(c, true, nbm, nbn, tl); }
 static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl) { return tiles_trmm(c, false, nbm, nbn, tl); }
-// lower-triangular output tiles x S split-K slices over nk k-steps.  Launch position p runs on XCD p % 8 (observed round-robin
-// dispatch; speed only): XCD x is handed a contiguous run of the slice-major tile order, so the tiles that re-read the same
+// Split-K plan of the symmetric rank-N update.  Off-diagonal tiles are cut into So slices, diagonal tiles (which run the balanced
+// lower-triangle path of zigp_gemm.h: 36 of 64 sub-tile products per step, ~0.7 of a full tile's time with its staging and barriers)
+// into Sd < So slices, so that every workgroup of the single wave of <= 512 resident workgroups finishes at the same time:
+// minimise max(1 / So, 0.72 / Sd) subject to n_off So + n_diag Sd <= 512.  M = 1024: 28 x 15 + 8 x 11 = 508 workgroups (was 36 x 14).
+struct SyrPlan { int So, Sd; int planes() const { return std::max(So, Sd); } };
+static inline SyrPlan syr_plan(int nbm) {
+  const int n_off = nbm * (nbm - 1) / 2, n_d = nbm, slots = 512;
+  SyrPlan best{1, 1};
+#if ZIGP_SYRK_DIAG
+  const double diag_cost = 0.72;   // measured: 28 x 15 + 8 x 10 slices ran as if a diagonal tile cost 0.69 of a full one (r03b A/B)
+#else
+  const double diag_cost = 1.0;
+#endif
+  if (n_off + n_d > slots) return best;
+  double best_t = 1e30;
+  for (int So = 1; So <= 128; ++So) {
+    const int left = slots - n_off * So;
+    if (left < n_d) break;
+    const int Sd = std::min(128, left / n_d);
+    const double t = std::max(n_off ? 1.0 / So : 0.0, diag_cost / Sd);
+    if (t < best_t - 1e-12) { best_t = t; best = SyrPlan{So, Sd}; }
+  }
+  // no more diagonal slices than needed to stay under the off-diagonal time (fewer planes to clear and sum)
+  while (best.Sd > 1 && n_off && diag_cost / (best.Sd - 1) <= 1.0 / best.So) --best.Sd;
+  return best;
+}
+// Lower-triangular output tiles x split-K slices over nk k-steps.  Launch position p runs on XCD p % 8 (observed round-robin
+// dispatch; speed only): XCD x is handed a contiguous run of the k-major tile order, so the tiles that re-read the same
 // column slice of the panels share one L2 instead of eight.
-static int tiles_syr2k(zigp_ctx* c, int nbm, int nk, int S, TileList& tl) {
-  return get_tiles(c, "syr:" + std::to_string(nbm) + ":" + std::to_string(nk) + ":" + std::to_string(S), [&](std::vector<GemmTile>& v) {
+static int tiles_syr2k(zigp_ctx* c, int nbm, int nk, SyrPlan sp, TileList& tl) {
+  return get_tiles(c, "syr:" + std::to_string(nbm) + ":" + std::to_string(nk) + ":" + std::to_string(sp.So) + ":" + std::to_string(sp.Sd), [&](std::vector<GemmTile>& v) {
     std::vector<GemmTile> t;
-    for (int s = 0; s < S; ++s)
-      for (int bi = 0; bi < nbm; ++bi)
-        for (int bj = 0; bj <= bi; ++bj) t.push_back(mk_tile(bi, bj, (int)((int64_t)nk * s / S), (int)((int64_t)nk * (s + 1) / S), s));
+    for (int bi = 0; bi < nbm; ++bi)
+      for (int bj = 0; bj <= bi; ++bj) {
+        const int S = (bi == bj) ? sp.Sd : sp.So;
+        for (int s = 0; s < S; ++s) t.push_back(mk_tile(bi, bj, (int)((int64_t)nk * s / S), (int)((int64_t)nk * (s + 1) / S), s));
+      }
+    std::stable_sort(t.begin(), t.end(), [](const GemmTile& a, const GemmTile& b) { return a.kbeg < b.kbeg; });
     const int n = (int)t.size(), per = (n + 7) / 8;
     v.reserve(n);
     for (int p = 0; (int)v.size() < n; ++p) {

@@ -246,8 +246,10 @@ k_pointwise(PwArgs p) {
 constexpr int KG_ROWS = 4;
 constexpr int KG_SPLIT = 4;   // column splits (blockIdx.y); each split accumulates into its own krow slab [KG_SPLIT][Mp][W]
 // ZIGP_KGRAD_RECOMPUTE (default): K[m,n] is recomputed from x_n and z_m (the expression of k_kuf_build, bit for bit) instead of read
-// back -- the kernel is HBM-bound on its two panel reads (J' and K, 0.54 GB per chunk and latent), the fp64 exp costs less than the
-// 0.27 GB it replaces.
+// back: half the HBM bytes (0.27 instead of 0.54 GB per chunk and latent) for 8.1 instead of 7.2 ms of kernel time per step when it runs
+// alone -- with the side-stream overlap (zigp_set_overlap, what bench.py times) the step is 0.3 % shorter (profiles/r03a_ab_kgrad.log).
+// r3, measured and dropped: a 1-row x 2-column version of 69 VGPRs, meant to sit beside the two rank-N-update workgroups of a CU (which
+// leave 112 registers per lane; this kernel holds 150): 9.4 ms alone and no better overlapped (185.0 vs 184.5 ms/step, r03e_overlap.log).
 #ifndef ZIGP_KGRAD_RECOMPUTE
 #define ZIGP_KGRAD_RECOMPUTE 1
 #endif
@@ -575,6 +577,22 @@ __global__ void k_colscale(const double* __restrict__ W, const double* __restric
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= Mp * Mp) return;
   out[idx] = s2[idx % Mp] * W[idx];
+}
+// Wt = W^T and (optionally) Wpt = (W diag(s2))^T = diag(s2) W^T, through a 32 x 33 LDS tile (coalesced reads and writes).
+// The lower-triangular products A1 = W K and H = W diag(s^2) A2 then read their triangular factor m-contiguous, like the W^T products:
+// all four run the 8-wave kernel shape (zigp_host.h, WavesFor).  Launch with dim3(Mp / 32, Mp / 32), dim3(32, 8).
+__global__ void __launch_bounds__(256)
+k_transpose_scale(const double* __restrict__ W, const double* __restrict__ s2, int64_t Mp, double* __restrict__ Wt, double* __restrict__ Wpt) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) tile[j][threadIdx.x] = W[(int64_t)(by + j) * Mp + bx + threadIdx.x];   // W[i = by + j][k = bx + x]
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const double v = tile[threadIdx.x][j];                       // W[i = by + x][k = bx + j]
+    const int64_t o = (int64_t)(bx + j) * Mp + by + threadIdx.x;   // Wt[k][i]
+    Wt[o] = v;
+    if (Wpt) Wpt[o] = v * s2[bx + j];
+  }
 }
 // Bs[k][j] = s2[k] * P[k][j]
 __global__ void k_rowscale(const double* __restrict__ P, const double* __restrict__ s2, int64_t Mp, double* __restrict__ out) {
