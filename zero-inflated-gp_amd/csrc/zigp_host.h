@@ -110,11 +110,14 @@ static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl) { retur
 // into Sd < So slices, so that every workgroup of the single wave of <= 512 resident workgroups finishes at the same time:
 // minimise max(1 / So, 0.72 / Sd) subject to n_off So + n_diag Sd <= 512.  M = 1024: 28 x 15 + 8 x 11 = 508 workgroups (was 36 x 14).
 struct SyrPlan { int So, Sd; int planes() const { return std::max(So, Sd); } };
+// (r3, measured and dropped: the update reading both operands from a transposed copy A1^T written by the A1 epilogue, i.e. on the 8-wave
+// m-contiguous kernel: the update itself 53.9 -> 56.0 TF, but the scattered transposed stores cost the A1 product 10 % -- 60.4 -> 54.3 TF --
+// and the step 9 ms: profiles/r03f_ab_syrk_a1t.log.)
 static inline SyrPlan syr_plan(int nbm) {
   const int n_off = nbm * (nbm - 1) / 2, n_d = nbm, slots = 512;
   SyrPlan best{1, 1};
 #if ZIGP_SYRK_DIAG
-  const double diag_cost = 0.72;   // measured: 28 x 15 + 8 x 10 slices ran as if a diagonal tile cost 0.69 of a full one (r03b A/B)
+  const double diag_cost = 0.72;   // same-box sweep at M = 1024 (profiles/r03g_ab_syrk_plan.log): (So, Sd) = (15, 11) 54.8, (15, 10) 54.7, (15, 9) 53.9, (16, 8) 52.3, (14, 12) 51.4 TF
 #else
   const double diag_cost = 1.0;
 #endif
