@@ -73,6 +73,69 @@ def cpu_baseline(X, Y, p, jitter, sample_rows, threads, repeats=3):
     return float(np.median(ts)), ts, data
 
 
+def kernel_key(name):
+    """template arguments of a gemm_f64_kernel instantiation as a tuple of strings: ('1', '1', '2', 'false', '1', '8', 'EpiStoreColsum')"""
+    if 'gemm_f64_kernel<' not in name:
+        return None
+    a = name.split('gemm_f64_kernel<')[-1].split('>')[0].replace(' ', '').split(',')
+    return tuple(a[:6] + [a[6].split('::')[-1]]) if len(a) >= 7 else None
+
+
+def live_pmc_traffic(dom_kernel, M, D, chunk, timeout_s=240):
+    """HBM bytes per launch of the dominant kernel measured IN THIS RUN: two child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE
+    separately, with --kernel-trace only -- MI355X_MICROARCH.md section HBM) of a short run of the same step (4 full chunks, overlap off),
+    corrected as the guide prescribes (FETCH_SIZE x 2 on gfx950, units of KB).  Returns (bytes per launch, launches) or None."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(prof) or 'rocprof' in os.environ.get('LD_PRELOAD', '') + os.environ.get('ROCP_TOOL_LIBRARIES', ''):
+        return None          # no profiler here, or this process already runs under one
+    want = kernel_key(dom_kernel)
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix='zigp_pmc_', dir='/tmp')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__),
+                   '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-other-configs', '--profile-steps', '0', '--no-overlap', '--no-pmc',
+                   '--rows', str(4 * chunk), '--M', str(M), '--D', str(D), '--chunk', str(chunk)]
+            env = dict(os.environ, TMPDIR='/tmp')
+            for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+                env.pop(k, None)
+            # own process group: a pass that overruns is ended as a whole (profiler and the program under it), by its group id only
+            pr = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGTERM)
+                try:
+                    pr.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                    pr.wait()
+                return None
+            if pr.returncode != 0:
+                return None
+            files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
+            if not files:
+                return None
+            tot, n = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                if row['Counter_Name'] == counter and kernel_key(row['Kernel_Name']) == want:
+                    tot += float(row['Counter_Value']); n += 1
+            if n == 0:
+                return None
+            vals[counter] = (tot / n, n)
+        return (2.0 * vals['FETCH_SIZE'][0] + vals['WRITE_SIZE'][0]) * 1024.0, vals['FETCH_SIZE'][1]
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -163,6 +226,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='timed region without stream overlap')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the two child rocprofv3 --pmc passes that measure the dominant kernel\'s HBM traffic')
     ap.add_argument('--profile-steps', type=int, default=1, help='steps of the separate profiled pass (0: none)')
     ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL, the default) or 'gloo' to rehearse the multi-rank path on fewer GPUs than ranks")
     ap.add_argument('--cpu-sample-rows', type=int, default=60000)
@@ -286,11 +350,18 @@ def main():
             achieved = flops_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
             gemm_ms = sum(prof[k]['ms'] for k in gemm_classes)
             gemm_fl = sum(prof[k]['flops'] for k in gemm_classes)
-            # HBM traffic and MFMA busy fraction come from separate rocprofv3 --pmc passes (tools/pmc_run.sh, tools/pmc_mfma.sh).
-            # They are NOT measured in this run: quoted only from a summary collected on these kernel sources at this
-            # (M, chunk, D), with the file named; null otherwise.
+            # HBM traffic of the dominant kernel: measured in this run by two child rocprofv3 --pmc passes (live_pmc_traffic); if that is
+            # not possible (no profiler, already under one, --no-pmc) it is quoted from a summary under profiles/ collected on these
+            # kernel sources at this (M, chunk, D), with the file named; null otherwise.  The MFMA busy fraction (three more passes)
+            # is always quoted from such a summary (tools/pmc_mfma.sh).
             h = csrc_hash()
             traffic, traffic_src, mfma_util = None, None, None
+            if not args.no_pmc and world == 1:      # measured in THIS run (child rocprofv3 --pmc passes); the committed summary is the fallback
+                live = live_pmc_traffic(PROF_KERNELS[dom], M, D, args.chunk)
+                if live is not None:
+                    traffic = live[0]
+                    traffic_src = ('this run: child rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --rows %d --no-overlap`, '
+                                   '%d launches of the kernel, FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, KB -> bytes' % (4 * args.chunk, live[1]))
             for fn in sorted(os.listdir(os.path.join(ROOT, 'profiles')), reverse=True):
                 try:
                     if fn.endswith('_pmc_hbm_traffic.json') and traffic is None:

@@ -76,6 +76,11 @@ int zigp_set_pivot_rtol(zigp_ctx* ctx, double rtol);
  * (e.g. torch tensors) without copying -- the caller keeps them alive. X is (N,D), Y is (N). */
 int zigp_set_data(zigp_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t D);
 int zigp_set_data_device(zigp_ctx* ctx, const double* dX, const double* dY, int64_t N, int32_t D);
+/* Minibatch by row indices: the n rows `rows` of the resident set (repeats allowed) are gathered on the device and become the active
+ * data, rows [0, n), of the calls that follow -- replaces the per-step sample of GPflow's MinibatchData (onoffgpf/OnOffSVGP.py:46-47)
+ * without re-uploading X and Y (8 bytes per row cross the bus instead of 8 (D + 1)).  n = 0: back to the whole resident set;
+ * zigp_set_data / zigp_set_data_device reset it. */
+int zigp_select_rows(zigp_ctx* ctx, const int64_t* rows, int64_t n);
 
 /* One ELBO evaluation ("step" when grads != NULL) over rows [row_begin, row_end) of the resident data.
  * Replaces OnOffSVGP.build_likelihood (onoffgpf/OnOffSVGP.py:107-122) + its gradient (GPflow

@@ -306,3 +306,27 @@ def test_mean_function_shards_sum_to_full(engine):
     for k in ('mean_a', 'mean_b', 'u_fm', 'noise'):
         s = sum(np.asarray(q[2][k], dtype=float) for q in parts)
         assert np.max(np.abs(s - np.asarray(g[k], dtype=float))) <= 1e-9 * max(np.max(np.abs(np.asarray(g[k], dtype=float))), 1e-300), k
+
+
+def test_select_rows_equals_uploading_the_gathered_minibatch(engine):
+    """zigp_select_rows gathers a row-index sample (repeats allowed) of the RESIDENT data on the device -- MinibatchData's per-step sample
+    (onoffgpf/OnOffSVGP.py:46-47) without re-uploading X, Y: same numbers, bit for bit, as uploading X[idx], Y[idx]."""
+    X, Y, p = make_problem(5000, 70, 3, seed=12)
+    engine.set_chunk(2048)
+    engine.set_data(X, Y)
+    full = engine.elbo(p, jitter=1e-6)
+    idx = np.random.RandomState(3).randint(5000, size=1700)
+    engine.select_rows(idx)
+    a = engine.elbo(p, jitter=1e-6, scale=5000 / 1700.0)
+    assert engine.N == 1700
+    engine.select_rows(None)
+    again = engine.elbo(p, jitter=1e-6)
+    engine.set_data(X[idx], Y[idx])
+    b = engine.elbo(p, jitter=1e-6, scale=5000 / 1700.0)
+    assert a[0] == b[0] and a[1] == b[1] and full[0] == again[0]
+    for k in a[2]:
+        assert np.array_equal(np.asarray(a[2][k]), np.asarray(b[2][k])), k
+    engine.set_data(X, Y)
+    with pytest.raises(ValueError):
+        engine.select_rows([0, 5000])
+    engine.set_chunk(32768)

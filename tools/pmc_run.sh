@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 mkdir -p $ROOT/gpurun_out/$TAG
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/gpurun_out/$TAG/$C -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs --profile-steps 0 --no-overlap --rows ${ROWS:-262144} > $ROOT/gpurun_out/$TAG/$C.log 2>&1 || exit 1
+  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/gpurun_out/$TAG/$C -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-pmc --no-cpu-baseline --no-other-configs --profile-steps 0 --no-overlap --rows ${ROWS:-262144} > $ROOT/gpurun_out/$TAG/$C.log 2>&1 || exit 1
 done
 cd $ROOT
 F=$(find gpurun_out/$TAG/FETCH_SIZE -name '*counter_collection.csv' | head -1)

@@ -93,6 +93,9 @@ struct zigp_ctx {
   const double* dX = nullptr; const double* dY = nullptr;
   zigp::DevBuf ownX, ownY;
   int64_t N = 0; int D = 0;
+  // zigp_select_rows: the active data (dX, dY, N) is a gathered batch of the resident set (fullX, fullY, fullN)
+  const double* fullX = nullptr; const double* fullY = nullptr; int64_t fullN = 0;
+  zigp::DevBuf selX, selY, selIdx;
   // dense path state
   zigp::Latent lat[2];
   zigp::DevBuf pw_part;                 // pointwise block partials

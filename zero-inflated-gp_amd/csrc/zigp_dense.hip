@@ -543,7 +543,7 @@ int zigp_destroy(zigp_ctx* c) {
                     &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec, &l.sk};
     for (DevBuf* b : bs) b->release();
   }
-  DevBuf* bs[] = {&c->ownX, &c->ownY, &c->pw_part, &c->out9, &c->scratch, &c->scratch2, &c->packed};
+  DevBuf* bs[] = {&c->ownX, &c->ownY, &c->pw_part, &c->out9, &c->scratch, &c->scratch2, &c->packed, &c->selX, &c->selY, &c->selIdx};
   for (DevBuf* b : bs) b->release();
   if (c->kron && c->kron_free) c->kron_free(c->kron);
   if (c->kronf && c->kronf_free) c->kronf_free(c->kronf);
@@ -678,6 +678,7 @@ int zigp_set_data(zigp_ctx* c, const double* X, const double* Y, int64_t N, int3
   ZIGP_HIP(c, hipMemcpyAsync(c->ownY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   c->dX = c->ownX.p; c->dY = c->ownY.p; c->N = N; c->D = D;
+  c->fullX = c->dX; c->fullY = c->dY; c->fullN = N;
   return ZIGP_OK;
 }
 
@@ -685,6 +686,30 @@ int zigp_set_data_device(zigp_ctx* c, const double* dX, const double* dY, int64_
   if (!c) return ZIGP_EARG;
   if (!dX || !dY || N <= 0 || D <= 0 || D > MAXD) return fail_arg(c, "zigp_set_data_device: bad arguments");
   c->dX = dX; c->dY = dY; c->N = N; c->D = D;
+  c->fullX = dX; c->fullY = dY; c->fullN = N;
+  return ZIGP_OK;
+}
+
+int zigp_select_rows(zigp_ctx* c, const int64_t* rows, int64_t n) {
+  if (!c) return ZIGP_EARG;
+  if (!c->fullX) return fail_arg(c, "zigp_select_rows: no data set (call zigp_set_data first)");
+  if (n < 0 || (n > 0 && !rows)) return fail_arg(c, "zigp_select_rows: bad arguments");
+  if (n == 0) { c->dX = c->fullX; c->dY = c->fullY; c->N = c->fullN; return ZIGP_OK; }   // back to the whole resident set
+  for (int64_t i = 0; i < n; ++i)
+    if (rows[i] < 0 || rows[i] >= c->fullN) return fail_arg(c, "zigp_select_rows: row index out of range");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  ZIGP_TRY(begin_staged_call(c));
+  const int D = c->D;
+  ZIGP_ENSURE(c, c->selX, (size_t)n * D); ZIGP_ENSURE(c, c->selY, (size_t)n); ZIGP_ENSURE(c, c->selIdx, (size_t)n);
+  int64_t* h = (int64_t*)c->pinned.alloc(sizeof(int64_t) * n);
+  if (!h) { c->err = "hipHostMalloc failed for the staging arena"; return ZIGP_EHIP; }
+  memcpy(h, rows, sizeof(int64_t) * n);
+  ZIGP_HIP(c, hipMemcpyAsync(c->selIdx.p, h, sizeof(int64_t) * n, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_gather_rows, dim3(ceil_div(n * (D + 1), 256)), dim3(256), 0, c->stream, c->fullX, c->fullY,
+                     reinterpret_cast<const int64_t*>(c->selIdx.p), n, D, c->selX.p, c->selY.p);
+  ZIGP_HIP(c, hipGetLastError());
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream));   // the staged index block may be reused by the next call
+  c->dX = c->selX.p; c->dY = c->selY.p; c->N = n;
   return ZIGP_OK;
 }
 

@@ -236,11 +236,14 @@ enum { TRI_NONE = 0,
 
 // ---- diagonal tile of the symmetric rank-N update (TRI_C_LOWER, bi == bj: the A and the B operand are the SAME 128 rows) -------------
 // The generic path computes a diagonal tile as three 64 x 64 wave tiles (the fourth wave idles) = 0.75 of a full tile for 0.5625 of
-// useful work, in the time of a full tile.  Here only ONE operand tile is staged per BK step, and the 36 lower 16 x 16 sub-tiles (8 x 8
+// useful work, in the time of a full tile.  Here only ONE operand tile is needed per BK step, and the 36 lower 16 x 16 sub-tiles (8 x 8
 // grid, diagonal included) are dealt out 9 per wave: wave w owns the sub-tile rows w and 7 - w, i.e. w + 1 and 8 - w column sub-tiles.
 // The wave index is a template parameter (the four instantiations sit behind one scalar switch): every loop bound is a compile-time
-// constant.  36 accumulators, 8 A and <= 8 B fragments per k-step: ~120 VGPRs inside a kernel that holds 256 anyway.  The host gives
-// diagonal tiles longer k ranges (fewer split-K slices) so that both kinds of workgroup finish together (tiles_syr2k).
+// constant.  36 accumulators, 8 A and <= 8 B fragments per k-step: ~120 VGPRs inside a kernel that holds ~200 anyway.
+// A ring stage has room for two operand tiles, so a step of this path covers TWO BK slices (the second one in the B slot; the k-scale
+// slices ride in the spare 2 KB behind each image): half the barriers and staging waits per MFMA of the generic path, which is what
+// brings a diagonal tile down to ~0.6 of a full tile's time.  The host gives diagonal tiles k ranges twice as long as the others'
+// (tiles_syr2k): both kinds of workgroup then finish together, and every XCD's tiles stay inside one window of k.
 #ifndef ZIGP_SYRK_DIAG
 #define ZIGP_SYRK_DIAG 1
 #endif
@@ -248,6 +251,8 @@ template <int W, int NSTAGE, bool KSCALE, class Epi>
 __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile& tl, double* lds, int wave, int lane, const Epi& epi) {
   constexpr int WAVES = 4, CHUNKS = Shape<WAVES>::CHUNKS;
   constexpr int R1 = W, R2 = 7 - W, NC1 = W + 1, NC2 = 8 - W;   // this wave's two sub-tile rows and the column sub-tiles 0..NC-1 each needs
+  constexpr int SCALE_OFF = 128 * 16;                            // k-scale slice of an image: behind its 2048 doubles (TILE_DOUBLES = 2304)
+  static_assert(TILE_DOUBLES >= SCALE_OFF + BK, "no room for the k-scale slice behind the operand image");
   const GemmSeg& sg = g.seg[0];
   int ln = lane;
   asm volatile("" : "+v"(ln));
@@ -266,7 +271,8 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
   for (int c = 0; c < NC2; ++c)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc2[0][c][r] = 0.0;
-  const int total = tl.kend - tl.kbeg;
+  const int total = tl.kend - tl.kbeg;          // BK slices of this tile
+  const int nsteps = (total + 1) / 2;           // two slices per step; a last odd slice stands alone
   const uint32_t offA = glds_lane_offset<LAY_KCONTIG, WAVES, false>(sg.lda, wave, ln);
   const int64_t csA = glds_chunk_stride<LAY_KCONTIG, WAVES>(sg.lda);
   const int64_t row0 = (int64_t)tl.bi * BM;
@@ -275,31 +281,29 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
   const char* baseA = (const char*)(sg.A + row0 * sg.lda + kfirst);
   const char* baseS = (const char*)(g.kscale + kfirst);
   const int64_t strideA = kd * BK * 8;
-  auto issue = [&](int it) {
-    double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
-    glds_tile<LAY_KCONTIG, WAVES>(st, baseA + it * strideA, offA, csA, wave);
+  auto issue_slice = [&](double* img, int sl) {   // BK slice `sl` of the tile's k range into the image at img
+    glds_tile<LAY_KCONTIG, WAVES>(img, baseA + sl * strideA, offA, csA, wave);
     if (KSCALE) {
       if (ln < 8)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + kd * it * (BK * 8) + (int64_t)(16 * ln)),
-                                         (__attribute__((address_space(3))) void*)(st + 2 * TILE_DOUBLES), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + kd * sl * (BK * 8) + (int64_t)(16 * ln)),
+                                         (__attribute__((address_space(3))) void*)(img + SCALE_OFF), 16, 0, 0);
     }
   };
-  constexpr int GLDS_PER_STAGE = CHUNKS + (KSCALE ? 1 : 0);
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < total) issue(s);
-  for (int it = 0; it < total; ++it) {
-    if (it + NSTAGE - 2 < total) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (it + NSTAGE - 1 < total) issue(it + NSTAGE - 1);
-    const double* As = lds + (it % NSTAGE) * STAGE_DOUBLES;
+  // every step issues the same number of loads (uniform vmcnt accounting): the missing second slice of an odd tail re-reads the first
+  auto issue = [&](int st_) {
+    double* st = lds + (st_ % NSTAGE) * STAGE_DOUBLES;
+    issue_slice(st, 2 * st_);
+    issue_slice(st + TILE_DOUBLES, 2 * st_ + 1 < total ? 2 * st_ + 1 : 2 * st_);
+  };
+  constexpr int GLDS_PER_STAGE = 2 * (CHUNKS + (KSCALE ? 1 : 0));
+  auto slice_mfma = [&](const double* As) {
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       double bf[NC2], af1[4], af2[4];
 #pragma unroll
       for (int c = 0; c < NC2; ++c) bf[c] = As[b_base[ks] + c * 256];
       if (KSCALE) {
-        const double sc = As[2 * TILE_DOUBLES + ks * 4 + kq];
+        const double sc = As[SCALE_OFF + ks * 4 + kq];
 #pragma unroll
         for (int c = 0; c < NC2; ++c) bf[c] *= sc;
       }
@@ -317,6 +321,17 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc1[0][c][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af1[r], bf[c], acc1[0][c][r], 0, 0, 0);
     }
+  };
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nsteps) issue(s);
+  for (int it = 0; it < nsteps; ++it) {
+    if (it + NSTAGE - 2 < nsteps) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (it + NSTAGE - 1 < nsteps) issue(it + NSTAGE - 1);
+    const double* As = lds + (it % NSTAGE) * STAGE_DOUBLES;
+    slice_mfma(As);
+    if (2 * it + 1 < total) slice_mfma(As + TILE_DOUBLES);
   }
   EpiCtx e;
   e.C = g.C + (int64_t)tl.slice * g.slice_stride; e.ldc = g.ldc; e.alpha = g.alpha; e.lane = lane; e.prow = 0;

@@ -105,45 +105,60 @@ static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, TileList& tl) {
 }
 static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl) { return tiles_trmm(c, true, nbm, nbn, tl); }
 static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl) { return tiles_trmm(c, false, nbm, nbn, tl); }
-// Split-K plan of the symmetric rank-N update.  Off-diagonal tiles are cut into So slices, diagonal tiles (which run the balanced
-// lower-triangle path of zigp_gemm.h: 36 of 64 sub-tile products per step, ~0.7 of a full tile's time with its staging and barriers)
-// into Sd < So slices, so that every workgroup of the single wave of <= 512 resident workgroups finishes at the same time:
-// minimise max(1 / So, 0.72 / Sd) subject to n_off So + n_diag Sd <= 512.  M = 1024: 28 x 15 + 8 x 11 = 508 workgroups (was 36 x 14).
-struct SyrPlan { int So, Sd; int planes() const { return std::max(So, Sd); } };
+// Split-K plan of the symmetric rank-N update.  Off-diagonal tiles are cut into So slices, diagonal tiles (the balanced lower-triangle
+// path of zigp_gemm.h: 36 of 64 sub-tile products per slice, two slices per barrier -- ~0.6 of a full tile's time) into Sd = So / 2
+// slices of twice the length, So a multiple of 16: the k range then falls into 8 windows, one per XCD, each holding So / 8 slices of
+// every off-diagonal tile and Sd / 8 of every diagonal one -- an XCD's workgroups all stream the same eighth of the A1 panel through its
+// L2 (r3: with 15 and 11 slices, unaligned, the launch moved 0.95 GB instead of 0.60; profiles/r03k_pmc_hbm_traffic.json).
+// (n_off + n_diag / 2) So <= 512 resident workgroups: M = 1024: So = 16, Sd = 8, 28 x 16 + 8 x 8 = 512; M = 512: 64 / 32, 6 x 64 + 4 x 32 = 512.
+// A diagonal workgroup runs ~1.2 x as long as an off-diagonal one; the list puts the diagonal tiles first in each XCD's queue, so that
+// each shares its CU with an off-diagonal workgroup and inherits the whole matrix pipe when that one is done.
 // (r3, measured and dropped: the update reading both operands from a transposed copy A1^T written by the A1 epilogue, i.e. on the 8-wave
 // m-contiguous kernel: the update itself 53.9 -> 56.0 TF, but the scattered transposed stores cost the A1 product 10 % -- 60.4 -> 54.3 TF --
 // and the step 9 ms: profiles/r03f_ab_syrk_a1t.log.)
+struct SyrPlan { int So, Sd; int planes() const { return std::max(So, Sd); } };
 static inline SyrPlan syr_plan(int nbm) {
   const int n_off = nbm * (nbm - 1) / 2, n_d = nbm, slots = 512;
-  SyrPlan best{1, 1};
 #if ZIGP_SYRK_DIAG
-  const double diag_cost = 0.72;   // same-box sweep at M = 1024 (profiles/r03g_ab_syrk_plan.log): (So, Sd) = (15, 11) 54.8, (15, 10) 54.7, (15, 9) 53.9, (16, 8) 52.3, (14, 12) 51.4 TF
+  int So = (int)(slots / (n_off + 0.5 * n_d)) / 16 * 16;
+  So = std::max(16, std::min(64, So));
+  while (So > 16 && n_off * So + n_d * (So / 2) > slots) So -= 16;
+  return SyrPlan{So, So / 2};
 #else
-  const double diag_cost = 1.0;
-#endif
-  if (n_off + n_d > slots) return best;
-  double best_t = 1e30;
-  for (int So = 1; So <= 128; ++So) {
-    const int left = slots - n_off * So;
-    if (left < n_d) break;
-    const int Sd = std::min(128, left / n_d);
-    const double t = std::max(n_off ? 1.0 / So : 0.0, diag_cost / Sd);
-    if (t < best_t - 1e-12) { best_t = t; best = SyrPlan{So, Sd}; }
+  int best = 4; double best_eff = 0.0;   // without the diagonal path: smallest S >= 4 whose tile count fills whole waves of the slots to >= 95 %
+  for (int S = 4; S <= 64; ++S) {
+    const int t = (n_off + n_d) * S;
+    const double eff = (double)t / (double)(((t + slots - 1) / slots) * slots);
+    if (eff > best_eff + 1e-12) { best_eff = eff; best = S; }
+    if (eff >= 0.95) { best = S; break; }
   }
-  // no more diagonal slices than needed to stay under the off-diagonal time (fewer planes to clear and sum)
-  while (best.Sd > 1 && n_off && diag_cost / (best.Sd - 1) <= 1.0 / best.So) --best.Sd;
-  return best;
+  return SyrPlan{best, best};
+#endif
 }
-// Lower-triangular output tiles x split-K slices over nk k-steps.  Launch position p runs on XCD p % 8 (observed round-robin
-// dispatch; speed only): XCD x is handed a contiguous run of the k-major tile order, so the tiles that re-read the same
-// column slice of the panels share one L2 instead of eight.
+// Lower-triangular output tiles x split-K slices over nk k-steps.  Launch position p runs on XCD p % 8 (observed round-robin dispatch;
+// speed only): XCD x is handed the tiles whose k range lies in the x-th eighth of the k range (both slice counts multiples of 8), else
+// -- no diagonal path -- a contiguous run of the k-major tile order.
 static int tiles_syr2k(zigp_ctx* c, int nbm, int nk, SyrPlan sp, TileList& tl) {
   return get_tiles(c, "syr:" + std::to_string(nbm) + ":" + std::to_string(nk) + ":" + std::to_string(sp.So) + ":" + std::to_string(sp.Sd), [&](std::vector<GemmTile>& v) {
+    auto entry = [&](int bi, int bj, int s, int S) { return mk_tile(bi, bj, (int)((int64_t)nk * s / S), (int)((int64_t)nk * (s + 1) / S), s); };
+    if (sp.So % 8 == 0 && sp.Sd % 8 == 0) {
+      std::vector<GemmTile> q[8];
+      for (int x = 0; x < 8; ++x) {
+        for (int s = x * sp.Sd / 8; s < (x + 1) * sp.Sd / 8; ++s)
+          for (int bi = 0; bi < nbm; ++bi) q[x].push_back(entry(bi, bi, s, sp.Sd));
+        for (int s = x * sp.So / 8; s < (x + 1) * sp.So / 8; ++s)
+          for (int bi = 0; bi < nbm; ++bi)
+            for (int bj = 0; bj < bi; ++bj) q[x].push_back(entry(bi, bj, s, sp.So));
+      }
+      for (size_t e = 0; e < q[0].size(); ++e)          // all eight queues have the same length
+        for (int x = 0; x < 8; ++x) v.push_back(q[x][e]);
+      return;
+    }
     std::vector<GemmTile> t;
     for (int bi = 0; bi < nbm; ++bi)
       for (int bj = 0; bj <= bi; ++bj) {
         const int S = (bi == bj) ? sp.Sd : sp.So;
-        for (int s = 0; s < S; ++s) t.push_back(mk_tile(bi, bj, (int)((int64_t)nk * s / S), (int)((int64_t)nk * (s + 1) / S), s));
+        for (int s = 0; s < S; ++s) t.push_back(entry(bi, bj, s, S));
       }
     std::stable_sort(t.begin(), t.end(), [](const GemmTile& a, const GemmTile& b) { return a.kbeg < b.kbeg; });
     const int n = (int)t.size(), per = (n + 7) / 8;

@@ -567,6 +567,16 @@ k_dense_pack(DensePackArgs a) {
   if (t == 0) a.out[2 + h] = dv / L.var + pws[2 + h];
 }
 
+// rows `idx` of the resident (X, Y) gathered into a contiguous batch (MinibatchData's per-step sample, onoffgpf/OnOffSVGP.py:46-47)
+__global__ void k_gather_rows(const double* __restrict__ X, const double* __restrict__ Y, const int64_t* __restrict__ idx, int64_t n, int D,
+                              double* __restrict__ Xb, double* __restrict__ Yb) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * (D + 1)) return;
+  const int64_t i = t / (D + 1); const int d = (int)(t - i * (D + 1));
+  const int64_t r = idx[i];
+  if (d < D) Xb[i * D + d] = X[r * D + d]; else Yb[i] = Y[r];
+}
+
 // s2 = s*s
 __global__ void k_square(const double* s, double* s2, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

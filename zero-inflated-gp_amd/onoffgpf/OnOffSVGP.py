@@ -80,14 +80,19 @@ class OnOffSVGP(Parameterized):
         return out
 
     def _load_batch(self):
+        """X and Y go to HBM once; a minibatch (MinibatchData, :46-47) is a row-index sample gathered on the device per step."""
+        if not self._resident:
+            self._engine.set_data(self.Xtrain.value, self.Ytrain.value)
+            self._resident = True
         if self.minibatch_size >= self.num_data:
-            if not self._resident:
-                self._engine.set_data(self.Xtrain.value, self.Ytrain.value)
-                self._resident = True
             return 1.0
-        idx = self._rng.randint(self.num_data, size=self.minibatch_size)   # MinibatchData sampling [GPflow-recall]
-        self._engine.set_data(self.Xtrain.value[idx], self.Ytrain.value[idx])
-        self._resident = False
+        # GPflow 0.4 MinibatchData picks its index manager by the batch fraction [GPflow-recall; not in the reference tree, unverified]:
+        # below one half sampling WITH replacement (rng.randint), from one half up a fresh permutation's head (without replacement)
+        if 2 * self.minibatch_size < self.num_data:
+            idx = self._rng.randint(self.num_data, size=self.minibatch_size)
+        else:
+            idx = self._rng.permutation(self.num_data)[:self.minibatch_size]
+        self._engine.select_rows(idx)
         return float(self.num_data) / float(self.minibatch_size)          # :119-120
 
     def _elbo(self, need_grad):

@@ -67,6 +67,7 @@ SIGNATURES = {
     'zigp_set_chunk': (C.c_int, [C.c_void_p, C.c_int64]),
     'zigp_set_data': (C.c_int, [C.c_void_p, dp, dp, C.c_int64, C.c_int32]),
     'zigp_set_data_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    'zigp_select_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     'zigp_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64,
                             C.c_int32, dp, dp, C.POINTER(zigp_grads)]),
     'zigp_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), dp, C.c_int64, C.c_double, C.c_double, dp]),

@@ -72,6 +72,7 @@ class DenseEngine:
             raise ZigpError('zigp_create failed (rc=%d): no usable HIP device %d' % (rc, device))
         self.device = int(device)
         self.N = 0
+        self._full_N = 0
         self.D = 0
         self._keep = None
 
@@ -133,6 +134,7 @@ class DenseEngine:
             raise ValueError('Y must have N entries')
         _check(self.lib, self.ctx, self.lib.zigp_set_data(self.ctx, ptr(X), ptr(Y), X.shape[0], X.shape[1]))
         self.N, self.D = X.shape
+        self._full_N = self.N
 
     def set_data_device(self, X_t, Y_t):
         """Adopt torch CUDA float64 tensors (no copy); they are kept alive by this object."""
@@ -149,6 +151,18 @@ class DenseEngine:
         self._keep = (X_t, Y_t)
         _check(self.lib, self.ctx, self.lib.zigp_set_data_device(self.ctx, C.c_void_p(X_t.data_ptr()), C.c_void_p(Y_t.data_ptr()), N, D))
         self.N, self.D = N, D
+        self._full_N = N
+
+    def select_rows(self, idx=None):
+        """Minibatch by row indices (repeats allowed): the rows `idx` of the resident data set are gathered on the device and become
+        the active data of the calls that follow (rows 0 .. len(idx)); None / empty: back to the whole resident set."""
+        if idx is None or len(idx) == 0:
+            _check(self.lib, self.ctx, self.lib.zigp_select_rows(self.ctx, None, 0))
+            self.N = self._full_N
+            return
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64))
+        _check(self.lib, self.ctx, self.lib.zigp_select_rows(self.ctx, idx.ctypes.data, idx.size))
+        self.N = int(idx.size)
 
     def elbo(self, p, jitter=1e-6, scale=1.0, g_offset=0.0, rows=None, include_kl=True, need_grad=True):
         """Returns (elbo_data, kl, grads or None); ELBO = elbo_data - kl."""
