@@ -51,6 +51,11 @@ def test_null_context_is_rejected():
     assert lib.zigp_destroy(None) == _lib.ZIGP_EARG
     assert lib.zigp_set_chunk(None, 1024) == _lib.ZIGP_EARG
     assert lib.zigp_last_error(None) == b'null context'
+    assert lib.zigp_get_chunk(None, 1024) == _lib.ZIGP_EARG
+    assert lib.zigp_select_rows(None, None, 0) == _lib.ZIGP_EARG
+    assert lib.zigp_set_pivot_rtol(None, 0.0) == _lib.ZIGP_EARG
+    assert lib.zigp_comm_init(None, 0, 1, None) == _lib.ZIGP_EARG and lib.zigp_comm_destroy(None) == _lib.ZIGP_EARG
+    assert lib.zigp_comm_unique_id(None) == _lib.ZIGP_EARG and lib.zigp_comm_info(None, None, None, None) == _lib.ZIGP_EARG
 
 
 def test_log1pe_transform_roundtrip_and_gradient():

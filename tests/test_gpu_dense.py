@@ -330,3 +330,22 @@ def test_select_rows_equals_uploading_the_gathered_minibatch(engine):
     with pytest.raises(ValueError):
         engine.select_rows([0, 5000])
     engine.set_chunk(32768)
+
+
+def test_chunk_rule_is_reported_by_the_library():
+    """zigp_get_chunk: the rows-per-pass rule lives in the library only (bench.py reads it instead of re-implementing it)"""
+    import zigp
+    e = zigp.DenseEngine(0)
+    try:
+        assert [e.get_chunk(M) for M in (1024, 1000, 512, 256, 128, 50, 2048)] == [32768, 32768, 65536, 131072, 131072, 131072, 32768]
+        e.set_chunk(4096)
+        assert e.get_chunk(1024) == 4096 and e.get_chunk(64) == 4096
+        with pytest.raises(ValueError):
+            e.get_chunk(0)
+        assert e.comm_info() == dict(rank=0, nranks=0, allreduce_calls=0)
+        with pytest.raises(ValueError):
+            e.comm_init(2, 2, b'\0' * 128)          # rank out of range: rejected before anything touches RCCL
+        with pytest.raises(ValueError):
+            e.comm_init(0, 1, b'short')
+    finally:
+        e.close()

@@ -111,6 +111,24 @@ def test_minibatch_scale_and_adam():
                   OnOffLikelihood(), Z, Z.copy(), minibatch_size=100)
     e = [m.compute_log_likelihood() for _ in range(3)]
     assert len(set(e)) == 3                      # different minibatches
+    # the minibatch estimate (row sample gathered on the device, zigp_select_rows; scaled by num_data / batch, OnOffSVGP.py:119-120) is an
+    # unbiased estimate of the full-batch bound: 200 draws average to it within a few standard errors
+    np.random.seed(1)
+    full = OnOffSVGP(X, Y, onoffgpf.kernels.RBF(1, lengthscales=2.), onoffgpf.kernels.RBF(1, lengthscales=2., variance=5.),
+                     OnOffLikelihood(), Z, Z.copy())
+    ref = full.compute_log_likelihood()
+    draws = np.array([m.compute_log_likelihood() for _ in range(200)])
+    se = draws.std() / np.sqrt(len(draws))
+    print('full %.3f, minibatch mean %.3f +- %.3f' % (ref, draws.mean(), se))
+    assert abs(draws.mean() - ref) < 5 * se
+    # from half the data up the sample is the head of a fresh permutation: no repeated rows
+    m2 = OnOffSVGP(X, Y, onoffgpf.kernels.RBF(1, lengthscales=2.), onoffgpf.kernels.RBF(1, lengthscales=2., variance=5.),
+                   OnOffLikelihood(), Z, Z.copy(), minibatch_size=300)
+    seen = []
+    orig = m2._engine.select_rows
+    m2._engine.select_rows = lambda idx: (seen.append(np.array(idx)), orig(idx))[1]
+    m2.compute_log_likelihood()
+    assert len(seen) == 1 and len(np.unique(seen[0])) == 300
     m.optimize(method='adam', maxiter=50, learning_rate=0.01)
     assert np.isfinite(m.compute_log_likelihood())
 
