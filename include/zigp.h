@@ -191,6 +191,9 @@ int zigp_kron_head_predict(zigp_ctx* ctx, const zigp_kron_params* p, int32_t lik
 int zigp_comm_unique_id(void* id /* [ZIGP_COMM_ID_BYTES] */);
 int zigp_comm_init(zigp_ctx* ctx, int32_t rank, int32_t nranks, const void* id);
 int zigp_comm_destroy(zigp_ctx* ctx);
+/* Sum n host doubles over the ranks of the context's communicator, in place (staged through the device): for the few scalars a host loop
+ * wants agreed on (a convergence flag, a timing), and the self-check the Python wrapper runs right after zigp_comm_init. */
+int zigp_comm_allreduce_host(zigp_ctx* ctx, double* inout, int64_t n);
 /* rank / nranks of the context's communicator (nranks = 0: none) and the number of all-reduces issued through it so far */
 int zigp_comm_info(zigp_ctx* ctx, int32_t* rank, int32_t* nranks, int64_t* allreduce_calls);
 

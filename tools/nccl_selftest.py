@@ -38,7 +38,7 @@ ref = dict(dense=eng.elbo(p), dense_value=eng.elbo(p, need_grad=False), dense_no
 assert eng.comm_info()['nranks'] == 0
 sh = ShardedELBO(eng, dist, device='cuda:0')              # backend nccl -> library communicator
 shk = ShardedKronELBO(eng, dist, device='cuda:0')        # same engine: shares the communicator
-assert sh.library_comm and shk.library_comm and eng.comm_info() == dict(rank=0, nranks=1, allreduce_calls=0)
+assert sh.library_comm and shk.library_comm and eng.comm_info() == dict(rank=0, nranks=1, allreduce_calls=1)   # 1: the wrapper's self-check sum
 got = dict(dense=sh.elbo(p), dense_value=eng.elbo(p, need_grad=False), dense_nokl=eng.elbo(p, include_kl=False),
            kron=eng.kron_elbo(pk, Xk, Yk, scale=3.0, f_mu=0.25), kron_value=eng.kron_elbo(pk, Xk, Yk, need_grad=False),
            kron_nokl=eng.kron_elbo(pk, Xk, Yk, include_kl=False), kron_large=shk.kron_elbo(pl, Xl, Yl),
@@ -46,7 +46,7 @@ got = dict(dense=sh.elbo(p), dense_value=eng.elbo(p, need_grad=False), dense_nok
 for k in ref:
     assert same(ref[k], got[k]), k
 n = eng.comm_info()['allreduce_calls']
-assert n == len(ref), n                                    # one all-reduce per step, no more
+assert n == len(ref) + 1, n                                # one all-reduce per step (+ the self-check), no more
 # a non-PD Kuu is reported after the exchange, and the communicator keeps working
 bad = dict(p, Zf=p['Zf'].copy()); bad['Zf'][1] = bad['Zf'][0]
 try:
@@ -56,6 +56,7 @@ except zigp.NotPositiveDefiniteError:
 assert same(eng.elbo(p), ref['dense'])
 t = torch.tensor([1.25], dtype=torch.float64, device='cuda:0'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
 assert float(t.item()) == 1.25
+assert np.array_equal(eng.comm_allreduce([3.0, -1.5]), [3.0, -1.5])      # zigp_comm_allreduce_host: a host vector through the same communicator
 sh.close()
 assert eng.comm_info()['nranks'] == 0 and same(eng.elbo(p), ref['dense'])
 dist.destroy_process_group()

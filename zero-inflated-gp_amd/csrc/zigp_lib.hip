@@ -2,3 +2,4 @@
 // zigp_kernels.h (plain __global__ definitions), so they are compiled together.
 #include "zigp_dense.hip"
 #include "zigp_kron.hip"
+#include "zigp_comm.hip"

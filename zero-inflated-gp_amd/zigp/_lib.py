@@ -83,6 +83,7 @@ SIGNATURES = {
     'zigp_comm_unique_id': (C.c_int, [C.c_void_p]),
     'zigp_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'zigp_comm_destroy': (C.c_int, [C.c_void_p]),
+    'zigp_comm_allreduce_host': (C.c_int, [C.c_void_p, dp, C.c_int64]),
     'zigp_comm_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     'zigp_set_overlap': (C.c_int, [C.c_void_p, C.c_int32]),
     'zigp_set_kron_panels': (C.c_int, [C.c_void_p, C.c_int32]),

@@ -120,6 +120,12 @@ class DenseEngine:
     def comm_destroy(self):
         _check(self.lib, self.ctx, self.lib.zigp_comm_destroy(self.ctx))
 
+    def comm_allreduce(self, vec):
+        """sum a small float64 host vector over the ranks of the library's communicator (returns a new array)"""
+        v = np.array(vec, dtype=np.float64).reshape(-1)
+        _check(self.lib, self.ctx, self.lib.zigp_comm_allreduce_host(self.ctx, ptr(v), v.size))
+        return v
+
     def comm_info(self):
         r, n, k = C.c_int32(0), C.c_int32(0), C.c_int64(0)
         _check(self.lib, self.ctx, self.lib.zigp_comm_info(self.ctx, C.byref(r), C.byref(n), C.byref(k)))

@@ -90,10 +90,36 @@ class _Sharded:
         if self.library_comm:
             info = engine.comm_info()
             if info['nranks'] == 0:
-                obj = [engine.comm_unique_id() if self.rank == 0 else None]
+                # Any failure on the way (RCCL not loadable, communicator not formed, a self-check sum that does not add up) leaves every
+                # rank on the torch.distributed exchange of the packed host vector instead: the decision is itself agreed on by all ranks.
+                ok = 1.0
+                try:
+                    obj = [engine.comm_unique_id() if self.rank == 0 else None]
+                except Exception:
+                    obj, ok = [None], 0.0
                 dist.broadcast_object_list(obj, src=0)
-                engine.comm_init(self.rank, self.world, obj[0])
-                self._owns_comm = True
+                if obj[0] is None:
+                    ok = 0.0
+                else:
+                    try:
+                        engine.comm_init(self.rank, self.world, obj[0])
+                        self._owns_comm = True
+                        chk = engine.comm_allreduce([1.0, float(self.rank)])
+                        if chk[0] != self.world or chk[1] != self.world * (self.world - 1) / 2.0:
+                            ok = 0.0
+                    except Exception:
+                        ok = 0.0
+                import torch
+                flag = torch.tensor([ok], dtype=torch.float64, device=self.device or ('cuda' if dist.get_backend() == 'nccl' else 'cpu'))
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag.item()) != 1.0:
+                    if self._owns_comm:
+                        try:
+                            engine.comm_destroy()
+                        except Exception:
+                            pass
+                    self._owns_comm = False
+                    self.library_comm = False
             elif (info['rank'], info['nranks']) != (self.rank, self.world):       # another wrapper of this engine set it up
                 raise ValueError('engine already has a communicator for rank %d of %d' % (info['rank'], info['nranks']))
 
