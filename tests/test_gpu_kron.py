@@ -267,3 +267,26 @@ def test_kron_tiny_and_ragged_batches(engine):
         ed, kl, g = engine.kron_elbo(p, X, Y, jitter=1e-5)
         e_r, d_r, klf, klg = o.kron_elbo(X, Y, p, 1e-5)
         assert abs(ed - d_r) <= 1e-8 * max(abs(d_r), 1.0) and abs(kl - (klf + klg)) <= 1e-8 * abs(klf + klg)
+
+
+@pytest.mark.parametrize('M0,M1', [(32, 32), (10, 100)])
+def test_kron_stepper_equals_unprepared_call(engine, M0, M1):
+    """DenseEngine.kron_stepper: the fit loop's prepared step (buffers and structs set up once for a fixed model shape) goes through the
+    same entry points as kron_elbo -- same numbers bit for bit, for changing parameter values, host minibatches and resident rows, f_mu."""
+    X, Y, p = make_kron_problem(2500, M0, M1, seed=21)
+    st = engine.kron_stepper(p)
+    engine.set_data(X, Y)
+    rs = np.random.RandomState(0)
+    for it in range(3):
+        q = dict(p, u_fm=p['u_fm'] + 0.01 * it * rs.randn(*p['u_fm'].shape), noise=0.05 + 0.01 * it,
+                 var_g=[p['var_g'][0] * (1 + 0.1 * it), p['var_g'][1]], ell_f=[p['ell_f'][0] * (1 + 0.05 * it), p['ell_f'][1]])
+        for kw in (dict(X=X[:1000], Y=Y[:1000]), dict(rows=(300, 2400)), dict(X=X[:777], Y=Y[:777], f_mu=0.2)):
+            a = engine.kron_elbo(q, jitter=1e-5, scale=3.0, **kw)
+            b = st(q, jitter=1e-5, scale=3.0, **kw)
+            assert a[0] == b[0] and a[1] == b[1] and set(a[2]) == set(b[2]), (it, list(kw))
+            for k in a[2]:
+                va, vb = a[2][k], b[2][k]
+                for x, y in (zip(va, vb) if isinstance(va, list) else ((va, vb),)):
+                    assert np.array_equal(np.asarray(x), np.asarray(y)), (it, k)
+    with pytest.raises(ValueError):
+        st(dict(p, u_fm=np.zeros(3)), X[:10], Y[:10])       # another model shape needs another stepper

@@ -35,6 +35,12 @@ for tag in ('f', 'g'):
 ed, kl = C.c_double(0), C.c_double(0)
 t0 = time.perf_counter()
 for _ in range(n):
-    eng.lib.zigp_kron_elbo(eng.ctx, C.byref(s), ptr(X), ptr(Y), 1000, 1e-5, 105.28, 0.0, 1, C.byref(ed), C.byref(kl), C.byref(gs))
+    eng.lib.zigp_kron_elbo(eng.ctx, C.byref(s), ptr(X), ptr(Y), 1000, 1e-5, 105.28, 0.0, 0.0, 1, C.byref(ed), C.byref(kl), C.byref(gs), None)
 t_c = (time.perf_counter() - t0) / n
 print('minibatch step: python call %.1f us = C call %.1f us + packing %.1f us + result dicts / checks %.1f us' % (t_all * 1e6, t_c * 1e6, t_pack * 1e6, (t_all - t_c - t_pack) * 1e6))
+st = eng.kron_stepper(pk)
+for _ in range(20): st(pk, X, Y, jitter=1e-5, scale=105.28)
+t0 = time.perf_counter()
+for _ in range(n): st(pk, X, Y, jitter=1e-5, scale=105.28)
+t_st = (time.perf_counter() - t0) / n
+print('prepared step (DenseEngine.kron_stepper): %.1f us = C call %.1f us + %.1f us of Python' % (t_st * 1e6, t_c * 1e6, (t_st - t_c) * 1e6))

@@ -32,6 +32,7 @@ def onoff(Xtrain, Ytrain, Xtest, Ytest, dir, num_iter=50000, num_inducing_f=(10,
     scale = float(num_data) / float(num_minibatch)                                   # :311
     logger.info('*******  started optimization at ' + time.strftime('%Y%m%d-%H%M') + ' *******')
     resident = None     # generation of the epoch order whose arrays are resident in HBM
+    step = eng.kron_stepper(engine_params(pset))   # one model shape for the whole fit: buffers and structs prepared once
     for i in range(num_iter):                                                        # :375-431
         t0 = time.time()
         # DataSet.next_batch shuffles once per epoch and then slices (onofftf/main.py:98-133): the permuted epoch goes to the GPU once,
@@ -42,9 +43,9 @@ def onoff(Xtrain, Ytrain, Xtest, Ytest, dir, num_iter=50000, num_inducing_f=(10,
                 if gen != resident:
                     eng.set_data(train_data.xtrain, train_data.ytrain)
                     resident = gen
-                ed, kl, g = eng.kron_elbo(engine_params(pset), rows=(lo, hi), jitter=jitter_level, scale=scale)
+                ed, kl, g = step(engine_params(pset), rows=(lo, hi), jitter=jitter_level, scale=scale)
             else:
-                ed, kl, g = eng.kron_elbo(engine_params(pset), wrap[0], wrap[1], jitter=jitter_level, scale=scale)
+                ed, kl, g = step(engine_params(pset), wrap[0], wrap[1], jitter=jitter_level, scale=scale)
             opt.step(named_grads(g))                                                 # minimises cost = -(var_exp*scale - kl), :318
             if history is not None:
                 history.append(-(ed - kl))

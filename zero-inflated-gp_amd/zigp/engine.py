@@ -63,6 +63,80 @@ def _scalar(v):
     return float(v) if isinstance(v, (float, int)) else float(np.asarray(v).reshape(-1)[0])
 
 
+class KronStepper:
+    """see DenseEngine.kron_stepper"""
+    _ARR = (('Z', 0), ('Z', 1), ('ell_', 0), ('ell_', 1))
+
+    def __init__(self, engine, p):
+        self.eng = engine
+        s, keep, dims = engine._pack_kron(p)            # private copies below: the caller's arrays may be views that change or go away
+        self.dims = dims
+        self.par = {}
+        self.s = _lib.zigp_kron_params()
+        self.gs = _lib.zigp_kron_grads()
+        sizes = []
+        for tag in ('f', 'g'):
+            Z0, Z1, l0, l1, um, us = keep[tag]
+            self.par[tag] = [np.array(a, dtype=np.float64, order='C', copy=True) for a in (Z0, Z1, l0, l1, um, us)]
+            sizes += [a.size for a in self.par[tag]]
+        self.flat = np.zeros(sum(sizes))
+        self.out = {}
+        o = 0
+        for tag in ('f', 'g'):
+            Z0, Z1, l0, l1, um, us = self.par[tag]
+            setattr(self.s, 'M0' + tag, Z0.shape[0]); setattr(self.s, 'M1' + tag, Z1.shape[0])
+            for name, a in (('Z0', Z0), ('Z1', Z1), ('ell0', l0), ('ell1', l1)):
+                setattr(self.s, name + tag, ptr(a))
+            setattr(self.s, 'u_%sm' % tag, ptr(um)); setattr(self.s, 'u_%ss_sqrt' % tag, ptr(us))
+            views = []
+            for a in self.par[tag]:
+                views.append(self.flat[o:o + a.size].reshape(a.shape)); o += a.size
+            for name, v in zip(('Z0', 'Z1', 'ell0', 'ell1'), views[:4]):
+                setattr(self.gs, name + tag, ptr(v))
+            setattr(self.gs, 'u_%sm' % tag, ptr(views[4])); setattr(self.gs, 'u_%ss_sqrt' % tag, ptr(views[5]))
+            self.out['Z' + tag] = [views[0], views[1]]
+            self.out['ell_' + tag] = [views[2], views[3]]
+            self.out['u_%sm' % tag] = views[4]
+            self.out['u_%ss_sqrt' % tag] = views[5]
+        self.s.D0, self.s.D1 = dims
+        self._ed, self._kl, self._dmu = C.c_double(0), C.c_double(0), C.c_double(0)
+        self._sref, self._gref = C.byref(self.s), C.byref(self.gs)
+        self._edref, self._klref, self._dmuref = C.byref(self._ed), C.byref(self._kl), C.byref(self._dmu)
+
+    def __call__(self, p, X=None, Y=None, rows=None, jitter=1e-5, scale=1.0, g_offset=0.0, include_kl=True, f_mu=None):
+        s, copyto = self.s, np.copyto
+        for tag in ('f', 'g'):
+            b = self.par[tag]
+            Z, ell, var = p['Z' + tag], p['ell_' + tag], p['var_' + tag]
+            copyto(b[0], Z[0]); copyto(b[1], Z[1])
+            copyto(b[2], np.reshape(ell[0], -1)); copyto(b[3], np.reshape(ell[1], -1))      # a scalar lengthscale broadcasts over the factor's columns
+            copyto(b[4], np.reshape(p['u_%sm' % tag], -1)); copyto(b[5], np.reshape(p['u_%ss_sqrt' % tag], -1))
+            setattr(s, 'var0' + tag, _scalar(var[0])); setattr(s, 'var1' + tag, _scalar(var[1]))
+        s.noise = _scalar(p.get('noise', 1.0))
+        fmu = 0.0 if f_mu is None else _scalar(f_mu)
+        eng = self.eng
+        if rows is None:
+            X = as_f64(X)
+            Y = as_f64(Y).reshape(-1)
+            if X.ndim != 2 or X.shape[1] != self.dims[0] + self.dims[1] or Y.size != X.shape[0]:
+                raise ValueError('X must be (N,%d) and Y have N entries' % (self.dims[0] + self.dims[1]))
+            rc = eng.lib.zigp_kron_elbo(eng.ctx, self._sref, ptr(X), ptr(Y), X.shape[0], float(jitter), float(scale), float(g_offset), fmu,
+                                        1 if include_kl else 0, self._edref, self._klref, self._gref, self._dmuref)
+        else:
+            rc = eng.lib.zigp_kron_elbo_rows(eng.ctx, self._sref, int(rows[0]), int(rows[1]), float(jitter), float(scale), float(g_offset), fmu,
+                                             1 if include_kl else 0, self._edref, self._klref, self._gref, self._dmuref)
+        _check(eng.lib, eng.ctx, rc)
+        gs, out = self.gs, self.out
+        out['noise'] = gs.noise
+        out['var_f'] = [gs.var0f, gs.var1f]
+        out['var_g'] = [gs.var0g, gs.var1g]
+        if f_mu is not None:
+            out['f_mu'] = self._dmu.value
+        else:
+            out.pop('f_mu', None)
+        return self._ed.value, self._kl.value, out
+
+
 class DenseEngine:
     def __init__(self, device=0):
         self.lib = _lib.load()
@@ -332,6 +406,12 @@ class DenseEngine:
                 out['u_%sm' % tag] = a['um']
                 out['u_%ss_sqrt' % tag] = a['us']
         return ed.value, kl.value, out
+
+    def kron_stepper(self, p):
+        """A prepared Kronecker step for a FIXED model shape (the training loop: scripts/onoff.py:375-431 calls sess.run on one graph 50 000
+        times): parameter buffers, the ctypes structs and the gradient arrays are set up once; a call copies the new parameter values in
+        and returns views of its own gradient buffer (valid until the next call).  Same entry points, same numbers as kron_elbo."""
+        return KronStepper(self, p)
 
     def kron_predict(self, p, Xnew, jitter=1e-6, g_offset=0.0, f_mu=None):
         """(9,N) in the order of build_predict (scripts/onoff.py:184); onofftf/onoffpred.py uses jitter 1e-6, g_offset -1."""
