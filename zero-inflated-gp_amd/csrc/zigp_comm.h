@@ -18,29 +18,31 @@ struct RcclApi {
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
-inline RcclApi* rccl_api(std::string* err) {
-  static RcclApi api;
-  static bool tried = false;
-  if (tried) {
-    if (!api.handle && err) *err = "librccl.so.1 could not be loaded";
-    return api.handle ? &api : nullptr;
-  }
-  tried = true;
+struct RcclLoad { RcclApi api; std::string err; };
+inline RcclLoad rccl_load() {
+  RcclLoad r;
   void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) { if (err) *err = std::string("dlopen(librccl.so.1) failed: ") + dlerror(); return nullptr; }
+  if (!h) { const char* e = dlerror(); r.err = std::string("dlopen(librccl.so.1) failed: ") + (e ? e : "unknown error"); return r; }
+  RcclApi& api = r.api;
   api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
   api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
   if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy || !api.GetErrorString) {
-    if (err) *err = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy / ncclGetErrorString";
+    r.err = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy / ncclGetErrorString";
     dlclose(h);
-    return nullptr;
+    return r;
   }
   api.handle = h;
-  return &api;
+  return r;
+}
+// loaded once per process (function-local static: initialised exactly once also when contexts live on several threads)
+inline RcclApi* rccl_api(std::string* err) {
+  static RcclLoad l = rccl_load();
+  if (!l.api.handle) { if (err) *err = l.err; return nullptr; }
+  return &l.api;
 }
 
 inline int fail_comm(zigp_ctx* c, RcclApi* api, const char* what, ncclResult_t r) {
