@@ -110,9 +110,10 @@ int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, i
 int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
   const int Mp = lt.Mp, nbm = Mp / BM, nbn = (int)(Nc / BN);
   const int np = Mp / 32;   // allocated partial rows per fused column sum (a kernel writes one per wave tile: 64 or 32 rows)
-  TileList tl, tu;
+  TileList tl, tu, tu_lpt;
   ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, tl));
   ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu));
+  ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu_lpt, false));   // J': its epilogue loads an A2 tile, which the lockstep of the paired order makes coincide
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {
     ProfScope ps(c, PC_GEMM_A1, fl);   // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
@@ -139,7 +140,7 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
     }
     {
       ProfScope ps(c, PC_GEMM_J, fl);   // J' = W^T H - A2
-      ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.H.p, Nc, lt.Jp.p, Nc), EpiSubLoad{lt.A2.p})));
+      ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu_lpt, mk_args(lt.W.p, Mp, lt.H.p, Nc, lt.Jp.p, Nc), EpiSubLoad{lt.A2.p})));
     }
   }
   return 0;

@@ -89,22 +89,53 @@ static inline GemmArgs mk_args(const double* A, int64_t lda, const double* B, in
 // tile lists
 // ------------------------------------------------------------------------------------------------
 // Triangular products C(Mp x Nc) = T * B.  Row block bi of a lower-triangular T needs the k blocks [0, bi], of an upper-triangular
-// one (W^T) the k blocks [bi, nbm).
-// One tile per workgroup, longest tiles first (LPT), tiles of one column panel on one XCD (launch position p runs on XCD p % 8).
-// PMC: the B panel is fetched from HBM once per row block (1.18 GB per launch at M = 1024, Nc = 32768 for 0.27 GB of operand) -- the
-// tiles of a panel start at different times, so that XCD's L2 never sees them together.  Orders that make them share (a short and a
-// long tile of a panel paired per workgroup and walking k in lockstep: 2.2x fewer bytes, profiles/r01f_*; the tiles of a panel adjacent
-// in one XCD's queue) were 1-2 % / 7-22 % SLOWER per step: HBM traffic is not what limits these kernels.
-static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, TileList& tl) {
+// one (W^T) the k blocks [bi, nbm).  Two tile orders:
+// LPT (paired = false): one tile per workgroup, longest tiles first, tiles of one column panel on one XCD (launch position p runs on
+//   XCD p % 8).  PMC: the B panel is fetched once per row block (1.45-1.5 GB per launch at M = 1024, Nc = 32768 for 0.54 GB of operand
+//   and result) -- the tiles of a panel start at different times, so that XCD's L2 never sees them together.
+// paired = true: work unit = one workgroup = two tiles of the same column panel, a short one (u + 1 k blocks) and its complement
+//   (nbm - u), so every unit runs nbm + 1 k blocks; the units of a panel are consecutive entries of one XCD's queue and walk k in
+//   lockstep (lower: short tiles ascend from k block 0, long tiles descend so that block-step t reads k block nbm - t in every unit;
+//   upper: the mirror image): at any time the four units of a panel read at most two different slabs of it.  PMC: 2.2x fewer bytes.
+//   r3, same-box A/B on the 8-wave kernels (profiles/r03p_ab_paired.log): A1 / A2 / H at the LPT rate (60.4 / 60.4 / 61.1 vs 60.5 / 59.9 /
+//   61.1 TF), J' -3 % (its epilogue loads an A2 tile: with equal-length units all epilogues of a wave of workgroups coincide) -- so
+//   A1, A2 and H take the paired order and J' stays LPT.  (Round 1 had the 4-wave kernels 1-2 % slower in every paired variant.)
+static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, bool paired, TileList& tl) {
   const int kb = BM / BK;
-  const std::string key = std::string(lower ? "trl:" : "tru:") + std::to_string(nbm) + ":" + std::to_string(nbn);
+  const std::string key = std::string(lower ? "trl:" : "tru:") + std::to_string(nbm) + ":" + std::to_string(nbn) + (paired ? ":p" : ":l");
+  if (!paired)
+    return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
+      if (lower) { for (int bi = nbm - 1; bi >= 0; --bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, (bi + 1) * kb)); }
+      else { for (int bi = 0; bi < nbm; ++bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * kb, nbm * kb)); }
+    }, tl, 1);
   return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
-    if (lower) { for (int bi = nbm - 1; bi >= 0; --bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, (bi + 1) * kb)); }
-    else { for (int bi = 0; bi < nbm; ++bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * kb, nbm * kb)); }
-  }, tl, 1);
+    const int U = (nbm + 1) / 2;
+    auto tile = [&](int bi, int bj, int dir) {
+      GemmTile t = lower ? mk_tile(bi, bj, 0, (bi + 1) * kb) : mk_tile(bi, bj, bi * kb, nbm * kb);
+      t.kdir = dir;
+      return t;
+    };
+    std::vector<GemmTile> q[8];   // per-XCD queues of units (2 entries each)
+    for (int bj = 0; bj < nbn; ++bj)
+      for (int u = 0; u < U; ++u) {
+        const int lo = u, hi = nbm - 1 - u;                 // lo has the short k range for lower, hi for upper
+        std::vector<GemmTile>& dst = q[bj % 8];
+        if (lo == hi) { dst.push_back(tile(lo, bj, lower ? -1 : 1)); dst.push_back(mk_tile(0, 0, 0, 0)); continue; }
+        if (lower) { dst.push_back(tile(lo, bj, 1)); dst.push_back(tile(hi, bj, -1)); }
+        else { dst.push_back(tile(hi, bj, -1)); dst.push_back(tile(lo, bj, 1)); }
+      }
+    size_t longest = 0;
+    for (int x = 0; x < 8; ++x) longest = std::max(longest, q[x].size());
+    for (size_t e0 = 0; e0 < longest; e0 += 2)               // launch position p = 8 * (e0 / 2) + x  ->  XCD x
+      for (int x = 0; x < 8; ++x)
+        for (int e = 0; e < 2; ++e) v.push_back(e0 + e < q[x].size() ? q[x][e0 + e] : mk_tile(0, 0, 0, 0));
+  }, tl, 2);
 }
-static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl) { return tiles_trmm(c, true, nbm, nbn, tl); }
-static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl) { return tiles_trmm(c, false, nbm, nbn, tl); }
+#ifndef ZIGP_TRMM_PAIRED
+#define ZIGP_TRMM_PAIRED 1
+#endif
+static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired = ZIGP_TRMM_PAIRED != 0) { return tiles_trmm(c, true, nbm, nbn, paired, tl); }
+static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired = ZIGP_TRMM_PAIRED != 0) { return tiles_trmm(c, false, nbm, nbn, paired, tl); }
 // Split-K plan of the symmetric rank-N update.  Off-diagonal tiles are cut into So slices, diagonal tiles (the balanced lower-triangle
 // path of zigp_gemm.h: 36 of 64 sub-tile products per slice, two slices per barrier -- ~0.6 of a full tile's time) into Sd = So / 2
 // slices of twice the length, So a multiple of 16: the k range then falls into 8 windows, one per XCD, each holding So / 8 slices of
