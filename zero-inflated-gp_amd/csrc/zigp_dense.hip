@@ -111,8 +111,9 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
   const int Mp = lt.Mp, nbm = Mp / BM, nbn = (int)(Nc / BN);
   const int np = Mp / 32;   // allocated partial rows per fused column sum (a kernel writes one per wave tile: 64 or 32 rows)
   TileList tl, tu, tu_lpt;
-  ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, tl));
-  ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu));
+  const bool paired = trmm_paired_pays(nbm, nbn);
+  ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, tl, paired));
+  ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu, paired));
   ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu_lpt, false));   // J': its epilogue loads an A2 tile, which the lockstep of the paired order makes coincide
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {

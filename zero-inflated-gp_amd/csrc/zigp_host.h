@@ -134,8 +134,17 @@ static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, bool paired, Ti
 #ifndef ZIGP_TRMM_PAIRED
 #define ZIGP_TRMM_PAIRED 1
 #endif
-static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired = ZIGP_TRMM_PAIRED != 0) { return tiles_trmm(c, true, nbm, nbn, paired, tl); }
-static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired = ZIGP_TRMM_PAIRED != 0) { return tiles_trmm(c, false, nbm, nbn, paired, tl); }
+// The paired order has nbn * ceil(nbm / 2) units of EQUAL length: it only pays where they fill whole waves of the 512 resident
+// workgroups (cfg3: 256 panels x 4 units = 2 waves exactly; cfg2: 392 x 2 = 784 units would leave the second wave 47 % empty, and so
+// would the short last chunk of cfg3) -- otherwise LPT, whose tiles of mixed length pack the tail.
+static inline bool trmm_paired_pays(int nbm, int nbn) {
+  if (!ZIGP_TRMM_PAIRED) return false;
+  const int units = nbn * ((nbm + 1) / 2), slots = 512;
+  const int waves = (units + slots - 1) / slots;
+  return units >= slots && (double)units / ((double)waves * slots) >= 0.95;
+}
+static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired) { return tiles_trmm(c, true, nbm, nbn, paired, tl); }
+static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired) { return tiles_trmm(c, false, nbm, nbn, paired, tl); }
 // Split-K plan of the symmetric rank-N update.  Off-diagonal tiles are cut into So slices, diagonal tiles (the balanced lower-triangle
 // path of zigp_gemm.h: 36 of 64 sub-tile products per slice, two slices per barrier -- ~0.6 of a full tile's time) into Sd = So / 2
 // slices of twice the length, So a multiple of 16: the k range then falls into 8 windows, one per XCD, each holding So / 8 slices of
