@@ -198,6 +198,73 @@ def _gloo_kron_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+class _FlakyCommEngine(_OracleShardEngine):
+    """engine double whose library communicator cannot be formed on ONE rank (what a broken RCCL set-up on a node would look like)"""
+
+    def __init__(self, X, Y, rank, mode):
+        super().__init__(X, Y)
+        self.rank, self.mode, self.destroyed, self.inited = rank, mode, 0, 0
+
+    def comm_info(self):
+        return dict(rank=0, nranks=0, allreduce_calls=0)
+
+    def comm_unique_id(self):
+        return b'\1' * 128
+
+    def comm_init(self, rank, nranks, uid):
+        self.inited += 1
+        if self.mode == 'init' and rank == 1:
+            raise RuntimeError('RCCL error in ncclCommInitRank: unhandled system error')
+
+    def comm_allreduce(self, vec):
+        if self.mode == 'sum' and self.rank == 0:
+            return np.array([1.0, 0.0])          # a sum that does not add up on one rank
+        return np.array([2.0, 1.0])
+
+    def comm_destroy(self):
+        self.destroyed += 1
+
+
+def _gloo_fallback_worker(rank, world, port, mode, q):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from zigp.parallel import ShardedELBO, shard_bounds
+    from conftest import make_problem as mp_
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    X, Y, p = mp_(120, 6, 2, seed=3, ell=0.5)
+    lo, hi = shard_bounds(X.shape[0], world, rank)
+    eng = _FlakyCommEngine(X[lo:hi], Y[lo:hi], rank, mode)
+    sh = ShardedELBO(eng, dist, library_comm=True)          # ask for the library exchange; it cannot be set up on every rank
+    ed, kl, g = sh.elbo(p, jitter=1e-6)
+    q.put((rank, sh.library_comm, eng.inited, eng.destroyed, ed, kl))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['init', 'sum'])
+def test_library_exchange_failure_on_one_rank_makes_every_rank_fall_back(mode):
+    """If the library communicator cannot be formed (or its self-check sum is wrong) on ANY rank, ALL ranks agree to use the
+    torch.distributed exchange of the packed host vector instead, tear down what they had set up, and still return the right sums."""
+    import torch.multiprocessing as mp
+    import zigp_oracle_torch as ot
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_fallback_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    X, Y, p = make_problem(120, 6, 2, seed=3, ell=0.5)
+    e1, d1, kl1, g1 = ot.elbo_and_grad(X, Y, p, 1e-6)
+    for rank, lib_comm, inited, destroyed, ed, kl in res:
+        assert lib_comm is False and inited == 1
+        assert destroyed == (0 if (mode == 'init' and rank == 1) else 1)      # whoever got a communicator gave it back
+        assert abs(ed - d1) < 1e-10 * abs(d1) and abs(kl - kl1) < 1e-12 * abs(kl1)
+
+
 def test_data_parallel_kronecker_gloo_world2_equals_single_process():
     """The Kronecker step (cfg5) sharded over rows: 2 gloo ranks, ragged shards, f and g on different grids; KL counted once."""
     import torch.multiprocessing as mp
