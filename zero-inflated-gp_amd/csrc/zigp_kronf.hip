@@ -943,8 +943,9 @@ constexpr int KF_KROW_W = 2 + 2 * MAXD;
 // Fixed-order sums of the point-wise block partials -> pws[0..KPW_ACC): the result block of a step has a size that depends on the
 // inducing grid only (never on the shard), so a data-parallel run can sum it over ranks in place (comm_allreduce).
 __global__ void __launch_bounds__(256)
-k_kron_pw_reduce(const double* __restrict__ acc, int blocks, double* __restrict__ pws) {
+k_kron_pw_reduce(const double* __restrict__ acc, int blocks, double kl_counted, double* __restrict__ pws) {
   __shared__ double sh[4];
+  if (threadIdx.x == 0) pws[7] = kl_counted;   // 1 on the rank(s) that count the KL: summed over ranks like everything else
 #pragma unroll
   for (int q = 0; q < KPW_ACC; ++q) {
     double v = 0.0;
@@ -1142,7 +1143,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   }
   if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
   else hipLaunchKernelGGL(k_kron_head_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
-  hipLaunchKernelGGL(k_kron_pw_reduce, dim3(1), dim3(256), 0, c->stream, d_pwacc, pw_blocks, ks.res.p + RES_PWS);
+  hipLaunchKernelGGL(k_kron_pw_reduce, dim3(1), dim3(256), 0, c->stream, d_pwacc, pw_blocks, include_kl ? 1.0 : 0.0, ks.res.p + RES_PWS);
   ZIGP_HIP(c, hipGetLastError());
   if (need_grad) {
     const int waves = std::min(ka.ntiles, 1024 / nlat);   // one wave per SIMD of the chip: the kernels hold ~400-500 registers per lane
@@ -1244,12 +1245,15 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   const double s_ve = pws[0], s_dn = pws[1], s_gv[2] = {pws[2], pws[3]};
   if (elbo_data) *elbo_data = s_ve;
   if (d_offset) *d_offset = pws[4];
+  // KL from its five scalars; in a data-parallel run they are the sums over the ranks that count it (pws[7] of them: one, by the
+  // contract of zigp_comm_init), and every rank returns the same value
   double klsum = 0.0;
-  if (include_kl) {
+  const double kl_ranks = pws[7];
+  if (kl_ranks > 0.0) {
     for (int h = 0; h < nlat; ++h) {
       const double* v = hres + (size_t)h * RES_SIZE + RES_KLV;
       const int M0 = hl[h].M[0], M1 = hl[h].M[1];
-      klsum += 0.5 * (v[0] - (double)M0 * M1 - v[1] + v[2] + (double)M1 * v[3] + (double)M0 * v[4]);
+      klsum += 0.5 * (v[0] - kl_ranks * (double)M0 * M1 - v[1] + v[2] + (double)M1 * v[3] + (double)M0 * v[4]);
     }
   }
   if (kl) *kl = klsum;
