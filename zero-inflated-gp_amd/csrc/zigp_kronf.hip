@@ -111,28 +111,99 @@ __device__ __forceinline__ void kf_frag_mm(double (&out)[4 * NBA], const double*
   }
 }
 
+// exp(y) of B values at once, y <= 0.  These are the steps of the device library's exp (same constants, same operations in the same
+// order: the results are bit-identical to exp()), written ACROSS the values: sixteen calls of exp() in a row compile to sixteen
+// chains of ~16 dependent fp64 operations, one after the other (the kernels around this are at their register limit and the scheduler
+// orders for pressure).  Measured with in-kernel stamps on the two K tiles of a 32 x 32 grid: 8.0 k -> 7.3 k cycles from this alone
+// (a dependent v_fma_f64 issues every ~5 cycles, so the chains cost less than they look); the branches below were the larger part.
+template <int B>
+__device__ __forceinline__ void kf_exp_neg(double (&y)[B]) {
+  const double LOG2E = __longlong_as_double(0x3ff71547652b82feLL);
+  const double NLN2_HI = __longlong_as_double(0xbfe62e42fefa39efLL), NLN2_LO = __longlong_as_double(0xbc7abc9e3b39803fLL);
+  const double C11 = __longlong_as_double(0x3e5ade156a5dcb37LL), C10 = __longlong_as_double(0x3e928af3fca7ab0cLL);
+  const double CJ[8] = {__longlong_as_double(0x3ec71dee623fde64LL), __longlong_as_double(0x3efa01997c89e6b0LL), __longlong_as_double(0x3f2a01a014761f6eLL),
+                        __longlong_as_double(0x3f56c16c1852b7b0LL), __longlong_as_double(0x3f81111111122322LL), __longlong_as_double(0x3fa55555555502a1LL),
+                        __longlong_as_double(0x3fc5555555555511LL), __longlong_as_double(0x3fe000000000000bLL)};
+  double k[B], r[B], p[B];
+#pragma unroll
+  for (int i = 0; i < B; ++i) k[i] = __builtin_rint(y[i] * LOG2E);
+#pragma unroll
+  for (int i = 0; i < B; ++i) r[i] = fma(NLN2_HI, k[i], y[i]);
+#pragma unroll
+  for (int i = 0; i < B; ++i) r[i] = fma(NLN2_LO, k[i], r[i]);
+#pragma unroll
+  for (int i = 0; i < B; ++i) p[i] = fma(C11, r[i], C10);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < B; ++i) p[i] = fma(r[i], p[i], CJ[j]);
+#pragma unroll
+  for (int i = 0; i < B; ++i) p[i] = fma(r[i], p[i], 1.0);
+#pragma unroll
+  for (int i = 0; i < B; ++i) p[i] = fma(r[i], p[i], 1.0);
+#pragma unroll
+  for (int i = 0; i < B; ++i) {
+    const double e = ldexp(p[i], (int)k[i]);
+    y[i] = !(-1075.0 > y[i]) ? e : 0.0;      // below: 2^k is out of range of the conversion; exp underflows long before
+  }
+}
+
+// -0.5 |z_m / ell - x / ell|^2 for the B rows m = 4 (q0 + i) + g of a batch; DD: the input dimension at compile time, 0: runtime f.D
+template <int DD, int B>
+__device__ __forceinline__ void kf_r2_batch(double (&y)[B], const KfFac& f, const double* zs, const double (&xs)[MAXD], int q0, int g, int mlast) {
+  const int D = DD ? DD : f.D;
+#pragma unroll
+  for (int i = 0; i < B; ++i) {
+    const int m = min(4 * (q0 + i) + g, mlast);
+    double r2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < (DD ? DD : MAXD); ++d)
+      if (d < D) { const double t = zs[m * D + d] - xs[d]; r2 = fma(t, t, r2); }
+    y[i] = -0.5 * r2;
+  }
+}
 // K_p tile of this wave: K[q] = k_p(z_{4q+g}, x_n) for the lane's point n, 0 for padding rows / points   (kern.K(Z_p, xnew), :199-201).
 // zs = Z_p / ell (LDS copy in the small-grid kernels).  The per-lane conditions (padding row, padding point) are SELECTS, not
 // branches: with a branch around each row the 16 loads of z and the 16 exp calls of a tile ran one after the other, each behind
 // its own memory round trip (in-kernel stamps: 21 k cycles for a forward tile whose MFMAs take 4.4 k).
-template <int Q>
+// The input dimension of a factor is a kernel argument (wave-uniform).  With `if (d < f.D)` around every term the compiler emits a
+// scalar branch per (row, dimension) and waits for each LDS read of z behind its own branch -- 140 branches and 32 serialized LDS
+// round trips per pair of K tiles, more than half of the 8.0 k cycles the stamps showed.  SPEC: ONE switch per batch of 8 rows picks a
+// straight-line body for D = 1, 2, 3 (the reference's factors are space (2) x time (1), scripts/onoff.py:52-53); larger D loops.
+// The kernels with runtime block counts keep the loop form (!SPEC): they are at the register limit and the switch made them spill.
+template <int Q, bool SPEC>
 __device__ __forceinline__ void kf_ktile(double (&K)[Q], const KfFac& f, int nb, const double* zs, const double* __restrict__ xrow, bool valid, int g) {
   double xs[MAXD];
 #pragma unroll
-  for (int d = 0; d < MAXD; ++d) xs[d] = (d < f.D) ? xrow[f.col0 + d] * f.inv_ell[d] : 0.0;
+  for (int d = 0; d < MAXD; ++d) xs[d] = 0.0;
+  if (SPEC && f.D == 1) xs[0] = xrow[f.col0] * f.inv_ell[0];
+  else if (SPEC && f.D == 2) { xs[0] = xrow[f.col0] * f.inv_ell[0]; xs[1] = xrow[f.col0 + 1] * f.inv_ell[1]; }
+  else {
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    double v = 0.0;
-    if (q < 4 * nb) {                         // wave-uniform (compile-time in the EXACT kernels)
-      const int m = 4 * q + g;
-      double r2 = 0.0;
+    for (int d = 0; d < MAXD; ++d) xs[d] = (d < f.D) ? xrow[f.col0 + d] * f.inv_ell[d] : 0.0;
+  }
+  constexpr int B = Q < 8 ? Q : 8;
+  const int mlast = 16 * nb - 1;             // zs holds 16 nb rows: blocks beyond nb (runtime block counts) read its last row and are zeroed below
 #pragma unroll
-      for (int d = 0; d < MAXD; ++d)
-        if (d < f.D) { const double t = zs[m * f.D + d] - xs[d]; r2 = fma(t, t, r2); }
-      const double e = f.var * exp(-0.5 * r2);
-      v = (m < f.M && valid) ? e : 0.0;
+  for (int q0 = 0; q0 < Q; q0 += B) {
+    double y[B];
+    if (SPEC) {
+      switch (f.D) {
+        case 1: kf_r2_batch<1, B>(y, f, zs, xs, q0, g, mlast); break;
+        case 2: kf_r2_batch<2, B>(y, f, zs, xs, q0, g, mlast); break;
+        case 3: kf_r2_batch<3, B>(y, f, zs, xs, q0, g, mlast); break;
+        default: kf_r2_batch<0, B>(y, f, zs, xs, q0, g, mlast);
+      }
+    } else {
+      kf_r2_batch<0, B>(y, f, zs, xs, q0, g, mlast);
     }
-    K[q] = v;
+    kf_exp_neg<B>(y);
+#pragma unroll
+    for (int i = 0; i < B; ++i)
+      if (q0 + i < Q) {
+        const int m = 4 * (q0 + i) + g;
+        K[q0 + i] = (m < f.M && m <= mlast && valid) ? f.var * y[i] : 0.0;
+      }
   }
 }
 
@@ -172,8 +243,8 @@ __device__ __forceinline__ void kf_forward_tile(KfTile<NB0, NB1>& t, const KfLat
                                                 int g, int slot) {
   const KfFac &f0 = L.f[0], &f1 = L.f[1];
   const int nb0 = EXACT ? NB0 : f0.nb, nb1 = EXACT ? NB1 : f1.nb;
-  kf_ktile<4 * NB0>(t.K0, f0, nb0, F.Z0, xrow, valid, g);
-  kf_ktile<4 * NB1>(t.K1, f1, nb1, F.Z1, xrow, valid, g);
+  kf_ktile<4 * NB0, EXACT>(t.K0, f0, nb0, F.Z0, xrow, valid, g);
+  kf_ktile<4 * NB1, EXACT>(t.K1, f1, nb1, F.Z1, xrow, valid, g);
 #pragma unroll
   for (int q = 0; q < 4 * NB0; ++q) { t.A0[q] = 0.0; t.B0[q] = 0.0; t.C0[q] = 0.0; }
 #pragma unroll
@@ -364,12 +435,10 @@ k_kf_backward(KfArgs a) {
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
+        // selects, not branches: the eight loads go out back to back (one round trip, not eight)
         const int64_t pt = (int64_t)tile * 16 + 4 * ks + g;
-        double v = psi_kind[p] == 0 ? 1.0 : 0.0;
-        if (psi_kind[p] >= 1 && psi_kind[p] <= 2 && pt < a.N) {
-          const double xv = a.X[pt * a.ldx + psi_col[p]] - psi_zc[p];
-          v = psi_kind[p] == 1 ? xv : xv * xv;
-        }
+        const double xv = a.X[(pt < a.N ? pt : 0) * a.ldx + psi_col[p]] - psi_zc[p];
+        const double v = psi_kind[p] == 0 ? 1.0 : (psi_kind[p] == 1 ? xv : (psi_kind[p] == 2 ? xv * xv : 0.0));
         psi[p][ks] = (pt < a.N) ? v : 0.0;
       }
     kf_store_tile<Q0>(c0, t.A0, g, n);
