@@ -16,7 +16,9 @@ namespace zigp {
 struct DevBuf {
   double* p = nullptr;
   size_t cap = 0;  // doubles
+  bool owned = true;   // false: p points into another buffer (alias)
   int ensure(size_t n) {
+    if (!owned) { p = nullptr; cap = 0; owned = true; }
     if (n <= cap) return 0;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
@@ -25,7 +27,8 @@ struct DevBuf {
     cap = n;
     return 0;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void alias(double* q, size_t n) { release(); p = q; cap = n; owned = false; }   // a view of n doubles at q (owned by someone else)
+  void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
 };
 
 enum ProfClass { PC_GEMM_A1 = 0, PC_GEMM_A2 = 1, PC_GEMM_H = 2, PC_GEMM_J = 3, PC_SYR2K = 4, PC_KUF = 5, PC_POINT = 6, PC_RED = 7, PC_MXM = 8, PC_OTHER = 9 };
@@ -116,6 +119,7 @@ struct zigp_ctx {
   // data-parallel exchange (zigp_comm_init): RCCL communicator, one rank per context / GPU
   void* comm = nullptr; int comm_rank = 0, comm_nranks = 1; int64_t comm_calls = 0;
   zigp::DevBuf packed;                  // result vector of the dense path (k_dense_pack)
+  zigp::DevBuf parm;                    // parameters of both latents, one staged image (latents_upload); lat[h].Z / ell / u / s are views into it
   double pivot_rtol = 8.0;              // zigp_set_pivot_rtol: a Cholesky pivot <= pivot_rtol * eps * (variance + jitter) is ZIGP_ENOTPD
   // profiling
   bool prof_on = false;

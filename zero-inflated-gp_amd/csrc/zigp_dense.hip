@@ -29,69 +29,101 @@ struct HostLatent {
   int M; const double *Z, *u, *s, *ell; double var;
 };
 
-// Parameters of one latent to the device (zero-padded to Mp).  Host->device copies from pageable memory block the
-// host, so they are all issued on the main stream BEFORE the two MxM launch chains fork.
-int latent_upload(zigp_ctx* c, Latent& lt, const HostLatent& h, int D) {
-  lt.M = h.M;
-  lt.Mp = (int)round_up(h.M, BM);
-  lt.var = h.var;
-  const int Mp = lt.Mp;
-  ZIGP_TRY(upload_padded(c, lt.Z, h.Z, (size_t)h.M * D, (size_t)Mp * D));
-  ZIGP_TRY(upload_padded(c, lt.ell, h.ell, D, MAXD));
-  ZIGP_TRY(upload_padded(c, lt.u, h.u, h.M, Mp));
-  ZIGP_TRY(upload_padded(c, lt.s, h.s, h.M, Mp));
-  ZIGP_ENSURE(c, lt.s2, Mp);
-  ZIGP_ENSURE(c, lt.Kuu, (size_t)Mp * Mp);
-  ZIGP_ENSURE(c, lt.L, (size_t)Mp * Mp);
-  ZIGP_ENSURE(c, lt.W, (size_t)Mp * Mp);
-  ZIGP_ENSURE(c, lt.T1, (size_t)Mp * Mp);
-  ZIGP_ENSURE(c, lt.vec, (size_t)4 * Mp + 8);
-  ZIGP_ENSURE(c, lt.Wp, (size_t)Mp * Mp);
-  ZIGP_ENSURE(c, lt.Wt, (size_t)Mp * Mp);
-  ZIGP_ENSURE(c, lt.Wpt, (size_t)Mp * Mp);
-  return 0;
-}
-
-// MxM forward for one latent (kernels only): Kuu, L, W.
-int latent_forward(zigp_ctx* c, Latent& lt, const HostLatent& h, int D, double jitter, bool want_W, double pivot_rtol) {
-  ProfScope ps(c, PC_MXM);
-  const int Mp = lt.Mp;
-  hipLaunchKernelGGL(k_square, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.s.p, lt.s2.p, Mp);
-  KernHyp hyp = make_hyp(h.ell, h.var, D);
-  hipLaunchKernelGGL(k_rbf_matrix, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.Z.p, (int64_t)h.M, lt.Z.p,
-                     (int64_t)h.M, hyp, jitter, lt.Kuu.p, (int64_t)Mp, (int64_t)Mp, (int64_t)Mp);
-  ZIGP_HIP(c, hipGetLastError());
-  ZIGP_HIP(c, hipMemcpyAsync(lt.L.p, lt.Kuu.p, sizeof(double) * Mp * Mp, hipMemcpyDeviceToDevice, c->stream));
-  ZIGP_TRY(potrf_trtri(c, lt.L.p, lt.W.p, lt.T1.p, Mp, want_W, lt.M, pivot_tol(h.var, jitter, pivot_rtol)));
-#if ZIGP_LOWER_VIA_WT
-  if (want_W) {   // W^T and (W diag(s^2))^T for the lower-triangular products (the latter is used by gradient steps only; it costs nothing extra)
-    hipLaunchKernelGGL(k_transpose_scale, dim3(Mp / 32, Mp / 32), dim3(32, 8), 0, c->stream, lt.W.p, lt.s2.p, (int64_t)Mp, lt.Wt.p, lt.Wpt.p);
-    ZIGP_HIP(c, hipGetLastError());
+// Parameters of both latents to the device (zero-padded to Mp): ONE staged image [Z | ell | u | s] x 2 and one copy -- the eight
+// separate copies of the first version were eight launches (~7 us apart) in front of a launch-bound M x M stage.  lt.Z / ell / u / s
+// are views into the context's parameter arena.
+int latents_upload(zigp_ctx* c, const HostLatent (&hl)[2], int D) {
+  size_t off[2][5], total = 0;
+  for (int h = 0; h < 2; ++h) {
+    Latent& lt = c->lat[h];
+    lt.M = hl[h].M;
+    lt.Mp = (int)round_up(hl[h].M, BM);
+    lt.var = hl[h].var;
+    const size_t Mp = lt.Mp;
+    off[h][0] = total; total += Mp * D;      // Z
+    off[h][1] = total; total += MAXD;        // ell
+    off[h][2] = total; total += Mp;          // u
+    off[h][3] = total; total += Mp;          // s
+    off[h][4] = total;
   }
+  ZIGP_ENSURE(c, c->parm, total);
+  ZIGP_PINNED(c, img, total);
+  memset(img, 0, sizeof(double) * total);
+  for (int h = 0; h < 2; ++h) {
+    const HostLatent& q = hl[h];
+    memcpy(img + off[h][0], q.Z, sizeof(double) * q.M * D);
+    memcpy(img + off[h][1], q.ell, sizeof(double) * D);
+    memcpy(img + off[h][2], q.u, sizeof(double) * q.M);
+    memcpy(img + off[h][3], q.s, sizeof(double) * q.M);
+  }
+  ZIGP_HIP(c, hipMemcpyAsync(c->parm.p, img, sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
+  for (int h = 0; h < 2; ++h) {
+    Latent& lt = c->lat[h];
+    const size_t Mp = lt.Mp;
+    lt.Z.alias(c->parm.p + off[h][0], Mp * D); lt.ell.alias(c->parm.p + off[h][1], MAXD);
+    lt.u.alias(c->parm.p + off[h][2], Mp); lt.s.alias(c->parm.p + off[h][3], Mp);
+    ZIGP_ENSURE(c, lt.s2, Mp);
+    ZIGP_ENSURE(c, lt.Kuu, Mp * Mp);
+    ZIGP_ENSURE(c, lt.L, Mp * Mp);
+    ZIGP_ENSURE(c, lt.W, Mp * Mp);
+    ZIGP_ENSURE(c, lt.T1, Mp * Mp);
+    ZIGP_ENSURE(c, lt.vec, 4 * Mp + 8);
+    ZIGP_ENSURE(c, lt.Wp, Mp * Mp);
+    ZIGP_ENSURE(c, lt.Wt, Mp * Mp);
+    ZIGP_ENSURE(c, lt.Wpt, Mp * Mp);
+  }
+  return 0;
+}
+
+// MxM forward of BOTH latents (kernels only): Kuu, L = chol, W = L^-1 (+ W^T, (W diag(s^2))^T), the KL pieces v = W u,
+// alpha = W^T v, dkinv = diag(K^-1), kl -> vec[3*Mp], and W' = W diag(s^2) for gradient steps.  Latent f runs on the main stream and g
+// on stream2 (the caller forks / joins); the launches ALTERNATE between the two chains step by step, so that both streams are fed
+// from the start (see potrf_trtri_jobs).
+int latents_forward(zigp_ctx* c, const HostLatent (&hl)[2], int D, double jitter, bool with_kl, bool need_grad) {
+  const hipStream_t st[2] = {c->stream_main, c->stream2};
+  struct Restore { zigp_ctx* c; ~Restore() { c->stream = c->stream_main; } } restore{c};
+  for (int h = 0; h < 2; ++h) {
+    Latent& lt = c->lat[h];
+    const int Mp = lt.Mp;
+    c->stream = st[h];
+    hipLaunchKernelGGL(k_square, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.s.p, lt.s2.p, Mp);
+    KernHyp hyp = make_hyp(hl[h].ell, hl[h].var, D);
+    hipLaunchKernelGGL(k_rbf_matrix, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.Z.p, (int64_t)hl[h].M, lt.Z.p,
+                       (int64_t)hl[h].M, hyp, jitter, lt.Kuu.p, (int64_t)Mp, (int64_t)Mp, (int64_t)Mp);
+    ZIGP_HIP(c, hipGetLastError());
+    ZIGP_HIP(c, hipMemcpyAsync(lt.L.p, lt.Kuu.p, sizeof(double) * Mp * Mp, hipMemcpyDeviceToDevice, c->stream));
+  }
+  {
+    PotrfJob jobs[2];
+    for (int h = 0; h < 2; ++h) {
+      Latent& lt = c->lat[h];
+      jobs[h] = PotrfJob{lt.L.p, lt.W.p, lt.T1.p, lt.Mp, true, lt.M, pivot_tol(hl[h].var, jitter, c->pivot_rtol)};
+    }
+    ZIGP_TRY(potrf_trtri_jobs(c, 2, jobs, st));
+  }
+  for (int step = 0; step < 5; ++step)
+    for (int h = 0; h < 2; ++h) {
+      Latent& lt = c->lat[h];
+      const int Mp = lt.Mp;
+      c->stream = st[h];
+      double* v = lt.vec.p; double* alpha = v + Mp; double* dkinv = v + 2 * Mp; double* klv = v + 3 * Mp;
+      switch (step) {
+#if ZIGP_LOWER_VIA_WT
+        case 0:   // W^T and (W diag(s^2))^T for the lower-triangular products (the latter is used by gradient steps only; it costs nothing extra)
+          hipLaunchKernelGGL(k_transpose_scale, dim3(Mp / 32, Mp / 32), dim3(32, 8), 0, c->stream, lt.W.p, lt.s2.p, (int64_t)Mp, lt.Wt.p, lt.Wpt.p);
+          break;
 #endif
-  return 0;
-}
-
-// Gradient-side MxM pieces: W' = W diag(s^2) (operand of H = W' A2)
-int latent_forward_grad(zigp_ctx* c, Latent& lt) {
-  ProfScope ps(c, PC_MXM);
-  const int Mp = lt.Mp;
-  ZIGP_ENSURE(c, lt.Wp, (size_t)Mp * Mp);
-  hipLaunchKernelGGL(k_colscale, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.W.p, lt.s2.p, (int64_t)Mp, lt.Wp.p);
-  ZIGP_HIP(c, hipGetLastError());
-  return 0;
-}
-
-// KL value pieces: v = W u, alpha = W^T v, dkinv = diag(K^-1), kl -> vec[3*Mp]
-int latent_kl(zigp_ctx* c, Latent& lt) {
-  ProfScope ps(c, PC_MXM);
-  const int Mp = lt.Mp;
-  ZIGP_ENSURE(c, lt.vec, (size_t)4 * Mp + 8);
-  double* v = lt.vec.p; double* alpha = v + Mp; double* dkinv = v + 2 * Mp; double* klv = v + 3 * Mp;
-  hipLaunchKernelGGL(k_gemv_rows, dim3(Mp), dim3(256), 0, c->stream, lt.W.p, lt.u.p, (int64_t)Mp, v);
-  hipLaunchKernelGGL(k_kl_cols, dim3(Mp / 64), dim3(64, COL_LANES), 0, c->stream, lt.W.p, v, (int64_t)Mp, alpha, dkinv);
-  hipLaunchKernelGGL(k_kl_value, dim3(1), dim3(256), 0, c->stream, v, lt.L.p, lt.s.p, dkinv, lt.M, (int64_t)Mp, klv);
-  ZIGP_HIP(c, hipGetLastError());
+        // v = W u and alpha = W^T v are needed by the KL value, by the fused mean (v^T A1) and by the rank-1 parts of the data-term gradient
+        case 1: if (with_kl) hipLaunchKernelGGL(k_gemv_rows, dim3(Mp), dim3(256), 0, c->stream, lt.W.p, lt.u.p, (int64_t)Mp, v); break;
+        case 2: if (with_kl) hipLaunchKernelGGL(k_kl_cols, dim3(Mp / 64), dim3(64, COL_LANES), 0, c->stream, lt.W.p, v, (int64_t)Mp, alpha, dkinv); break;
+        case 3: if (with_kl) hipLaunchKernelGGL(k_kl_value, dim3(1), dim3(256), 0, c->stream, v, lt.L.p, lt.s.p, dkinv, lt.M, (int64_t)Mp, klv); break;
+        case 4:   // W' = W diag(s^2) (operand of H = W' A2)
+          if (need_grad) hipLaunchKernelGGL(k_colscale, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.W.p, lt.s2.p, (int64_t)Mp, lt.Wp.p);
+          break;
+        default: break;
+      }
+      ZIGP_HIP(c, hipGetLastError());
+    }
   return 0;
 }
 
@@ -205,7 +237,11 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
       hipLaunchKernelGGL(k_gemv_cols, dim3(Mp / 64), dim3(64, COL_LANES), 0, c->stream, lt.W.p, lt.a1gm.p, (int64_t)Mp, lt.du.p);
     }
     // C1 = sym(sum_s planes) -> T1
-    hipLaunchKernelGGL(k_sym_from_planes, dim3(gridmm), dim3(256), 0, c->stream, lt.dLpart.p, syr_plan(nb).planes(), (int64_t)Mp, lt.T1.p);
+    {
+      const SyrPlan sp = syr_plan(nb);
+      const int nt = Mp / 32;
+      hipLaunchKernelGGL(k_sym_from_planes, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, lt.dLpart.p, sp.So, sp.Sd, (int64_t)Mp, lt.T1.p);
+    }
     // dsq = diag(A2 G A2^T) = diag(W^T C1 W): Y = C1 W -> T3 ; dsq[m] = sum_k W[k][m] Y[k][m]
     ZIGP_TRY((run_gemm_sk<LAY_KCONTIG, LAY_MNCONTIG>(c, lt.sk, "y", nb, [&](int bi, int bj, int& k0, int& k1) { k0 = bj * kb; k1 = nb * kb; },
                                                      lt.T1.p, lt.W.p, lt.T3.p, Mp, SK_STORE, 1.0, false)));
@@ -281,17 +317,12 @@ struct DenseCall {
 int dense_mxm_forward(zigp_ctx* c, DenseCall& k) {
   ZIGP_TRY(begin_staged_call(c));
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
-  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_upload(c, c->lat[h], k.hl[h], k.D));
+  ZIGP_TRY(latents_upload(c, k.hl, k.D));
   {
+    ProfScope ps(c, PC_MXM);     // wall time of the two concurrent chains: both events on the main stream, the second after the join
     TwoStream ts(c);
     ZIGP_TRY(ts.fork());
-    for (int h = 0; h < 2; ++h) {
-      if (h == 1) ts.second();
-      ZIGP_TRY(latent_forward(c, c->lat[h], k.hl[h], k.D, k.jitter, true, c->pivot_rtol));
-      // v = W u and alpha = W^T v are needed by the KL value, by the fused mean (v^T A1) and by the rank-1 parts of the data-term gradient
-      ZIGP_TRY(latent_kl(c, c->lat[h]));
-      if (k.need_grad) ZIGP_TRY(latent_forward_grad(c, c->lat[h]));
-    }
+    ZIGP_TRY(latents_forward(c, k.hl, k.D, k.jitter, true, k.need_grad));
     ZIGP_TRY(ts.join());
   }
   return request_info(c, &k.hinfo);   // read after the final synchronisation
@@ -318,7 +349,10 @@ int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
   const int D = k.D;
   k.pw_blocks = (int)(Nc / PW_PTS);
   ZIGP_ENSURE(c, c->pw_part, (size_t)k.pw_blocks * PW_ACC);
-  ZIGP_HIP(c, hipMemsetAsync(c->pw_part.p, 0, sizeof(double) * k.pw_blocks * PW_ACC, c->stream));
+  ZeroRanges zr;               // the small accumulators of the call: one launch instead of a memset each
+  zr.count = 0;
+  auto zero = [&](double* ptr, int64_t n) { zr.p[zr.count] = ptr; zr.n[zr.count] = n; ++zr.count; };
+  zero(c->pw_part.p, (int64_t)k.pw_blocks * PW_ACC);
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
     const int Mp = lt.Mp;
@@ -333,13 +367,12 @@ int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
       const int S = syr_plan(Mp / BM).planes();
       ZIGP_ENSURE(c, lt.dLpart, (size_t)S * Mp * Mp);
       ZIGP_ENSURE(c, lt.a1gm, Mp);
-      ZIGP_HIP(c, hipMemsetAsync(lt.a1gm.p, 0, sizeof(double) * Mp, c->stream));
-      ZIGP_HIP(c, hipMemsetAsync(lt.du.p, 0, sizeof(double) * Mp, c->stream));
-      ZIGP_HIP(c, hipMemsetAsync(lt.dsq.p, 0, sizeof(double) * Mp, c->stream));
-      ZIGP_HIP(c, hipMemsetAsync(lt.krow.p, 0, sizeof(double) * KG_SPLIT * Mp * (2 + 2 * D), c->stream));
+      zero(lt.a1gm.p, Mp); zero(lt.du.p, Mp); zero(lt.dsq.p, Mp); zero(lt.krow.p, (int64_t)KG_SPLIT * Mp * (2 + 2 * D));
       if (k.has_rows) ZIGP_HIP(c, hipMemsetAsync(lt.dLpart.p, 0, sizeof(double) * S * Mp * Mp, c->stream));
     }
   }
+  hipLaunchKernelGGL(k_zero_ranges, dim3(64), dim3(256), 0, c->stream, zr);      // at most 1 + 2 x 4 ranges
+  ZIGP_HIP(c, hipGetLastError());
   return 0;
 }
 
@@ -545,7 +578,7 @@ int zigp_destroy(zigp_ctx* c) {
                     &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec, &l.sk};
     for (DevBuf* b : bs) b->release();
   }
-  DevBuf* bs[] = {&c->ownX, &c->ownY, &c->pw_part, &c->out9, &c->scratch, &c->scratch2, &c->packed, &c->selX, &c->selY, &c->selIdx};
+  DevBuf* bs[] = {&c->ownX, &c->ownY, &c->pw_part, &c->out9, &c->scratch, &c->scratch2, &c->packed, &c->parm, &c->selX, &c->selY, &c->selIdx};
   for (DevBuf* b : bs) b->release();
   if (c->kron && c->kron_free) c->kron_free(c->kron);
   if (c->kronf && c->kronf_free) c->kronf_free(c->kronf);
@@ -702,13 +735,18 @@ int zigp_prior_kl(zigp_ctx* c, const zigp_params* p, double jitter, double* kl2)
   HostLatent hl[2] = {{p->Mf, p->Zf, p->u_fm, p->u_fs_sqrt, p->ell_f, p->var_f}, {p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g}};
   ZIGP_TRY(begin_staged_call(c));
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
-  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_upload(c, c->lat[h], hl[h], p->D));
-  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_forward(c, c->lat[h], hl[h], p->D, jitter, true, c->pivot_rtol));
-  ZIGP_TRY(check_info(c, "Kuu"));
-  for (int h = 0; h < 2; ++h) {
-    ZIGP_TRY(latent_kl(c, c->lat[h]));
-    ZIGP_HIP(c, hipMemcpyAsync(&kl2[h], c->lat[h].vec.p + 3 * c->lat[h].Mp, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  ZIGP_TRY(latents_upload(c, hl, p->D));
+  {
+    TwoStream ts(c);
+    ZIGP_TRY(ts.fork());
+    ZIGP_TRY(latents_forward(c, hl, p->D, jitter, true, false));
+    ZIGP_TRY(ts.join());
   }
+  double klh[2] = {0.0, 0.0};
+  for (int h = 0; h < 2; ++h)
+    ZIGP_HIP(c, hipMemcpyAsync(&klh[h], c->lat[h].vec.p + 3 * c->lat[h].Mp, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  ZIGP_TRY(check_info(c, "Kuu"));          // synchronises; on failure kl2 is left untouched
+  kl2[0] = klh[0]; kl2[1] = klh[1];
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
   return ZIGP_OK;

@@ -178,9 +178,9 @@ template <bool NEWMAP> __device__ __forceinline__ int kswz(int row) {
 // Staging addresses.  A global_load_lds takes (scalar base) + (32-bit per-lane byte offset).  The per-lane offset of this wave's FIRST
 // 1 KB chunk is computed once per tile; its other 16 / WAVES - 1 chunks lie a uniform distance further on (chunk c = WAVES p + wave holds
 // rows 8c .. 8c + 7 of a k-contiguous tile -- 8 WAVES rows per p, and the swizzle only sees the row's low four bits -- or k-row c of an
-// m/n-contiguous one), which goes into the SCALAR base: one offset register per operand instead of 16 / WAVES (r3: the registers this
-// frees are what lets the peeled diagonal tail of the triangular products compile without spills).  The scalar base advances by a
-// constant each BK step, and the LDS destination (M0) is scalar arithmetic on the wave id -- no per-step vector address math.
+// m/n-contiguous one), which goes into the SCALAR base: one offset register per operand instead of 16 / WAVES.  The scalar base
+// advances by a constant each BK step, and the LDS destination (M0) is scalar arithmetic on the wave id -- no per-step vector address
+// math (glds_pin below is what makes the compiler keep it that way).
 template <int LAY, int WAVES, bool NEWMAP>
 __device__ __forceinline__ uint32_t glds_lane_offset(int64_t ld, int wave, int lane) {
   if (LAY == LAY_KCONTIG) {                           // chunk = rows 8c..8c+7, lane -> (row, granule position)
@@ -199,13 +199,26 @@ __device__ __forceinline__ int64_t glds_chunk_stride(int64_t ld) { return (LAY =
 #ifndef ZIGP_BPAD
 #define ZIGP_BPAD 1
 #endif
+// The uniform part of a staging address, pinned in a scalar register pair.  Without this the loop optimiser turns (uniform base that
+// advances per BK step) + (per-lane offset) into one 64-bit per-lane pointer PER LOAD as its induction variables: 2 VGPRs and two
+// v_lshl_add_u64 per load and step (18 VGPRs and 18 64-bit VALU adds per BK step in the 4-wave kernels; fp64 MFMAs do not overlap with
+// VALU work on this chip, profiles/r03t_kron_stamps.txt).  readfirstlane of a uniform value costs nothing (it folds to the SGPR it
+// already lives in) but is opaque to that transformation, and SGPR base + 32-bit VGPR offset is the load's native address form.
+// Measured: +0.5 % on every GEMM class, within box noise per step (profiles/r03x_ab_pin.log); kept for the registers.
+__device__ __forceinline__ const char* glds_pin(const char* p) {
+  const uint64_t u = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return (const char*)(((uint64_t)hi << 32) | lo);
+}
 template <int LAY, int WAVES, bool PAD = false>
 __device__ __forceinline__ void glds_tile(double* tile, const char* __restrict__ base, uint32_t off, int64_t chunk_stride, int wave) {
+  asm volatile("" : "+v"(off));   // keeps the 32 -> 64 bit extension of the offset next to the load (instruction selection works per
+                                  // block: hoisted out of the loop, the extension hides that the offset is 32 bits wide)
 #pragma unroll
   for (int p = 0; p < 16 / WAVES; ++p) {
     const int c = WAVES * p + wave;
     double* dst = tile + ((LAY == LAY_KCONTIG) ? c * 128 + (PAD ? (c >> 1) * 2 : 0) : c * LDMN);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + p * chunk_stride + (uint64_t)off),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(glds_pin(base + p * chunk_stride) + (uint64_t)off),
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
 }
@@ -284,8 +297,10 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
   auto issue_slice = [&](double* img, int sl) {   // BK slice `sl` of the tile's k range into the image at img
     glds_tile<LAY_KCONTIG, WAVES>(img, baseA + sl * strideA, offA, csA, wave);
     if (KSCALE) {
+      uint32_t so = 16 * ln;
+      asm volatile("" : "+v"(so));
       if (ln < 8)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + kd * sl * (BK * 8) + (int64_t)(16 * ln)),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(glds_pin(baseS + kd * sl * (BK * 8)) + (uint64_t)so),
                                          (__attribute__((address_space(3))) void*)(img + SCALE_OFF), 16, 0, 0);
     }
   };
@@ -397,8 +412,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
     glds_tile<ALAY, WAVES>(st, baseA + it * strideA, offA, csA, wave);
     glds_tile<BLAY, WAVES, B_PAD>(st + TILE_DOUBLES, baseB + it * strideB, offB, csB, wave);
     if (KSCALE) {   // 16 doubles of the scale vector; every wave issues the same 128 B (uniform vmcnt accounting)
+      uint32_t so = 16 * ln;
+      asm volatile("" : "+v"(so));
       if (ln < 8)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseS + kd * it * (BK * 8) + (int64_t)(16 * ln)),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(glds_pin(baseS + kd * it * (BK * 8)) + (uint64_t)so),
                                          (__attribute__((address_space(3))) void*)(st + 2 * TILE_DOUBLES), 16, 0, 0);
     }
   };

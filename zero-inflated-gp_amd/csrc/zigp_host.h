@@ -259,62 +259,101 @@ static inline double pivot_tol(double var, double jitter, double rtol = 8.0) { r
 // L = chol(A) in place in `Lb` (which holds a copy of A on entry), W = L^-1.  Mp multiple of 128.
 // ------------------------------------------------------------------------------------------------
 // Mreal = rows that are not identity padding (diagonal blocks factor only the panels that hold real rows)
-static int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool want_W, int Mreal = -1, double piv_tol = 0.0) {
-  if (Mreal < 0 || Mreal > Mp) Mreal = Mp;
-  const int nb = Mp / BM;
+// One or two factorisations at a time: the launches of job 0 go to streams[0], those of job 1 to streams[1], ALTERNATING step by
+// step.  A chain is ~25 dependent launches of 5-50 us; enqueued one chain after the other, the second stream started ~100-400 us
+// late (the host was still enqueueing the first), and the M x M forward of the two latents took that much longer than one chain.
+struct PotrfJob { double* L; double* W; double* T; int Mp; bool want_W; int Mreal; double piv_tol; };
+static int potrf_trtri_jobs(zigp_ctx* c, int njobs, const PotrfJob* jobs, const hipStream_t* streams) {
+  hipStream_t const saved = c->stream;
+  struct Restore { zigp_ctx* c; hipStream_t s; ~Restore() { c->stream = s; } } restore{c, saved};
   const int kb = BM / BK;  // k-steps per block
-  // c->d_info is cleared by the caller (several factorizations may share one check_info)
-  ZIGP_HIP(c, hipMemsetAsync(Wb, 0, sizeof(double) * Mp * Mp, c->stream));
   const size_t shm = sizeof(double) * PB * PBLD;
-  for (int j = 0; j < nb; ++j) {
-    double* Ajj = Lb + (int64_t)j * BM * Mp + (int64_t)j * BM;
-    double* Wjj = Wb + (int64_t)j * BM * Mp + (int64_t)j * BM;
-    const int nreal_j = std::max(0, std::min(BM, Mreal - j * BM));
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(1024), shm, c->stream, Ajj, Ajj, Wjj, (int64_t)Mp, j * BM, c->d_info, (nreal_j + PNB - 1) / PNB, piv_tol);
-    ZIGP_HIP(c, hipGetLastError());
-    if (j + 1 < nb) {
-      TileList tp, ts;
-      ZIGP_TRY(get_tiles(c, "po_p:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
-        for (int bi = j + 1; bi < nb; ++bi) v.push_back(mk_tile(bi, j, j * kb, (j + 1) * kb));
-      }, tp));
-      // L[bi][j] = A[bi][j] * W_jj^T   (in place: each tile reads only itself and W_jj)
-      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, tp, mk_args(Lb, Mp, Wb, Mp, Lb, Mp), EpiStore())));
-      ZIGP_TRY(get_tiles(c, "po_s:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
-        for (int bi = j + 1; bi < nb; ++bi)
-          for (int bj = j + 1; bj <= bi; ++bj) v.push_back(mk_tile(bi, bj, j * kb, (j + 1) * kb));
-      }, ts));
-      // A[bi][bj] -= L[bi][j] L[bj][j]^T
-      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, ts, mk_args(Lb, Mp, Lb, Mp, Lb, Mp, -1.0), EpiAccum())));
-    }
+  int nbmax = 0;
+  for (int q = 0; q < njobs; ++q) nbmax = std::max(nbmax, jobs[q].Mp / BM);
+  // c->d_info is cleared by the caller (several factorizations may share one check_info)
+  for (int q = 0; q < njobs; ++q) {
+    c->stream = streams[q];
+    ZIGP_HIP(c, hipMemsetAsync(jobs[q].W, 0, sizeof(double) * jobs[q].Mp * jobs[q].Mp, c->stream));
+  }
+  for (int j = 0; j < nbmax; ++j) {
+    for (int step = 0; step < 3; ++step)
+      for (int q = 0; q < njobs; ++q) {
+        const PotrfJob& J = jobs[q];
+        const int Mp = J.Mp, nb = Mp / BM, Mreal = (J.Mreal < 0 || J.Mreal > Mp) ? Mp : J.Mreal;
+        if (j >= nb) continue;
+        c->stream = streams[q];
+        double* Lb = J.L; double* Wb = J.W;
+        if (step == 0) {
+          double* Ajj = Lb + (int64_t)j * BM * Mp + (int64_t)j * BM;
+          double* Wjj = Wb + (int64_t)j * BM * Mp + (int64_t)j * BM;
+          const int nreal_j = std::max(0, std::min(BM, Mreal - j * BM));
+          hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(1024), shm, c->stream, Ajj, Ajj, Wjj, (int64_t)Mp, j * BM, c->d_info, (nreal_j + PNB - 1) / PNB, J.piv_tol);
+          ZIGP_HIP(c, hipGetLastError());
+        } else if (j + 1 < nb && step == 1) {
+          TileList tp;
+          ZIGP_TRY(get_tiles(c, "po_p:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
+            for (int bi = j + 1; bi < nb; ++bi) v.push_back(mk_tile(bi, j, j * kb, (j + 1) * kb));
+          }, tp));
+          // L[bi][j] = A[bi][j] * W_jj^T   (in place: each tile reads only itself and W_jj)
+          ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, tp, mk_args(Lb, Mp, Wb, Mp, Lb, Mp), EpiStore())));
+        } else if (j + 1 < nb && step == 2) {
+          TileList ts;
+          ZIGP_TRY(get_tiles(c, "po_s:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
+            for (int bi = j + 1; bi < nb; ++bi)
+              for (int bj = j + 1; bj <= bi; ++bj) v.push_back(mk_tile(bi, bj, j * kb, (j + 1) * kb));
+          }, ts));
+          // A[bi][bj] -= L[bi][j] L[bj][j]^T
+          ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, ts, mk_args(Lb, Mp, Lb, Mp, Lb, Mp, -1.0), EpiAccum())));
+        }
+      }
   }
   // zero the strictly-upper blocks of L (they still hold the copy of A)
-  for (int bi = 0; bi + 1 < nb; ++bi)
-    ZIGP_HIP(c, hipMemset2DAsync(Lb + (int64_t)bi * BM * Mp + (int64_t)(bi + 1) * BM, sizeof(double) * Mp, 0,
-                                 sizeof(double) * (size_t)(Mp - (bi + 1) * BM), BM, c->stream));
-  if (!want_W) return 0;
+  for (int bi = 0; bi + 1 < nbmax; ++bi)
+    for (int q = 0; q < njobs; ++q) {
+      const int Mp = jobs[q].Mp, nb = Mp / BM;
+      if (bi + 1 >= nb) continue;
+      c->stream = streams[q];
+      ZIGP_HIP(c, hipMemset2DAsync(jobs[q].L + (int64_t)bi * BM * Mp + (int64_t)(bi + 1) * BM, sizeof(double) * Mp, 0,
+                                   sizeof(double) * (size_t)(Mp - (bi + 1) * BM), BM, c->stream));
+    }
   // W by recursive doubling over diagonal-block groups: W21 = -W22 (L21 W11)
-  for (int b = 1; b < nb; b *= 2) {
-    TileList t1, t2;
-    ZIGP_TRY(get_tiles(c, "tri1:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
-      for (int lo = 0; lo < nb; lo += 2 * b) {
-        const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
-        if (mid >= nb) continue;
-        for (int bi = mid; bi < hi; ++bi)
-          for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, mid * kb));
+  for (int b = 1; b < nbmax; b *= 2)
+    for (int step = 0; step < 2; ++step)
+      for (int q = 0; q < njobs; ++q) {
+        const PotrfJob& J = jobs[q];
+        const int Mp = J.Mp, nb = Mp / BM;
+        if (!J.want_W || b >= nb) continue;
+        c->stream = streams[q];
+        if (step == 0) {
+          TileList t1;
+          ZIGP_TRY(get_tiles(c, "tri1:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
+            for (int lo = 0; lo < nb; lo += 2 * b) {
+              const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
+              if (mid >= nb) continue;
+              for (int bi = mid; bi < hi; ++bi)
+                for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, mid * kb));
+            }
+          }, t1));
+          ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t1, mk_args(J.L, Mp, J.W, Mp, J.T, Mp), EpiStore())));
+        } else {
+          TileList t2;
+          ZIGP_TRY(get_tiles(c, "tri2:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
+            for (int lo = 0; lo < nb; lo += 2 * b) {
+              const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
+              if (mid >= nb) continue;
+              for (int bi = mid; bi < hi; ++bi)
+                for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, mid * kb, (bi + 1) * kb));
+            }
+          }, t2));
+          ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t2, mk_args(J.W, Mp, J.T, Mp, J.W, Mp, -1.0), EpiStore())));
+        }
       }
-    }, t1));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t1, mk_args(Lb, Mp, Wb, Mp, Tb, Mp), EpiStore())));
-    ZIGP_TRY(get_tiles(c, "tri2:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
-      for (int lo = 0; lo < nb; lo += 2 * b) {
-        const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
-        if (mid >= nb) continue;
-        for (int bi = mid; bi < hi; ++bi)
-          for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, mid * kb, (bi + 1) * kb));
-      }
-    }, t2));
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t2, mk_args(Wb, Mp, Tb, Mp, Wb, Mp, -1.0), EpiStore())));
-  }
   return 0;
+}
+static int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool want_W, int Mreal = -1, double piv_tol = 0.0) {
+  const PotrfJob job = {Lb, Wb, Tb, Mp, want_W, Mreal, piv_tol};
+  const hipStream_t st = c->stream;
+  return potrf_trtri_jobs(c, 1, &job, &st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -356,15 +356,49 @@ k_kuu_grad(const double* __restrict__ G, const double* __restrict__ Kuu, double 
   }
 }
 
-// C1[i][j] = sum_s part[s][max(i,j)][min(i,j)]   (planes hold the lower triangle of A1 G A1^T; fixed summation order)
-__global__ void k_sym_from_planes(const double* __restrict__ part, int S, int64_t Mp, double* __restrict__ out) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Mp * Mp) return;
-  int64_t i = idx / Mp, j = idx - i * Mp;
-  const int64_t src = (j <= i) ? idx : (j * Mp + i);
-  double a = 0.0;
-  for (int s = 0; s < S; ++s) a += part[(int64_t)s * Mp * Mp + src];
-  out[idx] = a;
+// C1[i][j] = sum_s part[s][max(i,j)][min(i,j)]   (planes hold the lower triangle of A1 G A1^T; fixed summation order: s ascending)
+// One workgroup per 32 x 32 tile on or below the diagonal: the planes are read ONCE, along rows (the first version read the upper
+// half through transposed addresses, S strided loads per element: 118-150 us at M = 512 with 64 planes, a quarter of the M x M reverse
+// pass), the mirror image goes out through LDS.  Tiles inside a diagonal 128-block live in the first Sd planes only (the others hold
+// the zeros of the memset, and x + 0 = x: the sums keep their bits).
+__global__ void __launch_bounds__(256)
+k_sym_from_planes(const double* __restrict__ part, int So, int Sd, int64_t Mp, double* __restrict__ out) {
+  __shared__ double sh[32][33];
+  const int t = blockIdx.x;
+  int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while (tr * (tr + 1) / 2 > t) --tr;
+  while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+  const int tc = t - tr * (tr + 1) / 2;
+  const int S = (tr * 32 / BM == tc * 32 / BM) ? Sd : So;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t plane = Mp * Mp;
+  const double* __restrict__ src = part + (int64_t)(32 * tr + ty) * Mp + 32 * tc + tx;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += src[(int64_t)s * plane + (int64_t)(8 * k) * Mp];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sh[ty + 8 * k][tx] = a[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = ty + 8 * k;
+    if (tr != tc) {
+      out[(int64_t)(32 * tr + r) * Mp + 32 * tc + tx] = sh[r][tx];
+      out[(int64_t)(32 * tc + r) * Mp + 32 * tr + tx] = sh[tx][r];
+    } else {
+      out[(int64_t)(32 * tr + r) * Mp + 32 * tc + tx] = (tx <= r) ? sh[r][tx] : sh[tx][r];
+    }
+  }
+}
+// zero up to twelve device ranges in one launch (the per-call accumulators of the dense path: a memset launch each costs ~5 us of a
+// launch-bound M x M stage)
+struct ZeroRanges { double* p[12]; int64_t n[12]; int count; };
+__global__ void __launch_bounds__(256)
+k_zero_ranges(ZeroRanges z) {
+  for (int q = 0; q < z.count; ++q)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < z.n[q]; i += (int64_t)gridDim.x * 256) z.p[q][i] = 0.0;
 }
 // V = U + U^T - C
 __global__ void k_uut_minus(const double* __restrict__ U, const double* __restrict__ C, int64_t Mp, double* __restrict__ V) {
