@@ -531,10 +531,27 @@ __host__ __device__ inline KfWork kf_work_layout(int nb0c, int nb1c) {
 constexpr int KF_MQ = 16 * KF_NBMAX;
 constexpr int KF_W_AL = 0, KF_W_S2 = KF_MQ * KF_MQ, KF_W_P0 = 2 * KF_MQ * KF_MQ, KF_W_P1 = 3 * KF_MQ * KF_MQ, KF_W_K0 = 4 * KF_MQ * KF_MQ,
               KF_W_K1 = KF_W_K0 + KF_MQ * 16, KF_W_TOTAL = KF_W_K1 + KF_MQ * 16;   // = kf_work_layout(KF_NBMAX, KF_NBMAX)
+// sums of the point-wise block partials, one workgroup of 256 threads (see k_kron_pw_reduce)
+__device__ __forceinline__ void kf_pw_reduce(const double* __restrict__ acc, int blocks, double kl_counted, double* __restrict__ pws) {
+  __shared__ double sh[4];
+  if (threadIdx.x == 0) pws[7] = kl_counted;   // 1 on the rank(s) that count the KL: summed over ranks like everything else
+#pragma unroll
+  for (int q = 0; q < KPW_ACC; ++q) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 256) v += acc[(int64_t)KPW_ACC * b + q];
+    v = block_sum<4>(v, sh);
+    if (threadIdx.x == 0) pws[q] = v;
+  }
+}
 constexpr int KF_RED_GROUPS = 16;
 __global__ void __launch_bounds__(256)
 k_kf_reduce(const double* __restrict__ acc0, const double* __restrict__ acc1, int nparts, double* __restrict__ work0, double* __restrict__ work1,
-            int nb0c, int nb1c, int nb0_f, int nb1_f, int nb0_g, int nb1_g) {
+            int nb0c, int nb1c, int nb0_f, int nb1_f, int nb0_g, int nb1_g, const double* __restrict__ pwacc, int pw_blocks, double kl_counted,
+            double* __restrict__ pws) {
+  if (blockIdx.x == gridDim.x - 1) {          // the extra workgroup(s): the point-wise sums (first latent's only)
+    if (blockIdx.y == 0 && pwacc) kf_pw_reduce(pwacc, pw_blocks, kl_counted, pws);
+    return;
+  }
   __shared__ double sh[KF_RED_GROUPS][16];
   const double* acc = blockIdx.y == 0 ? acc0 : acc1;
   double* work = blockIdx.y == 0 ? work0 : work1;
@@ -1043,20 +1060,12 @@ constexpr size_t KF_SPILL_MAX_DOUBLES = (size_t)8 << 30;   // 64 GB of the 288 G
 struct KfHostLatent { int M[2]; const double* Z[2]; const double* ell[2]; double var[2]; const double* u; const double* s; };
 constexpr int KF_KROW_W = 2 + 2 * MAXD;
 
-// Fixed-order sums of the point-wise block partials -> pws[0..KPW_ACC): the result block of a step has a size that depends on the
-// inducing grid only (never on the shard), so a data-parallel run can sum it over ranks in place (comm_allreduce).
+// Fixed-order sums of the point-wise block partials -> pws[0..KPW_ACC) (kf_pw_reduce, above): the result block of a step has a size
+// that depends on the inducing grid only (never on the shard), so a data-parallel run can sum it over ranks in place (comm_allreduce).
+// Value-only steps launch it on its own; gradient steps run it as one extra workgroup of k_kf_reduce (a launch less on a step that is
+// launch-bound at minibatch size).
 __global__ void __launch_bounds__(256)
-k_kron_pw_reduce(const double* __restrict__ acc, int blocks, double kl_counted, double* __restrict__ pws) {
-  __shared__ double sh[4];
-  if (threadIdx.x == 0) pws[7] = kl_counted;   // 1 on the rank(s) that count the KL: summed over ranks like everything else
-#pragma unroll
-  for (int q = 0; q < KPW_ACC; ++q) {
-    double v = 0.0;
-    for (int b = threadIdx.x; b < blocks; b += 256) v += acc[(int64_t)KPW_ACC * b + q];
-    v = block_sum<4>(v, sh);
-    if (threadIdx.x == 0) pws[q] = v;
-  }
-}
+k_kron_pw_reduce(const double* __restrict__ acc, int blocks, double kl_counted, double* __restrict__ pws) { kf_pw_reduce(acc, blocks, kl_counted, pws); }
 
 static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
                      double g_offset, double f_mu, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
@@ -1246,7 +1255,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   }
   if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
   else hipLaunchKernelGGL(k_kron_head_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
-  hipLaunchKernelGGL(k_kron_pw_reduce, dim3(1), dim3(256), 0, c->stream, d_pwacc, pw_blocks, include_kl ? 1.0 : 0.0, ks.res.p + RES_PWS);
+  if (!need_grad) hipLaunchKernelGGL(k_kron_pw_reduce, dim3(1), dim3(256), 0, c->stream, d_pwacc, pw_blocks, include_kl ? 1.0 : 0.0, ks.res.p + RES_PWS);
   ZIGP_HIP(c, hipGetLastError());
   if (need_grad) {
     const int waves = std::min(ka.ntiles, 1024 / nlat);   // one wave per SIMD of the chip: the kernels hold ~400-500 registers per lane
@@ -1296,8 +1305,9 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       hipLaunchKernelGGL(k_kfl_accum, dim3((nblk + 3) / 4, nparts, nlat), dim3(256), 0, c->stream, aa);
       ZIGP_HIP(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_kf_reduce, dim3(nblk * 256 / 16, nlat), dim3(256), 0, c->stream, ka.lat[0].acc, ka.lat[gl_].acc, nparts,
-                       lat(0) + LAT_WORK, lat(gl_) + LAT_WORK, pl.nb0c, pl.nb1c, Mq[0][0] / 16, Mq[0][1] / 16, Mq[gl_][0] / 16, Mq[gl_][1] / 16);
+    hipLaunchKernelGGL(k_kf_reduce, dim3(nblk * 256 / 16 + 1, nlat), dim3(256), 0, c->stream, ka.lat[0].acc, ka.lat[gl_].acc, nparts,
+                       lat(0) + LAT_WORK, lat(gl_) + LAT_WORK, pl.nb0c, pl.nb1c, Mq[0][0] / 16, Mq[0][1] / 16, Mq[gl_][0] / 16, Mq[gl_][1] / 16,
+                       d_pwacc, pw_blocks, include_kl ? 1.0 : 0.0, ks.res.p + RES_PWS);
     ZIGP_HIP(c, hipGetLastError());
     KflFinishArgs fa;
     memset(&fa, 0, sizeof(fa));
