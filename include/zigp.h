@@ -197,10 +197,11 @@ int zigp_comm_allreduce_host(zigp_ctx* ctx, double* inout, int64_t n);
 /* rank / nranks of the context's communicator (nranks = 0: none) and the number of all-reduces issued through it so far */
 int zigp_comm_info(zigp_ctx* ctx, int32_t* rank, int32_t* nranks, int64_t* allreduce_calls);
 
-/* Stream overlap inside zigp_elbo (default off): when on, the HBM-bound kernels of a row chunk (Kuf-cotangent reductions,
- * the next chunk's Kuf panels) run on a second HIP stream underneath the chunk's two MFMA-bound rank-N updates.  Results
- * are bit-identical either way; it is off by default so that every kernel runs alone on one stream and per-kernel durations
- * (HIP events, rocprofv3 --stats) mean what they say. */
+/* Stream overlap inside zigp_elbo (default ON since round 3): the HBM-bound kernels of a row chunk (Kuf-cotangent reductions,
+ * the next chunk's Kuf panels) run on a second HIP stream underneath the chunk's two MFMA-bound rank-N updates (-3 % per
+ * cfg3 step).  Results are bit-identical either way.  Turn it off (0) to profile: every kernel then runs alone on one stream
+ * and per-kernel durations from an external tracer (rocprofv3 --stats) mean what they say; the library's own event timing
+ * (zigp_profile_*, include/zigp_diag.h) already keeps the chunks it times on one stream. */
 int zigp_set_overlap(zigp_ctx* ctx, int32_t on);
 
 #ifdef __cplusplus

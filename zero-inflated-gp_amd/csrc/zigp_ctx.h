@@ -103,7 +103,7 @@ struct zigp_ctx {
   zigp::Latent lat[2];
   zigp::DevBuf pw_part;                 // pointwise block partials
   // mean function of f, m(x) = mean_b + mean_a . x (zigp_set_mean_function), and its gradient from the last zigp_elbo
-  int overlap = 0;                      // zigp_set_overlap: 1 = HBM-bound side kernels of a chunk on stream2 under its SYRKs
+  int overlap = 1;                      // zigp_set_overlap: 1 (default) = HBM-bound side kernels of a chunk on stream2 under its SYRKs
   bool mean_on = false;
   double mean_a[8] = {0}, mean_b = 0.0, mean_da[8] = {0}, mean_db = 0.0;   // 8 = zigp::MAXD (zigp_kernels.h)
   zigp::DevBuf out9;                    // predict outputs (9,Nc)

@@ -351,6 +351,7 @@ int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
   ZIGP_ENSURE(c, c->pw_part, (size_t)k.pw_blocks * PW_ACC);
   ZeroRanges zr;               // the small accumulators of the call: one launch instead of a memset each
   zr.count = 0;
+  static_assert(1 + 2 * 4 <= ZERO_RANGES_MAX, "one launch zeroes every small accumulator of a call");
   auto zero = [&](double* ptr, int64_t n) { zr.p[zr.count] = ptr; zr.n[zr.count] = n; ++zr.count; };
   zero(c->pw_part.p, (int64_t)k.pw_blocks * PW_ACC);
   for (int h = 0; h < 2; ++h) {

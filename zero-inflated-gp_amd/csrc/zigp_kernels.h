@@ -394,7 +394,8 @@ k_sym_from_planes(const double* __restrict__ part, int So, int Sd, int64_t Mp, d
 }
 // zero up to twelve device ranges in one launch (the per-call accumulators of the dense path: a memset launch each costs ~5 us of a
 // launch-bound M x M stage)
-struct ZeroRanges { double* p[12]; int64_t n[12]; int count; };
+constexpr int ZERO_RANGES_MAX = 12;
+struct ZeroRanges { double* p[ZERO_RANGES_MAX]; int64_t n[ZERO_RANGES_MAX]; int count; };
 __global__ void __launch_bounds__(256)
 k_zero_ranges(ZeroRanges z) {
   for (int q = 0; q < z.count; ++q)
