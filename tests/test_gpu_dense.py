@@ -16,6 +16,8 @@ CASES = [
     (2048, 128, 128, 3, 0.3, None, 0.5),   # cut-down cfg2
     (3000, 200, 136, 3, 0.25, 1024, 0.5),  # ragged: M not a multiple of 128, Mf != Mg, 3 chunks with a partial last one
     (1500, 300, 300, 2, 0.2, 1024, 0.5),
+    (1200, 300, 100, 2, 0.25, 1024, 0.5),  # three 128-blocks against one: the two latents' factorisation chains (launched alternately) differ in length
+    (1200, 100, 520, 2, 0.25, 1024, 0.5),  # one block against five (the longer chain on the second stream)
 ]
 
 
