@@ -224,11 +224,22 @@ struct KfFrags { const double *P0, *P1, *Al, *S2, *AlT, *S2T; const double *Z0, 
 __device__ __forceinline__ void kf_stage_z(double* dst, const KfFac& f) {
   for (int idx = threadIdx.x; idx < 16 * f.nb * f.D; idx += blockDim.x) dst[idx] = f.Zs[idx];
 }
-__device__ __forceinline__ void kf_stage_frag(double* dst, const double* __restrict__ src, int n) {   // n is a multiple of 256
-  const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
-  double2* d2 = reinterpret_cast<double2*>(dst);
-#pragma unroll 4
-  for (int idx = threadIdx.x; idx < n / 2; idx += blockDim.x) d2[idx] = s2[idx];
+// n is a multiple of 256.  32 bytes per lane and load, eight loads in flight per thread: the larger grids stage 130-160 KB per
+// workgroup (P1 alone is 100 KB at 100 points), and with 16-byte loads four at a time the copy was a chain of ~20 L2 round trips in
+// front of a workgroup's only tile (minibatch steps: one tile per wave).
+__device__ __forceinline__ void kf_stage_frag(double* dst, const double* __restrict__ src, int n) {
+  const double4* __restrict__ s4 = reinterpret_cast<const double4*>(src);
+  double4* d4 = reinterpret_cast<double4*>(dst);
+  const int n4 = n / 4, step = blockDim.x;
+  int idx = threadIdx.x;
+  for (; idx + 7 * step < n4; idx += 8 * step) {
+    double4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = s4[idx + u * step];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d4[idx + u * step] = v[u];
+  }
+  for (; idx < n4; idx += step) d4[idx] = s4[idx];
 }
 
 // Per-tile state of one latent for a grid of NB0 x NB1 16-row blocks.  EXACT kernels are instantiated for the block counts they run
