@@ -242,20 +242,38 @@ __device__ __forceinline__ void kf_stage_frag(double* dst, const double* __restr
   for (; idx < n4; idx += step) d4[idx] = s4[idx];
 }
 
+// The same copy without registers: global_load_lds moves 1 KB per wave instruction straight into LDS and only counts on vmcnt, so a
+// kernel can issue the whole image, compute what does not need it (the K tiles of its first tile), and wait in kf_stage_wait().
+// n is a multiple of 256 doubles (2 KB): chunk c = 128 doubles, dealt out over the waves of the workgroup.
+__device__ __forceinline__ void kf_stage_frag_async(double* dst, const double* __restrict__ src, int n) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6, lane = threadIdx.x & 63;
+  for (int c = wave; c < n / 128; c += nwaves)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)c * 128 + 2 * lane),
+                                     (__attribute__((address_space(3))) void*)(dst + c * 128), 16, 0, 0);
+}
+__device__ __forceinline__ void kf_stage_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // Per-tile state of one latent for a grid of NB0 x NB1 16-row blocks.  EXACT kernels are instantiated for the block counts they run
 // with: every loop bound is then a compile-time constant, the guards fold away and the compiler issues the fragment loads of a
 // product ahead of its MFMAs.  With runtime bounds each 16 x 16 x 4 step sat behind its own LDS round trip (in-kernel stamps: 21 k
 // cycles for the 64 products of a forward tile whose MFMAs take 4.4 k).
 template <int NB0, int NB1> struct KfTile { double K0[4 * NB0], K1[4 * NB1], A0[4 * NB0], A1[4 * NB1], B0[4 * NB0], C0[4 * NB0]; };
 
-// forward pieces of one tile: A_p = P_p K_p, B0 = Alpha K1, C0 = S2 A1^2
+// forward pieces of one tile: the K tiles (need the inducing inputs only), then A_p = P_p K_p, B0 = Alpha K1, C0 = S2 A1^2 (fragment images)
 template <int NB0, int NB1, bool EXACT>
-__device__ __forceinline__ void kf_forward_tile(KfTile<NB0, NB1>& t, const KfLat& L, const KfFrags& F, const double* __restrict__ xrow, bool valid,
-                                                int g, int slot) {
+__device__ __forceinline__ void kf_forward_ktiles(KfTile<NB0, NB1>& t, const KfLat& L, const double* Z0, const double* Z1, const double* __restrict__ xrow,
+                                                  bool valid, int g) {
   const KfFac &f0 = L.f[0], &f1 = L.f[1];
   const int nb0 = EXACT ? NB0 : f0.nb, nb1 = EXACT ? NB1 : f1.nb;
-  kf_ktile<4 * NB0, EXACT>(t.K0, f0, nb0, F.Z0, xrow, valid, g);
-  kf_ktile<4 * NB1, EXACT>(t.K1, f1, nb1, F.Z1, xrow, valid, g);
+  kf_ktile<4 * NB0, EXACT>(t.K0, f0, nb0, Z0, xrow, valid, g);
+  kf_ktile<4 * NB1, EXACT>(t.K1, f1, nb1, Z1, xrow, valid, g);
+}
+template <int NB0, int NB1, bool EXACT>
+__device__ __forceinline__ void kf_forward_products(KfTile<NB0, NB1>& t, const KfLat& L, const KfFrags& F, int slot) {
+  const int nb0 = EXACT ? NB0 : L.f[0].nb, nb1 = EXACT ? NB1 : L.f[1].nb;
 #pragma unroll
   for (int q = 0; q < 4 * NB0; ++q) { t.A0[q] = 0.0; t.B0[q] = 0.0; t.C0[q] = 0.0; }
 #pragma unroll
@@ -268,6 +286,12 @@ __device__ __forceinline__ void kf_forward_tile(KfTile<NB0, NB1>& t, const KfLat
   for (int q = 0; q < 4 * NB1; ++q) sq[q] = t.A1[q] * t.A1[q];
   kf_frag_mm<NB0, 4 * NB1>(t.C0, F.S2, nb0, 4 * nb1, sq, slot);
 }
+template <int NB0, int NB1, bool EXACT>
+__device__ __forceinline__ void kf_forward_tile(KfTile<NB0, NB1>& t, const KfLat& L, const KfFrags& F, const double* __restrict__ xrow, bool valid,
+                                                int g, int slot) {
+  kf_forward_ktiles<NB0, NB1, EXACT>(t, L, F.Z0, F.Z1, xrow, valid, g);
+  kf_forward_products<NB0, NB1, EXACT>(t, L, F, slot);
+}
 
 // ---- forward: part[0..3][n] = q0 = k0.a0, q1 = k1.a1, mean = k0^T Alpha k1, st = (a0^2)^T S2 (a1^2) -------------------------
 template <int NB0, int NB1>
@@ -278,20 +302,29 @@ k_kf_forward(KfArgs a) {
   const KfLat& L = a.lat[a.lat0 + blockIdx.y];
   {
     constexpr int n0 = NB0 * NB0 * 256, n1 = NB1 * NB1 * 256, n01 = NB0 * NB1 * 256;
-    kf_stage_frag(sfr, L.f[0].PF, n0); kf_stage_frag(sfr + KF_FRAG, L.f[1].PF, n1);
-    kf_stage_frag(sfr + 2 * KF_FRAG, L.AlF, n01); kf_stage_frag(sfr + 3 * KF_FRAG, L.S2F, n01);
+    // asynchronous copies (kf_stage_frag_async): the K tiles of the wave's first tile are computed underneath them, from the global
+    // copy of the scaled inducing inputs (the LDS copy becomes visible with the images, at kf_stage_wait)
+    kf_stage_frag_async(sfr, L.f[0].PF, n0); kf_stage_frag_async(sfr + KF_FRAG, L.f[1].PF, n1);
+    kf_stage_frag_async(sfr + 2 * KF_FRAG, L.AlF, n01); kf_stage_frag_async(sfr + 3 * KF_FRAG, L.S2F, n01);
     kf_stage_z(sz[0], L.f[0]); kf_stage_z(sz[1], L.f[1]);
-    __syncthreads();
   }
   const KfFrags F = {sfr, sfr + KF_FRAG, sfr + 2 * KF_FRAG, sfr + 3 * KF_FRAG, nullptr, nullptr, sz[0], sz[1]};
   const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
+  KfTile<NB0, NB1> t;
+  bool first = true;
+  if (w * a.tpw < t1) {
+    const int64_t pn = (int64_t)(w * a.tpw) * 16 + n;
+    kf_forward_ktiles<NB0, NB1, true>(t, L, L.f[0].Zs, L.f[1].Zs, a.X + (pn < a.N ? pn : 0) * a.ldx, pn < a.N, g);
+  }
+  kf_stage_wait();
   for (int tile = w * a.tpw; tile < t1; ++tile) {
     const int64_t pn = (int64_t)tile * 16 + n;
     const bool valid = pn < a.N;
-    KfTile<NB0, NB1> t;
-    kf_forward_tile<NB0, NB1, true>(t, L, F, a.X + (valid ? pn : 0) * a.ldx, valid, g, slot);
+    if (!first) kf_forward_ktiles<NB0, NB1, true>(t, L, F.Z0, F.Z1, a.X + (valid ? pn : 0) * a.ldx, valid, g);
+    first = false;
+    kf_forward_products<NB0, NB1, true>(t, L, F, slot);
     double q0 = 0.0, q1 = 0.0, mu = 0.0, st = 0.0;
 #pragma unroll
     for (int q = 0; q < 4 * NB0; ++q) {
@@ -364,11 +397,10 @@ k_kf_backward(KfArgs a) {
   double* sfr = lds + KF_WAVES * 4 * TILE;
   {
     constexpr int n0 = NB0 * NB0 * 256, n1 = NB1 * NB1 * 256, n01 = NB0 * NB1 * 256;
-    kf_stage_frag(sfr, f0.PF, n0); kf_stage_frag(sfr + KF_FRAG, f1.PF, n1);
-    kf_stage_frag(sfr + 2 * KF_FRAG, L.AlF, n01); kf_stage_frag(sfr + 3 * KF_FRAG, L.S2F, n01);
-    kf_stage_frag(sfr + 4 * KF_FRAG, L.AlTF, n01); kf_stage_frag(sfr + 5 * KF_FRAG, L.S2TF, n01);
+    kf_stage_frag_async(sfr, f0.PF, n0); kf_stage_frag_async(sfr + KF_FRAG, f1.PF, n1);
+    kf_stage_frag_async(sfr + 2 * KF_FRAG, L.AlF, n01); kf_stage_frag_async(sfr + 3 * KF_FRAG, L.S2F, n01);
+    kf_stage_frag_async(sfr + 4 * KF_FRAG, L.AlTF, n01); kf_stage_frag_async(sfr + 5 * KF_FRAG, L.S2TF, n01);
     kf_stage_z(sfr + 6 * KF_FRAG, f0); kf_stage_z(sfr + 6 * KF_FRAG + KF_MQ_ * MAXD, f1);
-    __syncthreads();
   }
   const KfFrags F = {sfr, sfr + KF_FRAG, sfr + 2 * KF_FRAG, sfr + 3 * KF_FRAG, sfr + 4 * KF_FRAG, sfr + 5 * KF_FRAG,
                      sfr + 6 * KF_FRAG, sfr + 6 * KF_FRAG + KF_MQ_ * MAXD};
@@ -398,12 +430,20 @@ k_kf_backward(KfArgs a) {
   }
 
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
+  KfTile<NB0, NB1> t;
+  bool first = true;
+  if (w * a.tpw < t1) {          // K tiles of the first tile under the asynchronous staging copies (global copy of the inducing inputs)
+    const int64_t pn = (int64_t)(w * a.tpw) * 16 + n;
+    kf_forward_ktiles<NB0, NB1, true>(t, L, f0.Zs, f1.Zs, a.X + (pn < a.N ? pn : 0) * a.ldx, pn < a.N, g);
+  }
+  kf_stage_wait();
   for (int tile = w * a.tpw; tile < t1; ++tile) {
     const int64_t pn = (int64_t)tile * 16 + n;
     const bool valid = pn < a.N;
     const double* xrow = a.X + (valid ? pn : 0) * a.ldx;
-    KfTile<NB0, NB1> t;
-    kf_forward_tile<NB0, NB1, true>(t, L, F, xrow, valid, g, slot);
+    if (!first) kf_forward_ktiles<NB0, NB1, true>(t, L, F.Z0, F.Z1, xrow, valid, g);
+    first = false;
+    kf_forward_products<NB0, NB1, true>(t, L, F, slot);
     const double gmn = L.gm[pn], gvn = L.gv[pn], dq0n = L.dq0[pn], dq1n = L.dq1[pn];   // zero for padding points (scale 0 in the point-wise kernel)
     double B1[Q1], C1[Q1], sq[Q0];
 #pragma unroll

@@ -8,6 +8,9 @@
 // LDS layout of the fragment images: P0 | P1 | Al | S2 | AlT | S2T, packed by the ACTUAL block counts
 // STAGE = false: a wave that owns only a tile or two reads the fragments straight from global memory (L2): staging would move the
 // same bytes once per workgroup and put a barrier in front of the first MFMA
+// The staged copy is ASYNCHRONOUS (kf_stage_frag_async): the caller computes the K tiles of its first tile, which need the inducing
+// inputs only, and then calls kf_stage_wait() -- in a minibatch step a wave owns one tile, and the 131 / 160 KB copy (8-10 k cycles)
+// used to sit in front of its 10 k cycles of K-tile arithmetic instead of under it.
 template <bool STAGE>
 __device__ __forceinline__ KfFrags kfl_stage_frags(double* lds, const KfLat& L, bool with_transposes) {
   if (!STAGE) { KfFrags G = {L.f[0].PF, L.f[1].PF, L.AlF, L.S2F, L.AlTF, L.S2TF, L.f[0].Zs, L.f[1].Zs}; return G; }
@@ -15,17 +18,16 @@ __device__ __forceinline__ KfFrags kfl_stage_frags(double* lds, const KfLat& L, 
   const int n0 = nb0 * nb0 * 256, n1 = nb1 * nb1 * 256, n01 = nb0 * nb1 * 256;
   double* p = lds;
   KfFrags F;
-  F.P0 = p; kf_stage_frag(p, L.f[0].PF, n0); p += n0;
-  F.P1 = p; kf_stage_frag(p, L.f[1].PF, n1); p += n1;
-  F.Al = p; kf_stage_frag(p, L.AlF, n01); p += n01;
-  F.S2 = p; kf_stage_frag(p, L.S2F, n01); p += n01;
+  F.P0 = p; kf_stage_frag_async(p, L.f[0].PF, n0); p += n0;
+  F.P1 = p; kf_stage_frag_async(p, L.f[1].PF, n1); p += n1;
+  F.Al = p; kf_stage_frag_async(p, L.AlF, n01); p += n01;
+  F.S2 = p; kf_stage_frag_async(p, L.S2F, n01); p += n01;
   F.AlT = nullptr; F.S2T = nullptr;
   F.Z0 = L.f[0].Zs; F.Z1 = L.f[1].Zs;      // global (L1-resident): the LDS of these kernels is full of fragment images
   if (with_transposes) {
-    F.AlT = p; kf_stage_frag(p, L.AlTF, n01); p += n01;
-    F.S2T = p; kf_stage_frag(p, L.S2TF, n01);
+    F.AlT = p; kf_stage_frag_async(p, L.AlTF, n01); p += n01;
+    F.S2T = p; kf_stage_frag_async(p, L.S2TF, n01);
   }
-  __syncthreads();
   return F;
 }
 
@@ -38,11 +40,19 @@ k_kfl_forward(KfArgs a) {
   const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
+  KfTile<NB0, NB1> t;
+  bool first = true;
+  if (w * a.tpw < t1) {          // K tiles of the first tile under the asynchronous staging copy
+    const int64_t pn = (int64_t)(w * a.tpw) * 16 + n;
+    kf_forward_ktiles<NB0, NB1, EXACT>(t, L, F.Z0, F.Z1, a.X + (pn < a.N ? pn : 0) * a.ldx, pn < a.N, g);
+  }
+  if (STAGE) kf_stage_wait();
   for (int tile = w * a.tpw; tile < t1; ++tile) {
     const int64_t pn = (int64_t)tile * 16 + n;
     const bool valid = pn < a.N;
-    KfTile<NB0, NB1> t;
-    kf_forward_tile<NB0, NB1, EXACT>(t, L, F, a.X + (valid ? pn : 0) * a.ldx, valid, g, slot);
+    if (!first) kf_forward_ktiles<NB0, NB1, EXACT>(t, L, F.Z0, F.Z1, a.X + (valid ? pn : 0) * a.ldx, valid, g);
+    first = false;
+    kf_forward_products<NB0, NB1, EXACT>(t, L, F, slot);
     double q0 = 0.0, q1 = 0.0, mu = 0.0, st = 0.0;
 #pragma unroll
     for (int q = 0; q < 4 * NB0; ++q) {
@@ -83,12 +93,20 @@ k_kfl_backward(KfArgs a) {
   const int Mq0 = 16 * nb0, Mq1 = 16 * nb1;
   const int64_t rec = 64 * (int64_t)(Mq0 + Mq1);
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
+  KfTile<NB0, NB1> t;
+  bool first = true;
+  if (w * a.tpw < t1) {          // K tiles of the first tile under the asynchronous staging copy
+    const int64_t pn = (int64_t)(w * a.tpw) * 16 + n;
+    kf_forward_ktiles<NB0, NB1, EXACT>(t, L, F.Z0, F.Z1, a.X + (pn < a.N ? pn : 0) * a.ldx, pn < a.N, g);
+  }
+  if (STAGE) kf_stage_wait();
   for (int tile = w * a.tpw; tile < t1; ++tile) {
     const int64_t pn = (int64_t)tile * 16 + n;
     const bool valid = pn < a.N;
     const double* xrow = a.X + (valid ? pn : 0) * a.ldx;
-    KfTile<NB0, NB1> t;
-    kf_forward_tile<NB0, NB1, EXACT>(t, L, F, xrow, valid, g, slot);
+    if (!first) kf_forward_ktiles<NB0, NB1, EXACT>(t, L, F.Z0, F.Z1, xrow, valid, g);
+    first = false;
+    kf_forward_products<NB0, NB1, EXACT>(t, L, F, slot);
     const double gmn = L.gm[pn], gvn = L.gv[pn], dq0n = L.dq0[pn], dq1n = L.dq1[pn];
     double* R = L.spill + (int64_t)tile * rec;
     double* R1 = R + 64 * Mq0;
