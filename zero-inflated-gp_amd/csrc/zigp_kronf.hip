@@ -1252,7 +1252,16 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       jb.AlF = L + LAT_ALF; jb.S2F = L + LAT_S2F; jb.AlTF = L + LAT_ALTF; jb.S2TF = L + LAT_S2TF;
       jb.klv = res(h) + RES_KLV;
     }
-    if (pl.large) hipLaunchKernelGGL(k_kfl_latent, dim3(nlat), dim3(1024), 0, c->stream, la);
+    if (pl.large) {
+      static bool attr = false;
+      if (!attr) {
+        ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_latent), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kfl_latent_lds(16 * 7)));
+        attr = true;
+      }
+      int mq1 = 0;
+      for (int h = 0; h < nlat; ++h) mq1 = std::max(mq1, la.job[h].Mq1);
+      hipLaunchKernelGGL(k_kfl_latent, dim3(nlat), dim3(1024), kfl_latent_lds(mq1), c->stream, la);
+    }
     else hipLaunchKernelGGL(k_kf_latent, dim3(nlat), dim3(1024), 0, c->stream, la);
     ZIGP_HIP(c, hipGetLastError());
   }

@@ -298,48 +298,62 @@ __device__ __forceinline__ void kf_frag_gmm(double* __restrict__ C, int ldc, con
   else kf_frag_gmm_cb<TB, TC, 1>(C, ldc, AF, nbr, ksn, B, ldb, ncb);
 }
 
-// global-operand twin of k_kf_latent (same job structure)
+// The latent stage of the larger grids (same job structure as k_kf_latent).  U, S2, T0, T1 and Alpha (16 x <= 112 each) live in LDS
+// while the kernel works on them and go out to global memory on the side (the reverse pass reads them): the first version kept them
+// in global memory only, and every phase began with an L2 round trip on what the phase before had just written -- 22.6 us for a few
+// hundred MFMAs.  P_p comes as fragment images from global memory as before (P1 is 100 KB at 100 points, read once).
+constexpr int KFL_LAT_ROWS = 16;      // Mq0 of the larger-grid plan (kf_plan: m0 <= 16)
+__host__ __device__ inline size_t kfl_latent_lds(int Mq1) { return sizeof(double) * 5 * KFL_LAT_ROWS * (size_t)(Mq1 + 1); }
 __global__ void __launch_bounds__(1024)
 k_kfl_latent(KfLatentArgs a) {
+  extern __shared__ double sm[];
   __shared__ double sh[16];
   const KfLatentJob& jb = a.job[blockIdx.x];
   const int t = threadIdx.x, M0 = jb.M0, M1 = jb.M1, Mq0 = jb.Mq0, Mq1 = jb.Mq1;
+  const int LD = Mq1 + 1, SZ = KFL_LAT_ROWS * LD;
+  double *sU = sm, *sS2 = sm + SZ, *sT0 = sm + 2 * SZ, *sT1 = sm + 3 * SZ, *sAl = sm + 4 * SZ;
   for (int idx = t; idx < Mq0 * Mq1; idx += 1024) {
     const int i = idx / Mq1, j = idx - i * Mq1;
     const bool in = i < M0 && j < M1;
-    const double sv = in ? jb.s[i * M1 + j] : 0.0;
-    jb.U[idx] = in ? jb.u[i * M1 + j] : 0.0;
-    jb.S2[idx] = sv * sv;
+    const double sv = in ? jb.s[i * M1 + j] : 0.0, uv = in ? jb.u[i * M1 + j] : 0.0;
+    sU[i * LD + j] = uv; sS2[i * LD + j] = sv * sv;
+    jb.U[idx] = uv; jb.S2[idx] = sv * sv;
   }
   __syncthreads();
-  kf_frag_gmm<true, true>(jb.T0, Mq1, jb.PF1, Mq1 / 16, Mq1 / 4, jb.U, Mq1, Mq0 / 16);     // T0^T = P1 U^T  (P1 symmetric)
-  kf_frag_gmm<false, false>(jb.T1, Mq1, jb.PF0, Mq0 / 16, Mq0 / 4, jb.U, Mq1, Mq1 / 16);   // T1 = P0 U
+  kf_frag_gmm<true, true>(sT0, LD, jb.PF1, Mq1 / 16, Mq1 / 4, sU, LD, Mq0 / 16);     // T0^T = P1 U^T  (P1 symmetric)
+  kf_frag_gmm<false, false>(sT1, LD, jb.PF0, Mq0 / 16, Mq0 / 4, sU, LD, Mq1 / 16);   // T1 = P0 U
   __syncthreads();
-  kf_frag_gmm<false, false>(jb.Al, Mq1, jb.PF0, Mq0 / 16, Mq0 / 4, jb.T0, Mq1, Mq1 / 16);  // Alpha = P0 (U P1)
+  kf_frag_gmm<false, false>(sAl, LD, jb.PF0, Mq0 / 16, Mq0 / 4, sT0, LD, Mq1 / 16);  // Alpha = P0 (U P1)
+  for (int idx = t; idx < Mq0 * Mq1; idx += 1024) {                                  // (T0, T1 are complete: out they go)
+    const int i = idx / Mq1, j = idx - i * Mq1;
+    jb.T0[idx] = sT0[i * LD + j]; jb.T1[idx] = sT1[i * LD + j];
+  }
   __syncthreads();
-  kf_write_frag(jb.AlF, Mq0 / 16, Mq1 / 4, t, 1024, jb.Al, Mq1, false);
-  kf_write_frag(jb.S2F, Mq0 / 16, Mq1 / 4, t, 1024, jb.S2, Mq1, false);
-  kf_write_frag(jb.AlTF, Mq1 / 16, Mq0 / 4, t, 1024, jb.Al, Mq1, true);
-  kf_write_frag(jb.S2TF, Mq1 / 16, Mq0 / 4, t, 1024, jb.S2, Mq1, true);
+  for (int idx = t; idx < Mq0 * Mq1; idx += 1024) { const int i = idx / Mq1, j = idx - i * Mq1; jb.Al[idx] = sAl[i * LD + j]; }
+  kf_write_frag(jb.AlF, Mq0 / 16, Mq1 / 4, t, 1024, sAl, LD, false);
+  kf_write_frag(jb.S2F, Mq0 / 16, Mq1 / 4, t, 1024, sS2, LD, false);
+  kf_write_frag(jb.AlTF, Mq1 / 16, Mq0 / 4, t, 1024, sAl, LD, true);
+  kf_write_frag(jb.S2TF, Mq1 / 16, Mq0 / 4, t, 1024, sS2, LD, true);
   double av = 0.0, bv = 0.0, cv = 0.0;
   for (int idx = t; idx < M0 * M1; idx += 1024) {
     const int i = idx / M1, j = idx - i * M1;
-    const int64_t o = (int64_t)i * Mq1 + j;
-    const double sv = jb.s[idx];
-    av = fma(jb.U[o], jb.Al[o], av);
-    bv += log(sv * sv);
-    cv = fma(jb.dvec0[i] * jb.dvec1[j], sv * sv, cv);
+    const double s2 = sS2[i * LD + j];
+    av = fma(sU[i * LD + j], sAl[i * LD + j], av);
+    bv += log(s2);
+    cv = fma(jb.dvec0[i] * jb.dvec1[j], s2, cv);
   }
-  double vals[3] = {av, bv, cv};
+  // the three scalars in one pass: wave sums, then 16 partials each in fixed order
+  __shared__ double sh3[3][16];
+  const double vals[3] = {av, bv, cv};
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    double v = wave_sum(vals[q]);
-    __syncthreads();
-    if ((t & 63) == 0) sh[t >> 6] = v;
-    __syncthreads();
-    if (t == 0) { double r = 0.0; for (int w = 0; w < 16; ++w) r += sh[w]; jb.klv[q] = r; }
+    const double v = wave_sum(vals[q]);
+    if ((t & 63) == 0) sh3[q][t >> 6] = v;
   }
+  __syncthreads();
+  if (t < 3) { double r = 0.0; for (int w = 0; w < 16; ++w) r += sh3[t][w]; jb.klv[t] = r; }
   if (t == 0) { jb.klv[3] = jb.dvec0[Mq0]; jb.klv[4] = jb.dvec1[Mq1]; }
+  (void)sh;
 }
 
 // C (m x n) [+]= op(A) op(B) for SMALL outputs with a long k: one output element per wave, the lanes split k (coalesced reads of the
