@@ -12,7 +12,8 @@
 //   k_kron_pointwise / k_kron_head_pointwise (zigp_kron.hip)                       (probit moments, likelihood, reverse pass)
 //   k_kf_backward recomputes the forward tile, hand-derived reverse pass; the sums over points (dAlpha, dS2, dP_p and the
 //                 kernel-cotangent moments) accumulate in MFMA accumulators across the wave's tiles -> one partial per wave
-//   k_kf_reduce   fixed-order sum of the per-wave partials
+//   k_kf_reduce   fixed-order sum of the per-wave partials (+ one workgroup for the sums of the point-wise block partials;
+//                 value-only steps launch k_kron_pw_reduce for those instead)
 //   k_kf_finish   one workgroup per latent: the M x M reverse pass (dU, dP_p -> dK_p -> dZ, dell, dvar; KL gradient)
 // plus ONE staged host->device copy (parameters + minibatch) and ONE device->host copy (results).
 #include "zigp_host.h"
