@@ -10,6 +10,7 @@ distance from the oracle of the same factored identities evaluated on the CPU wi
 DESIGN.md section 1)."""
 import os
 
+import mpmath as mp
 import numpy as np
 import pytest
 
@@ -32,12 +33,40 @@ def _pptr_params(grid):
     return Xtr, Ytr, np.ascontiguousarray(Xtr[idx]), np.ascontiguousarray(Ytr[idx]), p
 
 
-def _factored_elbo_and_grad_torch(X, Y, p_np, jitter, scale):
+def _inv_compensated():
+    """torch.linalg.inv whose reverse pass -P^T dP P^T is evaluated in 40-digit arithmetic and rounded once (forward: the plain LU
+    inverse).  That product is the one place where the factored reverse pass loses digits on an ill-conditioned factor
+    (tools/dd_experiment.py); the engine carries it in two-double arithmetic (kf_dd_mac, csrc/zigp_kronf.hip)."""
+    import torch
+
+    class Inv(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, K):
+            P = torch.linalg.inv(K)
+            ctx.save_for_backward(P)
+            return P
+
+        @staticmethod
+        def backward(ctx, dP):
+            (P,) = ctx.saved_tensors
+            with mp.workdps(40):
+                Pm, dPm = mp.matrix(P.numpy().tolist()), mp.matrix(dP.numpy().tolist())
+                G = -(Pm.T * dPm * Pm.T)
+                out = np.array([[float(G[i, j]) for j in range(G.cols)] for i in range(G.rows)])
+            return torch.as_tensor(out, dtype=P.dtype)
+
+    return Inv.apply
+
+
+def _factored_elbo_and_grad_torch(X, Y, p_np, jitter, scale, compensated=False):
     """The FACTORED identities the engine evaluates (DESIGN.md section 5b / SURVEY.md a10, a11), on the CPU in torch with the oracle's own
-    inverse (torch.linalg.inv, LU) and autograd: its distance from the literal dense order is what the op order alone costs."""
+    inverse (torch.linalg.inv, LU) and autograd: its distance from the literal dense order is what the op order alone costs.
+    compensated: the reverse pass of the inverse in 40 digits (_inv_compensated) -- the accurate evaluation of the same algebra, against
+    which the literal oracle's OWN float64 error on the ill-conditioned gradient blocks is measured."""
     import torch
     import zigp_oracle_torch as ot
     t = ot._t
+    inv = _inv_compensated() if compensated else torch.linalg.inv
     p = {k: [t(v).clone().requires_grad_(True) for v in p_np[k]] for k in ot.KRON_KEYS}
     for k in ot.KRON_VEC_KEYS:
         p[k] = t(p_np[k]).clone().requires_grad_(True)
@@ -47,7 +76,7 @@ def _factored_elbo_and_grad_torch(X, Y, p_np, jitter, scale):
         Z, ell, var = p['Z' + tag], p['ell_' + tag], p['var_' + tag]
         M0, M1 = Z[0].shape[0], Z[1].shape[0]
         K = [ot.rbf_K(Z[q], None, ell[q], var[q]) + torch.eye(Z[q].shape[0], dtype=ot.DT) * jitter for q in range(2)]
-        P = [torch.linalg.inv(Kq) for Kq in K]
+        P = [inv(Kq) for Kq in K]
         d0 = Z[0].shape[1]
         k0, k1 = ot.rbf_K(Z[0], Xt[:, :d0], ell[0], var[0]), ot.rbf_K(Z[1], Xt[:, d0:], ell[1], var[1])
         U, S2 = p['u_%sm' % tag].reshape(M0, M1), torch.square(p['u_%ss_sqrt' % tag]).reshape(M0, M1)
@@ -84,6 +113,12 @@ def _conds(p, jit):
 
 @pytest.mark.parametrize('grid', [(32, 32), (10, 100)])
 def test_pptr_init_minibatch_gradient_matches_literal_oracle(engine, grid):
+    """Full gradient of a 1000-row minibatch step at the pptr init.  Tolerance 1e-6 (north_star) against the literal oracle -- except
+    where the ORACLE's own float64 error is larger: at 32 x 32 (cond(K_s) = 5e7) the literal order itself is only good to ~1e-3 on
+    d / d Z_s.  Its error is measured against the accurate evaluation of the same algebra (CPU, reverse pass of the inverse in 40
+    digits), and the GPU must (i) be at least as close to that evaluation as the oracle is, (ii) differ from the oracle by no more than
+    2x the oracle's own error.  (Rounds 2-3 allowed 3x the distance of a float64 CPU evaluation of the factored algebra instead: the
+    engine was then less accurate than the reference's op order on those blocks)"""
     import zigp_oracle_torch as ot
     Xtr, Ytr, xb, yb, p = _pptr_params(grid)
     jit, scale = 1e-5, Xtr.shape[0] / 1000.0                                  # scripts/onoff.py:18,311
@@ -91,21 +126,25 @@ def test_pptr_init_minibatch_gradient_matches_literal_oracle(engine, grid):
     ed, kl, g = engine.kron_elbo(p, xb, yb, jitter=jit, scale=scale)
     e_r, d_r, kl_r, g_r = ot.kron_elbo_and_grad(xb, yb, p, jit, scale=scale)
     e_c, d_c, kl_c, g_c = _factored_elbo_and_grad_torch(xb, yb, p, jit, scale)
+    e_a, d_a, kl_a, g_a = _factored_elbo_and_grad_torch(xb, yb, p, jit, scale, compensated=True)
     print('  data term: gpu %.12e oracle %.12e (rel %.2e; CPU factored %.2e)   KL: gpu %.10e oracle %.10e (rel %.2e; CPU factored %.2e)'
           % (ed, scale * d_r, abs(ed - scale * d_r) / abs(scale * d_r), abs(scale * d_c - scale * d_r) / abs(scale * d_r),
              kl, kl_r, abs(kl - kl_r) / abs(kl_r), abs(kl_c - kl_r) / abs(kl_r)))
-    assert abs(ed - scale * d_r) <= max(1e-6, 3 * abs(d_c - d_r) / abs(d_r)) * abs(scale * d_r)
+    assert abs(ed - scale * d_r) <= 1e-6 * abs(scale * d_r)
     assert abs(kl - kl_r) <= 1e-7 * abs(kl_r)
-    worst = 0.0
+    worst = worst_a = 0.0
     for k in ('Zf', 'Zg', 'ell_f', 'ell_g', 'var_f', 'var_g', 'u_fm', 'u_gm', 'u_fs_sqrt', 'u_gs_sqrt', 'noise'):
-        a_, b_, c_ = g[k], g_r[k], g_c[k]
-        for q, (a, b, c) in enumerate(zip(a_, b_, c_) if isinstance(b_, list) else ((a_, b_, c_),)):
-            e_gpu, floor = relerr(np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)), relerr(np.asarray(c).reshape(-1), np.asarray(b).reshape(-1))
-            worst = max(worst, e_gpu)
-            print('  grad %-10s[%d] gpu vs oracle %.2e   op-order floor (CPU factored + autograd) %.2e   max|ref| %.3e'
-                  % (k, q, e_gpu, floor, np.max(np.abs(np.asarray(b)))))
-            assert e_gpu < max(1e-6, 3.0 * floor), (k, q, e_gpu, floor)
-    print('  worst gradient block vs oracle: %.2e' % worst)
+        a_, b_, c_, d_ = g[k], g_r[k], g_c[k], g_a[k]
+        for q, (a, b, c, d) in enumerate(zip(a_, b_, c_, d_) if isinstance(b_, list) else ((a_, b_, c_, d_),)):
+            a, b, c, d = (np.asarray(v).reshape(-1) for v in (a, b, c, d))
+            e_gpu, fac64 = relerr(a, b), relerr(c, b)
+            e_gpu_acc, e_orc_acc = relerr(a, d), relerr(b, d)
+            worst, worst_a = max(worst, e_gpu), max(worst_a, e_gpu_acc)
+            print('  grad %-10s[%d] gpu vs oracle %.2e | vs the accurate evaluation: gpu %.2e, literal oracle %.2e | float64 CPU factored vs oracle %.2e   max|ref| %.3e'
+                  % (k, q, e_gpu, e_gpu_acc, e_orc_acc, fac64, np.max(np.abs(b))))
+            assert e_gpu < max(1e-6, 2.0 * e_orc_acc), (k, q, e_gpu, e_orc_acc)
+            assert e_gpu_acc < max(1e-6, e_orc_acc), (k, q, e_gpu_acc, e_orc_acc)
+    print('  worst gradient block: vs oracle %.2e, vs the accurate evaluation %.2e' % (worst, worst_a))
 
 
 @pytest.mark.parametrize('grid', [(32, 32), (10, 100)])
@@ -134,8 +173,6 @@ def test_pptr_init_predict_9tuple_matches_literal_oracle(engine, grid):
     # the moments downstream of (mean, var) inherit their error, no more
     assert max(errs) < max(1e-6, 3.0 * max(errs[3:7]))
 
-
-import mpmath as mp
 
 
 def _mp_latent(X, Z, ell, var, u, s, jit):
@@ -198,8 +235,8 @@ def test_pptr_init_illconditioned_gradient_entries_against_40_digit_differences(
     is determined to ~1e-2 only in float64: the literal dense oracle and the factored identities (both on the CPU, both with an LU
     inverse) differ by that much.  Truth for a handful of entries: central differences of the ELBO evaluated in 40-digit arithmetic
     (100 rows).  CPU dry run: on the largest dZ_s entry of f the literal order is off by 4e-5 and the factored identities by 2e-3 (the
-    explicit K_s^-1 enters the reverse pass twice); the lengthscale entries by 1e-8 .. 2e-7.  The GPU (factored, Cholesky) must be
-    within 1e-6, or as close as the oracle (x10), or as close as the CPU evaluation of its own algebra (x3) -- the numbers are printed."""
+    explicit K_s^-1 enters the reverse pass twice); the lengthscale entries by 1e-8 .. 2e-7.  The GPU carries that product in two-double
+    arithmetic (round 4) and must be within 1e-7 or AT LEAST AS CLOSE AS THE LITERAL ORACLE on every probed entry -- the numbers are printed."""
     import zigp_oracle_torch as ot
     Xtr, Ytr, xb, yb, p = _pptr_params((32, 32))
     n, jit, scale = 100, 1e-5, 7.0
@@ -208,6 +245,7 @@ def test_pptr_init_illconditioned_gradient_entries_against_40_digit_differences(
     ed, kl, g = engine.kron_elbo(p, X, Y, jitter=jit, scale=scale)
     e_r, d_r, kl_r, g_r = ot.kron_elbo_and_grad(X, Y, p, jit, scale=scale)
     e_c, d_c, kl_c, g_c = _factored_elbo_and_grad_torch(X, Y, p, jit, scale)
+    e_a, d_a, kl_a, g_a = _factored_elbo_and_grad_torch(X, Y, p, jit, scale, compensated=True)   # the yardstick of the minibatch test, validated here
     noise = float(np.squeeze(p['noise']))
 
     def latent(pp, tag):
@@ -240,13 +278,14 @@ def test_pptr_init_illconditioned_gradient_entries_against_40_digit_differences(
                 vals[sgn] = elbo_mp(pp, tag)
             truth = float((vals[+1] - vals[-1]) / (2 * h))
             if what == 'Z':
-                got, orc, fac = g['Z' + tag][0][iz], g_r['Z' + tag][0][iz], g_c['Z' + tag][0][iz]
+                got, orc, fac, acc = g['Z' + tag][0][iz], g_r['Z' + tag][0][iz], g_c['Z' + tag][0][iz], g_a['Z' + tag][0][iz]
             else:
-                got, orc, fac = g['ell_' + tag][0][0], g_r['ell_' + tag][0][0], g_c['ell_' + tag][0][0]
-            e_gpu, e_orc, e_fac = abs(got - truth) / abs(truth), abs(orc - truth) / abs(truth), abs(fac - truth) / abs(truth)
-            print('  d ELBO / d %s_%s[0]%s = %.10e (40-digit differences): gpu off by %.2e, literal oracle %.2e, CPU factored %.2e'
-                  % (what, tag, list(iz) if what == 'Z' else '[0]', truth, e_gpu, e_orc, e_fac))
-            assert e_gpu < max(1e-6, 10 * e_orc, 3 * e_fac), (tag, what, e_gpu, e_orc, e_fac)
+                got, orc, fac, acc = g['ell_' + tag][0][0], g_r['ell_' + tag][0][0], g_c['ell_' + tag][0][0], g_a['ell_' + tag][0][0]
+            e_gpu, e_orc, e_fac, e_acc = (abs(v - truth) / abs(truth) for v in (got, orc, fac, acc))
+            print('  d ELBO / d %s_%s[0]%s = %.10e (40-digit differences): gpu off by %.2e, literal oracle %.2e, CPU factored float64 %.2e, '
+                  'CPU factored with the compensated inverse reverse pass %.2e' % (what, tag, list(iz) if what == 'Z' else '[0]', truth, e_gpu, e_orc, e_fac, e_acc))
+            assert e_acc < max(1e-7, e_orc), (tag, what, e_acc, e_orc)      # the yardstick is at least as good as the oracle
+            assert e_gpu < max(1e-7, e_orc), (tag, what, e_gpu, e_orc, e_fac)          # no less accurate than the reference's op order
 
 
 class _Perturbed:

@@ -837,6 +837,58 @@ __device__ __forceinline__ void kf_lds_mm_seq(double* C, const double* A, const 
     if (ACC) C[i * KF_SLD + j] += v; else C[i * KF_SLD + j] = v;
   }
 }
+// ---- compensated (two-double) products for the P_p sandwich of the reverse pass -------------------------------------------------
+// dK_p = -P_p sym(dP_p) P_p is where the factored reverse pass loses its digits on an ill-conditioned factor: the entries of P_p = K_p^-1
+// are ~cond(K_p) / var in size with alternating signs and the products cancel down to the gradient.  CPU experiment with a working
+// precision per stage (tools/dd_experiment.py; pptr init, 32 x 32 grid, cond(K_s) = 5e7, largest d ELBO / d Z_s entry): everything in
+// float64 1.7e-3; THESE TWO PRODUCTS carried in twice the precision (inputs and result plain float64) 1.1e-8; nothing else matters
+// (the inverse itself, Alpha, the sums over points, the reductions against K_p: unchanged results in 106 bits).  Error-free
+// transformations: Knuth's two-sum, the FMA two-product; the running sum is (hi, lo), lo collects every rounding error (Ogita, Rump &
+// Oishi's Dot2: the result is as accurate as if computed in doubled precision and rounded once).  Contraction must stay off inside.
+__device__ __forceinline__ void kf_dd_mac(double& sh, double& sl, double a, double b) {          // (sh, sl) += a b
+#pragma clang fp contract(off)
+  const double p = a * b;
+  const double e = __builtin_fma(a, b, -p);
+  const double s = sh + p;
+  const double bb = s - sh;
+  const double err = (sh - (s - bb)) + (p - bb);
+  sh = s;
+  sl += err + e;
+}
+__device__ __forceinline__ void kf_dd_mac2(double& sh, double& sl, double a, double bh, double bl) {   // (sh, sl) += a (bh + bl)
+#pragma clang fp contract(off)
+  const double p = a * bh;
+  const double e = __builtin_fma(a, bl, __builtin_fma(a, bh, -p));
+  const double s = sh + p;
+  const double bb = s - sh;
+  const double err = (sh - (s - bb)) + (p - bb);
+  sh = s;
+  sl += err + e;
+}
+// (Ch, Cl) = A B, one thread per element, A / B float64 LDS images (row stride KF_SLD); result normalised (|Cl| <= ulp(Ch) / 2)
+__device__ __forceinline__ void kf_lds_mm_dd(double* Ch, double* Cl, const double* A, const double* B, int m, int n, int k) {
+  for (int idx = threadIdx.x; idx < m * n; idx += blockDim.x) {
+    const int i = idx / n, j = idx - i * n;
+    double sh = 0.0, sl = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < k; ++q) kf_dd_mac(sh, sl, A[i * KF_SLD + q], B[q * KF_SLD + j]);
+    const double h = sh + sl;
+    Ch[i * KF_SLD + j] = h;
+    Cl[i * KF_SLD + j] = sl - (h - sh);
+  }
+}
+// G = -(A (Bh + Bl)) - coef A2, rounded once to float64 (A2 = the matrix whose multiple is subtracted: P_p, KL logdet term)
+__device__ __forceinline__ void kf_lds_mm_dd2_neg(double* G, const double* A, const double* Bh, const double* Bl, const double* A2, double coef, int m, int n,
+                                                  int k) {
+  for (int idx = threadIdx.x; idx < m * n; idx += blockDim.x) {
+    const int i = idx / n, j = idx - i * n;
+    double sh = 0.0, sl = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < k; ++q) kf_dd_mac2(sh, sl, A[i * KF_SLD + q], Bh[q * KF_SLD + j], Bl[q * KF_SLD + j]);
+    kf_dd_mac(sh, sl, coef, A2[i * KF_SLD + j]);
+    G[i * KF_SLD + j] = -(sh + sl);
+  }
+}
 __device__ __forceinline__ void kf_lds_load(double* dst, const double* __restrict__ src, int rows, int cols, int ld) {
   for (int idx = threadIdx.x; idx < rows * cols; idx += blockDim.x) { const int i = idx / cols, j = idx - i * cols; dst[i * KF_SLD + j] = src[(int64_t)i * ld + j]; }
 }
@@ -999,15 +1051,12 @@ k_kf_finish(KfFinishArgs a) {
     sX[i * KF_SLD + j] = v;
   }
   __syncthreads();
-  kf_lds_mm<false, false, false>(sQ, sX, sP, Mq, Mq, Mq);      // Q = sym(dP) P
+  // G = -P sym(dP) P - coef P in compensated arithmetic (kf_dd_mac, above): Q = sym(dP) P as (hi, lo) -- lo in the dead dP buffer --
+  // then P (Q_hi + Q_lo) + coef P summed in (hi, lo) and rounded once
+  kf_lds_mm_dd(sQ, sdP, sX, sP, Mq, Mq, Mq);
   __syncthreads();
   const double coef = kl ? 0.5 * (double)Mo : 0.0;
-  kf_lds_mm<false, false, false>(sG, sP, sQ, Mq, Mq, Mq);      // P Q
-  __syncthreads();
-  for (int idx = t; idx < Mq * Mq; idx += 1024) {              // G = -P Q - coef P
-    const int i = idx / Mq, j = idx - i * Mq;
-    sG[i * KF_SLD + j] = -sG[i * KF_SLD + j] - coef * sP[i * KF_SLD + j];
-  }
+  kf_lds_mm_dd2_neg(sG, sP, sQ, sdP, sP, coef, Mq, Mq, Mq);
   __syncthreads();
   // krow[m][c]: Kuu part (as k_kuu_grad, Kz = K_p - jitter I) + data moments rebuilt around z_m
   // eight lanes per (m, c) entry sweep j (fixed-order tree over the eight partial sums)

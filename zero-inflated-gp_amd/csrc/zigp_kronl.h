@@ -517,6 +517,20 @@ k_kfl_finish(KflFinishArgs a) {
       Xs[r * xs + c] = v;
     }
     __syncthreads();
+    if (p == 0) {
+      // the factor of <= 16 points (the spatial one: the factor the reference's initialisation makes ill-conditioned, scripts/onoff.py:57-66)
+      // takes the compensated sandwich of the small grids (kf_dd_mac, zigp_kronf.hip): Q2 = X P as (hi, lo), lo in the unused rows 16..31
+      // of this factor's Q region.  The <= 112-point factor stays in float64 (cond(K_t) = 1.5 at the reference's lengthscale).
+      for (int idx = t; idx < Mq * Mq; idx += KFL_FIN_THREADS) {
+        const int i = idx / Mq, j = idx - i * Mq;
+        double sh = 0.0, sl = 0.0;
+        for (int q = 0; q < Mq; ++q) kf_dd_mac(sh, sl, Xs[i * xs + q], P[q * Mq + j]);
+        const double h = sh + sl;
+        G[i * ldw + j] = h;
+        Q[(16 + i) * ldw + j] = sl - (h - sh);
+      }
+      return;
+    }
     kf_rowblock_mm(Mq, Mq, [&](int r, int q) { return Xs[r * xs + q]; }, P, Mq, [&](int r, int j, double v) { G[(R + r) * ldw + j] = v; });   // Q2 -> G region
     return;
   }
@@ -525,11 +539,22 @@ k_kfl_finish(KflFinishArgs a) {
   for (int idx = t; idx < 16 * Mq; idx += KFL_FIN_THREADS) { const int r = idx / Mq, c = idx - r * Mq; Xs[r * xs + c] = P[(R + r) * Mq + c]; }
   __syncthreads();
   double* Gm = Q;     // the KL product is dead: G rows go there
-  kf_rowblock_mm(Mq, Mq, [&](int r, int q) { return Xs[r * xs + q]; }, G, ldw, [&](int r, int j, double v) { Gm[(R + r) * ldw + j] = v; });     // G = P Q2
+  const double coef = kl ? 0.5 * (double)Mo : 0.0;
+  if (p == 0) {       // compensated: Gm = -(P (Q2_hi + Q2_lo) + coef P), rounded once
+    const double* Ql = Q + 16 * ldw;
+    for (int idx = t; idx < Mq * Mq; idx += KFL_FIN_THREADS) {
+      const int i = idx / Mq, j = idx - i * Mq;
+      double sh = 0.0, sl = 0.0;
+      for (int q = 0; q < Mq; ++q) kf_dd_mac2(sh, sl, Xs[i * xs + q], G[q * ldw + j], Ql[q * ldw + j]);
+      kf_dd_mac(sh, sl, coef, Xs[i * xs + j]);
+      Gm[i * ldw + j] = -(sh + sl);
+    }
+  } else {
+    kf_rowblock_mm(Mq, Mq, [&](int r, int q) { return Xs[r * xs + q]; }, G, ldw, [&](int r, int j, double v) { Gm[(R + r) * ldw + j] = v; });     // G = P Q2
+  }
   __syncthreads();
   // krow[m][c]: Kuu part (as k_kuu_grad, Kz = K_p - jitter I) + data moments rebuilt around z_m.  A wave owns row m, its lanes sweep the
   // columns j (coalesced rows of G, P, K_p), fixed-order wave sums
-  const double coef = kl ? 0.5 * (double)Mo : 0.0;
   const int W = 2 + 2 * D;
   const int lane = t & 63;
   for (int m = R + (t >> 6); m < min(R + 16, M); m += KFL_FIN_THREADS / 64) {
@@ -538,7 +563,7 @@ k_kfl_finish(KflFinishArgs a) {
     for (int d = 0; d < MAXD; ++d) { s1[d] = 0.0; s2[d] = 0.0; zm[d] = d < D ? Z[m * D + d] : 0.0; }
     for (int j = lane; j < M; j += 64) {
       const double kz = Kuu[m * PB + j] - ((m == j) ? a.jitter : 0.0);
-      const double tt = (-Gm[m * ldw + j] - coef * P[m * Mq + j]) * kz;
+      const double tt = (p == 0 ? Gm[m * ldw + j] : -Gm[m * ldw + j] - coef * P[m * Mq + j]) * kz;
       s0 += tt;
 #pragma unroll
       for (int d = 0; d < MAXD; ++d)
