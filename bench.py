@@ -12,8 +12,11 @@ exec) and exits with its return code; under an external torch.distributed.run it
   --scaling weak   (default) every rank holds its own --rows shard (N=8: cfg4, 8e6 rows); `value` counts 1e6-row ELBO steps
                    per second summed over ranks
   --scaling strong the --rows rows are split over the ranks (zigp.parallel.shard_bounds); `value` = steps/s of that one job
-Each step ends with ONE all-reduce of the packed [ELBO, KL, gradient] vector: with --backend nccl inside libzigp.so (ncclAllReduce on the
-device vector, zigp_comm_init -- RCCL over xGMI; torch.distributed carries the communicator id, the barriers and the MAX of the times).
+Each step ends with ONE all-reduce of the packed [ELBO, KL, gradient] vector (~82 KB): --exchange torch (default) through torch.distributed
+(backend nccl = RCCL over xGMI on a device tensor), --exchange library inside libzigp.so (ncclAllReduce on the packed device vector,
+zigp_comm_init).  With more than one rank the library exchange is additionally CHECKED after the timed region (one step through it, compared
+with the torch.distributed sums, under a watchdog) and the outcome is part of the JSON line: `library_exchange_check`.
+`--gpus 1 --force-dist` runs this exact multi-rank code path (process group + communicator in one process) with one rank.
 
 The timed region runs with kernel event timing OFF and the side-stream overlap ON (the fast configuration); the per-kernel
 numbers behind `roofline` come from a separate short profiled pass after it (every launch timed, single stream).
@@ -136,6 +139,68 @@ def live_pmc_traffic(dom_kernel, M, D, chunk, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def headline(args, world, total_rows, dt):
+    return {'metric': 'elbo_steps_per_sec', 'value': args.steps / dt * (total_rows / 1e6), 'unit': 'ELBO steps/s (value+gradient, 1e6-row steps, fp64)',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic'}
+
+
+def library_exchange_check(eng, dist, red_dev, p, jitter, scale, ref_out, rank, dt, args, world, total_rows, limit_s=150.0):
+    """One step through ncclAllReduce inside libzigp.so (zigp_comm_init) compared with the sums torch.distributed produced for the same
+    step, plus a short timing of that path.  Returns a dict for the JSON line.  A hang anywhere inside ends the process after limit_s:
+    rank 0 first prints the headline it already has (with the check marked as timed out), every rank exits 0."""
+    import threading
+    import torch
+    from zigp.parallel import ShardedELBO, pack
+    done = threading.Event()
+
+    def overrun():
+        if done.is_set():
+            return
+        if rank == 0:
+            res = headline(args, world, total_rows, dt)
+            res['config'] = {'workload': 'dense zero-inflated GP ELBO step (value+gradient), see bench.py', 'rows_total': total_rows, 'M': args.M, 'D': args.D}
+            res['library_exchange_check'] = {'status': 'TIMED OUT after %.0f s inside the library-exchange check (after the timed region); '
+                                                       'the headline above is the torch.distributed exchange' % limit_s}
+            print(json.dumps(res))
+            sys.stdout.flush()
+        os._exit(0)
+
+    timer = threading.Timer(limit_s, overrun)
+    timer.daemon = True
+    timer.start()
+    info = {}
+    try:
+        eng.comm_set_timeout(45.0)
+        shl = ShardedELBO(eng, dist, device=red_dev, library_comm=True)
+        if not shl.library_comm:
+            info = {'status': 'not formed: the ranks agreed to stay on torch.distributed (RCCL not loadable, zigp_comm_init failed / timed out, or the self-check sum was wrong)'}
+        else:
+            got = shl.elbo(p, jitter=jitter, scale=scale)
+            va, _ = pack(got[0], got[1], got[2])
+            vb, _ = pack(ref_out[0], ref_out[1], ref_out[2])
+            rel = float(np.max(np.abs(va - vb)) / max(float(np.max(np.abs(vb))), 1e-300))
+            rel_e = abs(got[0] - ref_out[0]) / abs(ref_out[0])
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.time()
+            nrep = 3
+            for _ in range(nrep):
+                shl.elbo(p, jitter=jitter, scale=scale)
+            torch.cuda.synchronize(); dist.barrier()
+            tl = (time.time() - t0) / nrep
+            info = {'status': 'ok' if rel <= 1e-12 and rel_e <= 1e-12 else 'MISMATCH', 'ranks': dist.get_world_size(),
+                    'elbo_data_rel_diff': rel_e, 'packed_vector_max_rel_diff': rel,
+                    'allreduce_calls_in_library': eng.comm_info()['allreduce_calls'], 'ms_per_step_library_exchange': tl * 1e3,
+                    'what': 'one step through ncclAllReduce inside libzigp.so vs the same step through torch.distributed all_reduce (sum order '
+                            'may differ between the two collectives: 1e-12)'}
+            shl.close()
+    except Exception as e:       # never lose the headline over the check
+        info = {'status': 'error: %r' % (e,)}
+    done.set()
+    timer.cancel()
+    return info
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -164,6 +229,23 @@ def timeit(f, n, warm):
     return (time.time() - t0) / n
 
 
+def kron_fused_products(nb0, nb1, large):
+    """16x16x4 MFMA products the fused Kronecker kernels EXECUTE per 16-point tile and latent (forward kernel + backward kernel, which
+    recomputes the forward tile), for a grid of nb0 x nb1 16-row blocks (csrc/zigp_kronf.hip, zigp_kronl.h):
+    forward A0, A1, B0, C0; backward + B1, C1, P0 dA0, P1 dA1, the sums over points dAlpha, dS2, dP0, dP1 and the moment products."""
+    fwd = 4 * (nb0 * nb0 + nb1 * nb1 + 2 * nb0 * nb1)
+    bwd = fwd + 2 * 4 * nb0 * nb1 + 4 * (nb0 * nb0 + nb1 * nb1) + 4 * (2 * nb0 * nb1 + nb0 * nb0 + nb1 * nb1) + 4 * (nb0 + nb1)
+    return fwd + bwd
+
+
+def kron_roofline(n_rows, t, nb0, nb1, large=False):
+    """cfg5-style entries: the path is MFMA / VALU-issue bound, not HBM bound -- executed matrix flops over the step"""
+    tiles = (n_rows + 15) // 16
+    fl = 2.0 * tiles * kron_fused_products(nb0, nb1, large) * 2048.0        # two latents; a 16x16x4 product = 2048 flop
+    return dict(executed_mfma_flops=fl, tflops=fl / t / 1e12, frac_mfma=fl / t / PEAK_FP64_MFMA,
+                bound='mfma/valu issue (fp64 MFMA and VALU serialise on a SIMD); launch latency at minibatch size')
+
+
 def other_configs(eng, X3, Y3, p3, jitter):
     """The other BASELINE.json configurations and SURVEY section 8d's 'reported separately' numbers, each well under a second
     (N=1 only; `value` above is cfg3 value+gradient)."""
@@ -175,6 +257,16 @@ def other_configs(eng, X3, Y3, p3, jitter):
     npred = min(262144, N3)
     t = timeit(lambda: eng.predict(p3, X3[:npred], jitter=jitter), 2, 1)
     out['cfg3_predict'] = dict(rows=npred, ms=t * 1e3, rows_per_s=npred / t, note='host X in, (9,N) host out: PCIe-inclusive')
+    # the per-rank step of cfg3 under 8-GPU STRONG scaling (1e6 / 8 rows, the replicated M x M stage in full), timed on this one GPU
+    if N3 >= 8 and M3 >= 128:
+        n8 = N3 // 8
+        eng.set_data(X3[:n8], Y3[:n8])
+        t8 = timeit(lambda: eng.elbo(p3, jitter=jitter), 5, 2)
+        out['strong_1of8'] = dict(workload='rows [0, %d) of the headline workload (its 1/8 shard), M=%d, value+gradient: what each rank runs under '
+                                           '8-GPU strong scaling' % (n8, M3), ms_per_step=t8 * 1e3,
+                                  allreduce_us_assumed=50.0,
+                                  note='projected_8gpu_speedup (top level) = ms_per_step / (this + the assumed all-reduce): arithmetic on two '
+                                       'one-GPU measurements, NOT a measured 8-GPU run; the all-reduce of the 82 KB vector is assumed, never measured here')
     # cfg2: N=1e5, M=512
     X2, Y2, p2 = synth(100000, 512, 3)
     eng.set_data(X2, Y2)
@@ -196,20 +288,24 @@ def other_configs(eng, X3, Y3, p3, jitter):
         t = timeit(lambda: st(pk, rows=(0, n5), jitter=1e-5), 20, 3)
         # algorithmic bytes: X 24 B + Y 8 B per point read per pass; two passes (value, gradient)
         out['cfg5_full'] = dict(workload='pptr N=%d, 32x32, value+gradient, data resident in HBM' % n5, ms_per_step=t * 1e3,
-                                rows_per_s=n5 / t, algorithmic_GBps=2 * 32.0 * n5 / t / 1e9, frac_hbm=2 * 32.0 * n5 / t / PEAK_HBM)
+                                rows_per_s=n5 / t, algorithmic_GBps=2 * 32.0 * n5 / t / 1e9, frac_hbm=2 * 32.0 * n5 / t / PEAK_HBM,
+                                **kron_roofline(n5, t, 2, 2))
         t = timeit(lambda: st(pk, Xtr, Ytr, jitter=1e-5), 10, 2)
         out['cfg5_full']['ms_per_step_host_minibatch_in'] = t * 1e3      # PCIe-inclusive: X, Y (3.4 MB) staged and copied every step
         xb, yb = Xtr[:1000], Ytr[:1000]
         t = timeit(lambda: st(pk, xb, yb, jitter=1e-5, scale=n5 / 1000.0), 50, 5)
         t_generic = timeit(lambda: eng.kron_elbo(pk, xb, yb, jitter=1e-5, scale=n5 / 1000.0), 50, 5)
         out['cfg5_mb1000'] = dict(workload='pptr minibatch 1000 (scripts/onoff.py:55), 32x32', ms_per_step=t * 1e3, steps_per_s=1 / t,
-                                  ms_per_step_unprepared_call=t_generic * 1e3)
+                                  ms_per_step_unprepared_call=t_generic * 1e3, **kron_roofline(1000, t, 2, 2))
         np.random.seed(0)
         pk2 = engine_params(init_params(Xtr, (10, 100), (10, 100), kmeans_seed=1))
         st2 = eng.kron_stepper(pk2)
         t = timeit(lambda: st2(pk2, xb, yb, jitter=1e-5, scale=n5 / 1000.0), 50, 5)
         out['ref_grid_10x100_mb1000'] = dict(workload='pptr minibatch 1000, the reference\'s [10,100] grid (scripts/onoff.py:52-53)',
-                                              ms_per_step=t * 1e3, steps_per_s=1 / t)
+                                              ms_per_step=t * 1e3, steps_per_s=1 / t, **kron_roofline(1000, t, 1, 7, True))
+        t = timeit(lambda: st2(pk2, rows=(0, n5), jitter=1e-5), 10, 2)
+        out['ref_grid_10x100_full'] = dict(workload='pptr N=%d full batch, the reference\'s [10,100] grid, value+gradient, data resident' % n5,
+                                            ms_per_step=t * 1e3, rows_per_s=n5 / t, **kron_roofline(n5, t, 1, 7, True))
         t = timeit(lambda: eng.kron_predict(pk, Xtr, jitter=1e-6, g_offset=-1.0), 3, 1)
         out['cfg5_predict'] = dict(rows=n5, ms=t * 1e3, rows_per_s=n5 / t)
     except Exception as e:   # the Kronecker numbers are extras: never lose the headline line over them
@@ -234,6 +330,10 @@ def main():
     ap.add_argument('--profile-steps', type=int, default=1, help='steps of the separate profiled pass (0: none)')
     ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL, the default) or 'gloo' to rehearse the multi-rank path on fewer GPUs than ranks")
     ap.add_argument('--cpu-sample-rows', type=int, default=60000)
+    ap.add_argument('--exchange', choices=('torch', 'library'), default='torch',
+                    help="where the per-step all-reduce runs: torch.distributed on the packed vector (default) or ncclAllReduce inside libzigp.so")
+    ap.add_argument('--force-dist', action='store_true', help='with --gpus 1: still initialise the process group and run the multi-rank code path with one rank')
+    ap.add_argument('--no-library-check', action='store_true', help='skip the post-timing check of the library exchange against the torch.distributed sums')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -249,7 +349,12 @@ def main():
     dist = None
     ndev = max(torch.cuda.device_count(), 1)
     dev = local_rank % ndev          # a gloo rehearsal may put several ranks on one GPU
-    if world > 1:
+    if world == 1 and args.force_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         torch.cuda.set_device(dev)
         if args.backend == 'nccl':
@@ -284,7 +389,7 @@ def main():
     Yd = torch.from_numpy(Y).to('cuda:%d' % dev)
     eng.set_data_device(Xd, Yd)               # inputs resident in HBM before timing
     red_dev = ('cuda:%d' % dev) if args.backend == 'nccl' else 'cpu'
-    sh = ShardedELBO(eng, dist, device=red_dev)
+    sh = ShardedELBO(eng, dist, device=red_dev, library_comm=(args.exchange == 'library' and args.backend == 'nccl'))
     scale = 1.0
 
     def barrier():
@@ -298,30 +403,43 @@ def main():
     for _ in range(args.warmup):
         out = sh.elbo(p, jitter=jitter, scale=scale)
     barrier()
+    ck0 = eng.clock_stamp()
     t0 = time.time()
     for _ in range(args.steps):
         out = sh.elbo(p, jitter=jitter, scale=scale)
     barrier()
     dt = time.time() - t0
+    clock_timed = eng.clock_mhz(ck0, eng.clock_stamp())
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     elbo_data, kl = out[0], out[1]
 
+    # ---- the library exchange against the torch.distributed sums (all ranks; after the timed region, so that nothing it does can cost
+    # the headline number).  Everything that can block has a time limit: zigp_comm_init gives up by itself, and a watchdog ends the
+    # process (rank 0 prints the line it has, marked) if the check as a whole overruns.
+    lib_check = None
+    if dist is not None and args.backend == 'nccl' and not sh.library_comm and not args.no_library_check:
+        lib_check = library_exchange_check(eng, dist, red_dev, p, jitter, scale, out, rank, dt, args, world, total_rows)
+    elif sh.library_comm:
+        lib_check = {'status': 'the timed region itself ran on the library exchange'}
+
     # separate profiled pass (rank 0 only, its own shard, no all-reduce): every launch timed with HIP events on the stream
     # it runs on, single stream, so the per-kernel durations are those of kernels running alone
-    prof, prof_wall_ms = None, None
+    prof, prof_wall_ms, clock_prof = None, None, None
     if rank == 0 and args.profile_steps > 0:
         eng.set_overlap(False)
         eng.profile_sampling(1)
         eng.profile_enable(True)
         eng.elbo(p, jitter=jitter, scale=scale, include_kl=True)
         eng.profile_reset()
+        ckp = eng.clock_stamp()
         tp = time.time()
         for _ in range(args.profile_steps):
             eng.elbo(p, jitter=jitter, scale=scale, include_kl=True)
         prof_wall_ms = (time.time() - tp) / args.profile_steps * 1e3
+        clock_prof = eng.clock_mhz(ckp, eng.clock_stamp())
         prof = eng.profile_get()
         eng.profile_enable(False)
         eng.profile_sampling(8)
@@ -329,11 +447,8 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = args.steps / dt * (total_rows / 1e6)
-        res = {
-            'metric': 'elbo_steps_per_sec', 'value': value, 'unit': 'ELBO steps/s (value+gradient, 1e6-row steps, fp64)',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        res = headline(args, world, total_rows, dt)
+        res.update({
             'config': {'workload': 'dense zero-inflated GP ELBO step (value+gradient), N=%d rows %s, D=%d, M=%d per latent, full batch'
                                    % (args.rows, 'per GPU' if args.scaling == 'weak' else 'in total', D, M),
                        'rows_this_rank': N, 'rows_total': total_rows, 'M': M, 'D': D, 'chunk_rows': args.chunk, 'jitter': jitter,
@@ -341,9 +456,13 @@ def main():
             'n_ranks_seen': dist.get_world_size() if dist is not None else 1,
             'backend': (('rccl(nccl)' if args.backend == 'nccl' else args.backend) if dist is not None else 'none'),
             'exchange': ('ncclAllReduce inside libzigp.so (zigp_comm_init), %d calls' % eng.comm_info()['allreduce_calls']) if sh.library_comm
-                        else ('torch.distributed all_reduce of the packed host vector' if dist is not None else 'none'),
+                        else ('torch.distributed all_reduce of the packed vector (%s)' % ('device tensor, RCCL' if args.backend == 'nccl' else 'host tensor, gloo')
+                              if dist is not None else 'none'),
+            'library_exchange_check': lib_check,
             'elbo': elbo_data - kl, 'elbo_data': elbo_data, 'kl': kl,
-        }
+            'sustained_clock_mhz': {'timed_region': clock_timed, 'profiled_pass': clock_prof,
+                                    'how': 's_memtime / s_memrealtime stamps on every XCD before and after the region (zigp_clock_stamp), median over XCDs; nominal 2400'},
+        })
         if prof is not None:
             from zigp._lib import PROF_KERNELS
             gemm_classes = ('gemm_A1', 'gemm_A2', 'gemm_H', 'gemm_J', 'syrk')
@@ -388,11 +507,14 @@ def main():
                     pass
             Mp = (M + 127) // 128 * 128
             hbm = {}
-            for k, bytes_per_col in (('kgrad', 16.0 * Mp), ('kuf_build', 8.0 * Mp)):
+            # kgrad reads the J' panel only (8 Mp bytes per column) since it recomputes K from x, z (ZIGP_KGRAD_RECOMPUTE, round 3; PMC: 0.28 GB
+            # per launch): it is bound by the fp64 exp / VALU work of that recompute, not by HBM -- its GB/s is reported for the record
+            for k, bytes_per_col, bound in (('kgrad', 8.0 * Mp + 8.0 * (D + 2), 'fp64 VALU (K recomputed: ~45 fp64 instructions per element); HBM rate for the record'),
+                                            ('kuf_build', 8.0 * Mp + 8.0 * D, 'HBM write')):
                 if prof[k]['launches'] > 0 and prof[k]['ms'] > 0:
                     # bytes over ALL launches of the profiled pass: every column of the shard is swept once per latent and step
                     nbytes = bytes_per_col * N * 2 * args.profile_steps
-                    hbm[k] = {'GBps': nbytes / (prof[k]['ms'] * 1e-3) / 1e9, 'frac_of_8TBps': nbytes / (prof[k]['ms'] * 1e-3) / PEAK_HBM}
+                    hbm[k] = {'GBps': nbytes / (prof[k]['ms'] * 1e-3) / 1e9, 'frac_of_8TBps': nbytes / (prof[k]['ms'] * 1e-3) / PEAK_HBM, 'bound': bound}
             res['roofline'] = {
                 'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': PEAK_FP64_MFMA / 1e12, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP64_MFMA, 'traffic': traffic, 'traffic_source': traffic_src,
@@ -404,7 +526,7 @@ def main():
                 # (four triangular products + one symmetric rank-N update per latent)
                 'step_frac_10M2N': (10.0 * M * M * N / (dt / args.steps)) / PEAK_FP64_MFMA,
             }
-            res['hbm_bound_kernels'] = hbm
+            res['side_kernels'] = hbm
             res['mfma_busy_pmc'] = mfma_util
             # device time per class in the profiled pass (exact sums, no extrapolation).  mxm_stage covers BOTH latents' chains, which
             # run concurrently on two streams (forward: wall time of the two interleaved chains; reverse: the sum of the two chains):
@@ -417,6 +539,9 @@ def main():
         if not args.no_other_configs and world == 1:
             res['other_configs'] = other_configs(eng, X, Y, p, jitter)
             eng.set_data_device(Xd, Yd)
+            s8 = res['other_configs'].get('strong_1of8')
+            if s8:
+                res['projected_8gpu_speedup'] = ms_per_step / (s8['ms_per_step'] + s8['allreduce_us_assumed'] * 1e-3)
         if not args.no_cpu_baseline and world == 1:
             srows = min(args.cpu_sample_rows, N)
             try:

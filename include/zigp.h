@@ -190,6 +190,13 @@ int zigp_kron_head_predict(zigp_ctx* ctx, const zigp_kron_params* p, int32_t lik
 #define ZIGP_COMM_ID_BYTES 128
 int zigp_comm_unique_id(void* id /* [ZIGP_COMM_ID_BYTES] */);
 int zigp_comm_init(zigp_ctx* ctx, int32_t rank, int32_t nranks, const void* id);
+/* ZIGP_OK when RCCL can be bound in this process (librccl.so.1 found, every symbol resolved, an NCCL 2.x version of the same major as
+ * the headers the library was built against); *version (nullable) = its ncclGetVersion code.  Ranks should agree on this BEFORE any of
+ * them enters the collective zigp_comm_init: a rank that cannot load RCCL would otherwise leave its peers waiting. */
+int zigp_comm_available(int32_t* version);
+/* zigp_comm_init gives up with ZIGP_ECOMM when its peers have not joined after `seconds` (default 120, or env ZIGP_COMM_TIMEOUT_S at
+ * zigp_create); the communicator is then unusable on every rank: fall back to a host-side exchange or exit, do not retry on the same id. */
+int zigp_comm_set_timeout(zigp_ctx* ctx, double seconds);
 int zigp_comm_destroy(zigp_ctx* ctx);
 /* Sum n host doubles over the ranks of the context's communicator, in place (staged through the device): for the few scalars a host loop
  * wants agreed on (a convergence flag, a timing), and the self-check the Python wrapper runs right after zigp_comm_init. */

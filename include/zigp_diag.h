@@ -29,10 +29,19 @@ int zigp_profile_totals(zigp_ctx* ctx, int64_t* total_launches /*[ZIGP_NCLASS]*/
  * bench.py's separate profiled pass); every = n > 1: full-size chunks only, every n-th (default 8). */
 int zigp_profile_sampling(zigp_ctx* ctx, int32_t every);
 
+/* Clock stamps of the 8 XCDs, taken in stream order on the library's main stream (the call synchronises): out[8][3] =
+ * {XCC id, shader-clock counter (s_memtime), constant 100 MHz counter (s_memrealtime)}.  Two calls around a region give the
+ * sustained shader clock of that region: (cycles_1 - cycles_0) / ((rt_1 - rt_0) / 1e8), paired by XCC id. */
+int zigp_clock_stamp(zigp_ctx* ctx, int64_t* out /*[24]*/);
+
 /* ---- diagnostics used by the parity tests (building blocks through the same kernels) ---- */
 /* Kronecker entry points: on != 0 forces the GEMM-panel path (zigp_kron.hip) also for grids the fused register-resident kernels
  * (zigp_kronf.hip) cover -- two independent implementations of the same factored algebra that the tests check against each other. */
 int zigp_set_kron_panels(zigp_ctx* ctx, int32_t on);
+/* The gradient step of the larger fused grids (<= 16 x <= 112 points) sends its rows through in ranges of `tiles` 16-point tiles
+ * (default 1024 = 16 384 rows: the per-point operand records of a range stay within 128 MB).  Results do not depend on it, bit for bit;
+ * the tests lower it to run many ranges on small inputs. */
+int zigp_set_kron_range_tiles(zigp_ctx* ctx, int32_t tiles);
 /* C (m,n) = op(A) * op(B) with the fp64 MFMA GEMM core; transA/transB as BLAS; all dims padded internally. */
 int zigp_test_gemm(zigp_ctx* ctx, int32_t transA, int32_t transB, int64_t m, int64_t n, int64_t k,
                    const double* A, const double* B, double* C);

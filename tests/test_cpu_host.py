@@ -135,8 +135,13 @@ class _OracleShardEngine:
     def elbo(self, p, jitter=1e-6, scale=1.0, g_offset=0.0, rows=None, include_kl=True, need_grad=True):
         import zigp_oracle_torch as ot
         lo, hi = (0, self.X.shape[0]) if rows is None else rows
-        e, d, kl, g = ot.elbo_and_grad(self.X[lo:hi], self.Y[lo:hi], p, jitter, scale=scale, g_offset=g_offset,
-                                       include_kl=include_kl, need_grad=True)
+        if hi == lo:       # an empty shard: as the library evaluates it -- one row at the origin with scale 0 (zero data term, KL per include_kl)
+            e, d, kl, g = ot.elbo_and_grad(np.zeros((1, np.asarray(p['Zf']).shape[1])), np.zeros((1, 1)), p, jitter, scale=0.0, g_offset=g_offset,
+                                           include_kl=include_kl, need_grad=True)
+            scale = 0.0
+        else:
+            e, d, kl, g = ot.elbo_and_grad(self.X[lo:hi], self.Y[lo:hi], p, jitter, scale=scale, g_offset=g_offset,
+                                           include_kl=include_kl, need_grad=True)
         g = {k: (np.asarray(v).reshape(-1) if k.startswith('u_') else v) for k, v in g.items()}
         return d * scale, kl, g
 
@@ -177,6 +182,9 @@ class _OracleKronShardEngine:
     def kron_elbo(self, p, X=None, Y=None, jitter=1e-5, scale=1.0, g_offset=0.0, include_kl=True, need_grad=True, rows=None, f_mu=None):
         import zigp_oracle_torch as ot
         lo, hi = rows
+        if hi == lo:       # empty shard: one row at the origin with scale 0 (csrc/zigp_kron.hip kron_no_rows)
+            e, d, kl, g = ot.kron_elbo_and_grad(np.zeros((1, self.X.shape[1])), np.zeros((1, 1)), p, jitter, scale=0.0, g_offset=g_offset, include_kl=include_kl)
+            return 0.0, kl, g
         e, d, kl, g = ot.kron_elbo_and_grad(self.X[lo:hi], self.Y[lo:hi], p, jitter, scale=scale, g_offset=g_offset, include_kl=include_kl)
         return d * scale, kl, g
 
@@ -310,6 +318,71 @@ def test_data_parallel_allreduce_gloo_world2_equals_single_process():
     for k in ot.PARAM_KEYS:
         a, b = np.asarray(g[k]).reshape(-1), np.asarray(g1[k]).reshape(-1)
         assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300), k
+
+
+W8_BOUNDS = [0, 40, 40, 95, 130, 131, 200, 200, 260]      # 8 ragged shards: ranks 1 and 6 hold NO rows, rank 4 a single one
+
+
+def _gloo_w8_worker(rank, world, port, kind, q):
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from zigp.parallel import ShardedELBO, ShardedKronELBO
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    lo, hi = W8_BOUNDS[rank], W8_BOUNDS[rank + 1]
+    if kind == 'dense':
+        from conftest import make_problem as mp_
+        X, Y, p = mp_(260, 7, 2, seed=5, ell=0.5)
+        sh = ShardedELBO(_OracleShardEngine(X[lo:hi], Y[lo:hi]), dist)
+        ed, kl, g = sh.elbo(p, jitter=1e-6, scale=1.0, rows=(0, hi - lo))
+        g = {k: np.asarray(v) for k, v in g.items()}
+    else:
+        from test_gpu_kron import make_kron_problem
+        X, Y, p = make_kron_problem(260, 4, 3, seed=9, M0g=3, M1g=5)
+        sh = ShardedKronELBO(_OracleKronShardEngine(X[lo:hi], Y[lo:hi]), dist)
+        ed, kl, g = sh.kron_elbo(p, rows=(0, hi - lo), jitter=1e-5, scale=1.5)
+    assert not sh.library_comm                     # default: the torch.distributed exchange
+    if rank in (0, 6):                             # every rank holds the sums: a rank WITH rows and one WITHOUT report
+        q.put((rank, ed, kl, g))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['dense', 'kron'])
+def test_data_parallel_gloo_world8_ragged_and_empty_shards_equal_single_process(kind):
+    """cfg4's rank count on the CPU: 8 gloo ranks over ragged row shards, two of them EMPTY (they still make the same calls and take
+    part in the exchange with a zero contribution), one with a single row; the KL is counted once; every rank -- also an empty one --
+    ends with the single-process sums."""
+    import torch.multiprocessing as mp
+    import zigp_oracle_torch as ot
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_w8_worker, args=(r, 8, port, kind, q)) for r in range(8)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    if kind == 'dense':
+        X, Y, p = make_problem(260, 7, 2, seed=5, ell=0.5)
+        e1, d1, kl1, g1 = ot.elbo_and_grad(X, Y, p, 1e-6)
+        keys, sc = ot.PARAM_KEYS, 1.0
+    else:
+        from test_gpu_kron import make_kron_problem
+        X, Y, p = make_kron_problem(260, 4, 3, seed=9, M0g=3, M1g=5)
+        e1, d1, kl1, g1 = ot.kron_elbo_and_grad(X, Y, p, 1e-5, scale=1.5)
+        keys, sc = list(g1), 1.5
+    for rank, ed, kl, g in res:
+        assert abs(ed - sc * d1) < 1e-10 * abs(sc * d1) and abs(kl - kl1) < 1e-12 * abs(kl1), (rank, ed, sc * d1, kl, kl1)
+        for k in keys:
+            a, b = g[k], g1[k]
+            for x, y in (zip(a, b) if isinstance(b, (list, tuple)) else ((a, b),)):
+                x, y = np.asarray(x, dtype=float).reshape(-1), np.asarray(y, dtype=float).reshape(-1)
+                assert np.max(np.abs(x - y)) <= 1e-9 * max(np.max(np.abs(y)), 1e-300), (rank, k)
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]          # the ranks agree bit for bit
 
 
 class _LiteralDataSet:

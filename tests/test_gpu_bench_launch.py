@@ -96,3 +96,84 @@ def test_cfg4_per_rank_workload_two_ranks_through_the_launcher(engine):
           % (res['elbo_data'], tot, res['kl'], res['ms_per_step']))
     assert abs(res['elbo_data'] - tot) <= 1e-11 * abs(tot), (res['elbo_data'], tot)
     assert abs(res['kl'] - kl) <= 1e-12 * abs(kl)
+
+
+def test_comm_init_gives_up_when_a_peer_never_joins():
+    """zigp_comm_init is collective; a rank whose peer never arrives must get ZIGP_ECOMM after the timeout (zigp_comm_set_timeout)
+    instead of waiting forever.  Own process (a helper thread stays behind inside RCCL's bootstrap; the contract after a timeout is
+    'fall back or exit'): rank 0 of a 2-rank communicator nobody else joins, timeout 4 s."""
+    code = (
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "import zigp\n"
+        "eng = zigp.DenseEngine(0)\n"
+        "assert eng.comm_available()\n"
+        "eng.comm_set_timeout(4.0)\n"
+        "uid = eng.comm_unique_id()\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    eng.comm_init(0, 2, uid)\n"
+        "    print('NO ERROR'); sys.stdout.flush(); os._exit(3)\n"
+        "except zigp.ZigpError as e:\n"
+        "    dt = time.time() - t0\n"
+        "    assert 3.0 < dt < 30.0, dt\n"
+        "    assert 'did not return within' in str(e), str(e)\n"
+        "    assert eng.comm_info()['nranks'] == 0\n"
+        "    print('gave up after %%.1f s: %%s' %% (dt, e)); sys.stdout.flush()\n"
+        "os._exit(0)\n" % os.path.join(ROOT, 'zero-inflated-gp_amd'))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode == 0 and 'gave up after' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_force_dist_runs_the_multi_rank_code_path_with_one_rank():
+    """`bench.py --gpus 1 --force-dist` = the code path of the 8-GPU run (torch.distributed process group on RCCL, the per-step all-reduce
+    of the packed vector, barriers, MAX of the times) with ONE rank, and after the timed region the library-exchange check: communicator
+    through zigp_comm_init, one step through ncclAllReduce inside libzigp.so, compared with the torch.distributed sums."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--rows', '65536', '--M', '256', '--steps', '2',
+           '--warmup', '1', '--no-cpu-baseline', '--no-other-configs', '--profile-steps', '0']
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert res['n_gpus'] == 1 and res['backend'] == 'rccl(nccl)' and 'torch.distributed' in res['exchange']
+    chk = res['library_exchange_check']
+    print('library exchange check at one rank:', chk)
+    assert chk['status'] == 'ok' and chk['packed_vector_max_rel_diff'] == 0.0 and chk['allreduce_calls_in_library'] >= 2
+    clk = res['sustained_clock_mhz']['timed_region']
+    print('sustained clock of the timed region: %s MHz' % clk)
+    assert clk is None or 500 < clk < 3000
+
+
+def test_two_rank_rccl_exchange_matches_the_sum_of_the_shards(engine):
+    """Needs TWO GPUs (skipped on the one-GPU boxes this suite normally runs on): `bench.py --gpus 2` on RCCL -- the timed region
+    on the torch.distributed exchange, then the library exchange (ncclAllReduce inside libzigp.so with two REAL ranks) checked against it --
+    and the 2-rank ELBO against the sum of the two shard ELBOs computed by one engine."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs: RCCL refuses two ranks on one device')
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'nccl', '--rows', '65536', '--M', '256', '--steps', '2',
+           '--warmup', '1', '--no-cpu-baseline', '--no-other-configs', '--profile-steps', '0']
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    print('2-rank RCCL run:', {k: res[k] for k in ('value', 'ms_per_step', 'exchange', 'library_exchange_check')})
+    assert res['n_ranks_seen'] == 2 and res['library_exchange_check']['status'] == 'ok'
+    tot, kl = 0.0, None
+    engine.set_chunk(32768)
+    for rk in range(2):
+        X, Y, p = bench.synth(65536, 256, 3, rank=rk)
+        engine.set_data(X, Y)
+        ed, k, _ = engine.elbo(p, jitter=1e-6, include_kl=(rk == 0))
+        tot += ed
+        kl = k if rk == 0 else kl
+    assert abs(res['elbo_data'] - tot) <= 1e-11 * abs(tot) and abs(res['kl'] - kl) <= 1e-12 * abs(kl)

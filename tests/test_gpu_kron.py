@@ -227,6 +227,56 @@ def test_kron_shard_additivity_many_tiles(engine, M0, M1):
     # and a 3000-row slice against the literal oracle is covered by the parametrised tests above
 
 
+def test_kron_larger_grid_row_ranges_are_bit_stable(engine):
+    """The gradient step on the reference's [10, 100] grid (scripts/onoff.py:52-53) sends its rows through in ranges (bounded operand
+    spill, zigp_kronf.hip): 20 000 rows = 1 250 tiles go through as 2 ranges by default and as 20+ with 57-tile ranges -- every result
+    must be the same bits, and a row count that used to need 0.9 GB of records (the pptr full batch, 105 280 rows) runs in 128 MB."""
+    X, Y, p = make_kron_problem(20000, 10, 100, seed=12)
+    ref = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=2.0)
+    try:
+        for tiles in (57, 64, 100000):
+            engine.set_kron_range_tiles(tiles)
+            got = engine.kron_elbo(p, X, Y, jitter=1e-5, scale=2.0)
+            assert got[0] == ref[0] and got[1] == ref[1], tiles
+            for k in ref[2]:
+                a, b = got[2][k], ref[2][k]
+                for x, y in (zip(a, b) if isinstance(b, (list, tuple)) else ((a, b),)):
+                    assert np.array_equal(np.asarray(x), np.asarray(y)), (tiles, k)
+    finally:
+        engine.set_kron_range_tiles(1024)
+    Xb, Yb, pb = make_kron_problem(105280, 10, 100, seed=13)          # pptr's row count
+    ed, kl, g = engine.kron_elbo(pb, Xb, Yb, jitter=1e-5, scale=1.0)
+    h = 52640
+    a = engine.kron_elbo(pb, Xb[:h], Yb[:h], jitter=1e-5, scale=1.0, include_kl=True)
+    b = engine.kron_elbo(pb, Xb[h:], Yb[h:], jitter=1e-5, scale=1.0, include_kl=False)
+    assert abs((a[0] + b[0]) - ed) <= 1e-11 * abs(ed) and a[1] == kl
+    for q in range(2):
+        s_ = np.asarray(a[2]['Zf'][q]) + np.asarray(b[2]['Zf'][q])
+        assert np.max(np.abs(s_ - np.asarray(g['Zf'][q]))) <= 1e-8 * np.max(np.abs(np.asarray(g['Zf'][q])))
+
+
+@pytest.mark.parametrize('M0,M1', [(32, 32), (10, 100), (40, 9)])
+def test_kron_empty_row_range_contributes_zero_and_keeps_the_kl(engine, M0, M1):
+    """A rank of a data-parallel run whose shard is empty still makes the same calls (the exchange inside the step is collective):
+    rows=(k, k) gives a zero data term, the KL as usual, and exactly the KL part of the gradient -- fused small grid, larger grid, panels."""
+    X, Y, p = make_kron_problem(600, M0, M1, seed=14)
+    engine.set_data(X, Y)
+    full = engine.kron_elbo(p, rows=(0, 600), jitter=1e-5, scale=3.0)
+    nokl = engine.kron_elbo(p, rows=(0, 600), jitter=1e-5, scale=3.0, include_kl=False)
+    for k0 in (0, 17, 600):
+        e = engine.kron_elbo(p, rows=(k0, k0), jitter=1e-5, scale=3.0)
+        assert e[0] == 0.0 and e[1] == full[1]
+        z = engine.kron_elbo(p, rows=(k0, k0), jitter=1e-5, scale=3.0, include_kl=False)
+        assert z[0] == 0.0 and z[1] == 0.0
+        for k in full[2]:
+            a, b, c, d = e[2][k], full[2][k], nokl[2][k], z[2][k]
+            items = zip(a, b, c, d) if isinstance(b, (list, tuple)) else ((a, b, c, d),)
+            for x, y, w, v in items:
+                x, y, w, v = (np.asarray(t, dtype=float).reshape(-1) for t in (x, y, w, v))
+                assert np.all(v == 0.0), k
+                assert np.max(np.abs(x - (y - w))) <= 1e-9 * max(np.max(np.abs(y)), 1e-300), k      # KL part = full - data part
+
+
 def test_kron_predict_chunks_rows(engine):
     """prediction sets larger than 131072 rows are processed in chunks (bounded device / pinned memory): same values as per-chunk calls"""
     X, Y, p = make_kron_problem(140000, 12, 9, seed=2)

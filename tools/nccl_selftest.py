@@ -36,8 +36,8 @@ ref = dict(dense=eng.elbo(p), dense_value=eng.elbo(p, need_grad=False), dense_no
            kron_nokl=eng.kron_elbo(pk, Xk, Yk, include_kl=False), kron_large=eng.kron_elbo(pl, Xl, Yl),
            kron_panel=eng.kron_elbo(pp, Xp, Yp), head=eng.kron_head_elbo(ph, Xk, (Yk > 0).astype(float), 'bernoulli', f_mu=0.1))
 assert eng.comm_info()['nranks'] == 0
-sh = ShardedELBO(eng, dist, device='cuda:0')              # backend nccl -> library communicator
-shk = ShardedKronELBO(eng, dist, device='cuda:0')        # same engine: shares the communicator
+sh = ShardedELBO(eng, dist, device='cuda:0', library_comm=True)      # the opt-in library communicator
+shk = ShardedKronELBO(eng, dist, device='cuda:0', library_comm=True)        # same engine: shares the communicator
 assert sh.library_comm and shk.library_comm and eng.comm_info() == dict(rank=0, nranks=1, allreduce_calls=1)   # 1: the wrapper's self-check sum
 got = dict(dense=sh.elbo(p), dense_value=eng.elbo(p, need_grad=False), dense_nokl=eng.elbo(p, include_kl=False),
            kron=eng.kron_elbo(pk, Xk, Yk, scale=3.0, f_mu=0.25), kron_value=eng.kron_elbo(pk, Xk, Yk, need_grad=False),

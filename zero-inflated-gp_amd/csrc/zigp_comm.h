@@ -5,12 +5,41 @@
 #pragma once
 #include "zigp_ctx.h"
 #include <dlfcn.h>
+// The six RCCL entry points this unit binds with dlsym.  With the rccl development headers installed their declarations (and the
+// version the ABI below was compiled against) come from <rccl/rccl.h>; without them the library still builds -- single-GPU use needs
+// no RCCL at all -- from the minimal declarations below (the NCCL 2.x C API these functions have had since 2.0: a 128-byte opaque id,
+// an opaque communicator handle, int-valued enums).
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#define ZIGP_RCCL_HEADER_VERSION NCCL_VERSION_CODE
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;      // ncclFloat64
+ncclResult_t ncclGetVersion(int* version);
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#define ZIGP_RCCL_HEADER_VERSION 0
+#endif
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 namespace zigp {
 
 struct RcclApi {
   void* handle = nullptr;
+  int version = 0;            // ncclGetVersion of the library dlopen found
+  decltype(&ncclGetVersion) GetVersion = nullptr;
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
@@ -30,11 +59,24 @@ inline RcclLoad rccl_load() {
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-  if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy || !api.GetErrorString) {
-    r.err = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy / ncclGetErrorString";
+  api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(h, "ncclGetVersion"));
+  if (!api.GetVersion || !api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy || !api.GetErrorString) {
+    r.err = "librccl.so.1 lacks one of ncclGetVersion / ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy / ncclGetErrorString";
     dlclose(h);
     return r;
   }
+  // The by-value 128-byte id and the enum values are an ABI promise of the NCCL 2.x line: refuse anything else, and a library of
+  // another MAJOR version than the headers this unit was compiled against (the run-time library is whatever dlopen finds first).
+  int ver = 0;
+  if (api.GetVersion(&ver) != ncclSuccess || ver < 20000 || ver >= 30000 ||
+      (ZIGP_RCCL_HEADER_VERSION != 0 && ver / 10000 != ZIGP_RCCL_HEADER_VERSION / 10000)) {
+    char b[200];
+    snprintf(b, sizeof(b), "librccl.so.1 reports version code %d: not the NCCL 2.x ABI this library binds (headers: %d)", ver, (int)ZIGP_RCCL_HEADER_VERSION);
+    r.err = b;
+    dlclose(h);
+    return r;
+  }
+  api.version = ver;
   api.handle = h;
   return r;
 }

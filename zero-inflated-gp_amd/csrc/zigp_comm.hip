@@ -25,12 +25,53 @@ int zigp_comm_init(zigp_ctx* c, int32_t rank, int32_t nranks, const void* id128)
   ZIGP_HIP(c, hipSetDevice(c->device));
   RcclApi* api = rccl_api(&c->err);
   if (!api) return ZIGP_ECOMM;
-  ncclUniqueId id;
-  memcpy(&id, id128, sizeof(id));
-  ncclComm_t comm = nullptr;
-  const ncclResult_t r = api->CommInitRank(&comm, nranks, id, rank);
-  if (r != ncclSuccess) return fail_comm(c, api, "ncclCommInitRank", r);
-  c->comm = comm; c->comm_rank = rank; c->comm_nranks = nranks; c->comm_calls = 0;
+  // ncclCommInitRank is collective and has no timeout of its own: a peer that never arrives (crashed, RCCL not loadable there, another
+  // id) would block this rank forever.  It runs on a helper thread; if it has not returned after comm_timeout_s (zigp_comm_set_timeout,
+  // default 120 s, env ZIGP_COMM_TIMEOUT_S) the call gives up with ZIGP_ECOMM and leaves the helper behind (detached; the state it
+  // writes to is shared-owned, so a late return is harmless).  The caller should then fall back or exit -- never retry on this id.
+  struct InitJob {
+    std::mutex m; std::condition_variable cv; bool done = false;
+    ncclResult_t r = ncclSuccess; hipError_t he = hipSuccess; ncclComm_t comm = nullptr; ncclUniqueId id;
+  };
+  auto job = std::make_shared<InitJob>();
+  memcpy(&job->id, id128, sizeof(job->id));
+  const int device = c->device;
+  std::thread([job, api, device, rank, nranks]() {
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = ncclSuccess;
+    const hipError_t he = hipSetDevice(device);          // the current device is per thread
+    if (he == hipSuccess) r = api->CommInitRank(&comm, nranks, job->id, rank);
+    std::lock_guard<std::mutex> g(job->m);
+    job->he = he; job->r = r; job->comm = comm; job->done = true;
+    job->cv.notify_all();
+  }).detach();
+  {
+    std::unique_lock<std::mutex> g(job->m);
+    if (!job->cv.wait_for(g, std::chrono::duration<double>(c->comm_timeout_s), [&] { return job->done; })) {
+      char b[256];
+      snprintf(b, sizeof(b), "zigp_comm_init: ncclCommInitRank(rank %d of %d) did not return within %.0f s -- a peer never joined; "
+               "giving up on this communicator", (int)rank, (int)nranks, c->comm_timeout_s);
+      c->err = b;
+      return ZIGP_ECOMM;
+    }
+  }
+  if (job->he != hipSuccess) { c->err = "zigp_comm_init: hipSetDevice failed on the helper thread"; return ZIGP_EHIP; }
+  if (job->r != ncclSuccess) return fail_comm(c, api, "ncclCommInitRank", job->r);
+  c->comm = job->comm; c->comm_rank = rank; c->comm_nranks = nranks; c->comm_calls = 0;
+  return ZIGP_OK;
+}
+
+int zigp_comm_available(int32_t* version) {
+  std::string err;
+  RcclApi* api = rccl_api(&err);
+  if (version) *version = api ? api->version : 0;
+  return api ? ZIGP_OK : ZIGP_ECOMM;
+}
+
+int zigp_comm_set_timeout(zigp_ctx* c, double seconds) {
+  if (!c) return ZIGP_EARG;
+  if (!(seconds > 0)) return fail_arg(c, "zigp_comm_set_timeout: seconds must be > 0");
+  c->comm_timeout_s = seconds;
   return ZIGP_OK;
 }
 

@@ -115,9 +115,11 @@ struct zigp_ctx {
   zigp::KfState* kronf = nullptr;
   void (*kronf_free)(zigp::KfState*) = nullptr;
   bool kron_panels = false;             // zigp_set_kron_panels: force the panel (GEMM-core) Kronecker path
+  int kron_range_tiles = 1024;          // larger-grid fused backward: rows go through in ranges of this many 16-point tiles (bounded operand spill; zigp_set_kron_range_tiles)
   std::map<std::string, zigp::TileList> tiles;
   // data-parallel exchange (zigp_comm_init): RCCL communicator, one rank per context / GPU
   void* comm = nullptr; int comm_rank = 0, comm_nranks = 1; int64_t comm_calls = 0;
+  double comm_timeout_s = 120.0;         // zigp_comm_set_timeout: how long zigp_comm_init waits for its peers
   zigp::DevBuf packed;                  // result vector of the dense path (k_dense_pack)
   zigp::DevBuf parm;                    // parameters of both latents, one staged image (latents_upload); lat[h].Z / ell / u / s are views into it
   double pivot_rtol = 8.0;              // zigp_set_pivot_rtol: a Cholesky pivot <= pivot_rtol * eps * (variance + jitter) is ZIGP_ENOTPD

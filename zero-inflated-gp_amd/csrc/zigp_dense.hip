@@ -563,6 +563,7 @@ int zigp_create(zigp_ctx** out, int device_id) {
   if (hipMalloc((void**)&c->d_info, sizeof(int)) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(sizeof(double) * PB * PBLD)) != hipSuccess) { delete c; return ZIGP_EHIP; }
+  if (const char* e = getenv("ZIGP_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0) c->comm_timeout_s = v; }
   *out = c;
   return ZIGP_OK;
 }
@@ -794,6 +795,30 @@ int zigp_profile_sampling(zigp_ctx* c, int32_t every) {
 int zigp_profile_totals(zigp_ctx* c, int64_t* total_launches) {
   if (!c || !total_launches) return ZIGP_EARG;
   for (int i = 0; i < ZIGP_NCLASS; ++i) total_launches[i] = c->prof_total[i];
+  return ZIGP_OK;
+}
+
+// ---- sustained shader clock (bench.py) ------------------------------------------------------------
+// One workgroup per XCD (workgroups of a dispatch go round-robin over the 8 XCDs): lane 0 records its XCC id, the shader-clock counter
+// (s_memtime) and the constant 100 MHz counter (s_memrealtime).  Two calls bracket a measured region; the host pairs the stamps by XCC id.
+__global__ void k_clock_stamp(long long* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xf;     // HW_REG_XCC_ID, bits [3:0]
+  const long long cyc = (long long)__builtin_readcyclecounter();
+  const long long rt = (long long)__builtin_amdgcn_s_memrealtime();
+  out[3 * blockIdx.x + 0] = (long long)xcc;
+  out[3 * blockIdx.x + 1] = cyc;
+  out[3 * blockIdx.x + 2] = rt;
+}
+int zigp_clock_stamp(zigp_ctx* c, int64_t* out) {
+  if (!c || !out) return ZIGP_EARG;
+  static_assert(sizeof(long long) == sizeof(int64_t), "stamp layout");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  ZIGP_ENSURE(c, c->scratch2, 64);
+  hipLaunchKernelGGL(k_clock_stamp, dim3(8), dim3(64), 0, c->stream_main, reinterpret_cast<long long*>(c->scratch2.p));
+  ZIGP_HIP(c, hipGetLastError());
+  ZIGP_HIP(c, hipMemcpyAsync(out, c->scratch2.p, sizeof(int64_t) * 24, hipMemcpyDeviceToHost, c->stream_main));
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream_main));
   return ZIGP_OK;
 }
 

@@ -769,6 +769,10 @@ int kron_predict_chunked(zigp_ctx* c, const zigp_kron_params* p, const double* X
   }
   return ZIGP_OK;
 }
+// An EMPTY row set (a rank of a data-parallel run whose shard is empty) still has to make the same calls as its peers -- the exchange
+// inside the step is collective.  It is evaluated as ONE row at the origin with scale 0: the data term and every data-term gradient
+// are exactly zero, the KL part follows include_kl as usual.
+static const double kron_no_rows[2 * MAXD] = {0};
 }  // namespace
 
 extern "C" {
@@ -777,9 +781,10 @@ int zigp_kron_elbo(zigp_ctx* c, const zigp_kron_params* p, const double* X, cons
                    double g_offset, double f_mu, int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads, double* d_f_mu) {
   if (!c) return ZIGP_EARG;
   ZIGP_TRY(validate_kron(c, p));
-  if (!X || !Y || N <= 0) return fail_arg(c, "zigp_kron_elbo: need X, Y and N > 0");
+  if (N < 0 || (N > 0 && (!X || !Y))) return fail_arg(c, "zigp_kron_elbo: need X, Y for N > 0 rows");
   if (!(jitter >= 0)) return fail_arg(c, "zigp_kron_elbo: jitter must be >= 0");
   ZIGP_HIP(c, hipSetDevice(c->device));
+  if (N == 0) return kron_run(c, p, kron_no_rows, kron_no_rows, 1, jitter, 0.0, g_offset, f_mu, include_kl, false, nullptr, elbo_data, kl, grads, ZIGP_LIK_ONOFF, d_f_mu);
   return kron_run(c, p, X, Y, N, jitter, scale, g_offset, f_mu, include_kl, false, nullptr, elbo_data, kl, grads, ZIGP_LIK_ONOFF, d_f_mu);
 }
 
@@ -787,10 +792,14 @@ int zigp_kron_elbo_rows(zigp_ctx* c, const zigp_kron_params* p, int64_t row_begi
                         double f_mu, int32_t include_kl, double* elbo_data, double* kl, zigp_kron_grads* grads, double* d_f_mu) {
   if (!c) return ZIGP_EARG;
   ZIGP_TRY(validate_kron(c, p));
+  if (!(jitter >= 0)) return fail_arg(c, "zigp_kron_elbo_rows: jitter must be >= 0");
+  if (row_begin == row_end && row_begin >= 0 && row_begin <= c->N) {     // an empty range (an empty shard of a data-parallel run): zero data term, same calls as its peers
+    ZIGP_HIP(c, hipSetDevice(c->device));
+    return kron_run(c, p, kron_no_rows, kron_no_rows, 1, jitter, 0.0, g_offset, f_mu, include_kl, false, nullptr, elbo_data, kl, grads, ZIGP_LIK_ONOFF, d_f_mu);
+  }
   if (!c->dX) return fail_arg(c, "zigp_kron_elbo_rows: no data set (call zigp_set_data first)");
   if (p->D0 + p->D1 != c->D) return fail_arg(c, "zigp_kron_elbo_rows: D0 + D1 differs from the data's D");
-  if (row_begin < 0 || row_end > c->N || row_begin >= row_end) return fail_arg(c, "zigp_kron_elbo_rows: bad row range");
-  if (!(jitter >= 0)) return fail_arg(c, "zigp_kron_elbo_rows: jitter must be >= 0");
+  if (row_begin < 0 || row_end > c->N || row_begin > row_end) return fail_arg(c, "zigp_kron_elbo_rows: bad row range");
   ZIGP_HIP(c, hipSetDevice(c->device));
   return kron_run(c, p, c->dX + row_begin * c->D, c->dY + row_begin, row_end - row_begin, jitter, scale, g_offset, f_mu, include_kl, false, nullptr,
                   elbo_data, kl, grads, ZIGP_LIK_ONOFF, d_f_mu, true);
@@ -810,9 +819,10 @@ int zigp_kron_head_elbo(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, con
   if (!c) return ZIGP_EARG;
   if (lik == ZIGP_LIK_ONOFF) return fail_arg(c, "zigp_kron_head_elbo: use zigp_kron_elbo for the OnOff likelihood");
   ZIGP_TRY(validate_kron(c, p, lik));
-  if (!X || !Y || N <= 0) return fail_arg(c, "zigp_kron_head_elbo: need X, Y and N > 0");
+  if (N < 0 || (N > 0 && (!X || !Y))) return fail_arg(c, "zigp_kron_head_elbo: need X, Y for N > 0 rows");
   if (!(jitter >= 0)) return fail_arg(c, "zigp_kron_head_elbo: jitter must be >= 0");
   ZIGP_HIP(c, hipSetDevice(c->device));
+  if (N == 0) return kron_run(c, p, kron_no_rows, kron_no_rows, 1, jitter, 0.0, 0.0, f_mu, include_kl, false, nullptr, elbo_data, kl, grads, lik, d_f_mu);
   return kron_run(c, p, X, Y, N, jitter, scale, 0.0, f_mu, include_kl, false, nullptr, elbo_data, kl, grads, lik, d_f_mu);
 }
 
@@ -827,6 +837,13 @@ int zigp_kron_head_predict(zigp_ctx* c, const zigp_kron_params* p, int32_t lik, 
   return kron_predict_chunked(c, p, Xnew, N, jitter, 0.0, f_mu, out4, lik, 4);
 }
 
+
+int zigp_set_kron_range_tiles(zigp_ctx* c, int32_t tiles) {
+  if (!c) return ZIGP_EARG;
+  if (tiles < 1) return fail_arg(c, "zigp_set_kron_range_tiles: need >= 1 tile");
+  c->kron_range_tiles = tiles;
+  return ZIGP_OK;
+}
 
 int zigp_set_kron_panels(zigp_ctx* c, int32_t on) {
   if (!c) return ZIGP_EARG;

@@ -48,6 +48,7 @@ struct KfArgs {
   int tpw;        // tiles per wave
   int lat0;       // first latent of this launch (latents with different block counts are launched separately)
   int ntiles;     // Npad / 16
+  int tile0, tile1;   // k_kfl_backward: the tile range of this launch (its spill records are numbered from tile0)
 };
 
 // accumulator blocks of the backward kernel (16 x 16 each), compile-time layout for KF_NBMAX
@@ -1157,7 +1158,6 @@ static int kf_launch_small_latents(zigp_ctx* c, const int (*Mq)[2], int nlat, bo
   return 0;
 }
 
-constexpr size_t KF_SPILL_MAX_DOUBLES = (size_t)8 << 30;   // 64 GB of the 288 GB: the larger-grid backward spills its per-tile operands
 struct KfHostLatent { int M[2]; const double* Z[2]; const double* ell[2]; double var[2]; const double* u; const double* s; };
 constexpr int KF_KROW_W = 2 + 2 * MAXD;
 
@@ -1379,27 +1379,21 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       for (int h = 0; h < nlat; ++h) ka.lat[h].acc = ks.acc.p + (size_t)h * nparts * nblk * 256;
       ZIGP_TRY(kf_launch_small_latents(c, Mq, nlat, true, (unsigned)nwg, ka));
     } else {
-      size_t rec[2] = {0, 0}, spill_total = 0;
-      for (int h = 0; h < nlat; ++h) { rec[h] = (size_t)64 * (Mq[h][0] + Mq[h][1]); spill_total += rec[h] * ka.ntiles; }
-      // ~4 KB per point and latent at 10 x 100 (0.86 GB for the 105 280-row pptr full batch): bounded, with a message that says what to do
-      // -- the data term and its gradient are sums over rows, so a caller adds up zigp_kron_elbo_rows over sub-ranges (include_kl once)
-      if (spill_total > KF_SPILL_MAX_DOUBLES) {
-        char b[320];
-        snprintf(b, sizeof(b), "Kronecker gradient step on a %d x %d grid over %lld rows needs %.1f GB of per-point operands (limit %.0f GB): "
-                 "split the rows over several calls (the data term is additive; include_kl on one of them)", hl[0].M[0], hl[0].M[1], (long long)N,
-                 spill_total * 8.0 / 1e9, KF_SPILL_MAX_DOUBLES * 8.0 / 1e9);
-        c->err = b;
-        return ZIGP_EARG;
-      }
-      ZIGP_ENSURE(c, ks.spill, spill_total);
-      ka.lat[0].spill = ks.spill.p;
-      if (nlat == 2) ka.lat[1].spill = ks.spill.p + rec[0] * ka.ntiles;
-      if (large_exact) hipLaunchKernelGGL((k_kfl_backward<1, 7, true, true>), dim3(nwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
-      else hipLaunchKernelGGL((k_kfl_backward<1, 7, true, false>), dim3(nwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
-      ZIGP_HIP(c, hipGetLastError());
-      // sums over points: one wave per output block and split of tps tiles (4 for a minibatch: the chain of dependent loads is short)
-      const int tps = std::max(4, std::min(64, ka.ntiles / 16));
+      // The backward kernel spills ~4 KB of operands per point and latent (at 10 x 100), which k_kfl_accum then sums over the points.  The
+      // rows go through in RANGES of <= 1024 tiles (16 384 rows: <= 128 MB of records for both latents, Infinity-Cache resident), one
+      // backward + one accumulate launch per range.  The split of the tiles into accumulation parts of tps tiles does not depend on the
+      // ranges (a range is a whole number of parts), so the partial sums -- and k_kf_reduce's fixed-order total -- are the same bits as
+      // with one range over everything; memory no longer grows with the row count (rounds 2-3: 0.86 GB for the pptr full batch, and a
+      // 64 GB cap with an error beyond it).
+      size_t rec[2] = {0, 0};
+      for (int h = 0; h < nlat; ++h) rec[h] = (size_t)64 * (Mq[h][0] + Mq[h][1]);
+      const int tps = std::max(4, std::min(64, ka.ntiles / 16));     // tiles per accumulation part (4 for a minibatch: the chain of dependent loads is short)
       nparts = (ka.ntiles + tps - 1) / tps;
+      const int range_tiles = std::max(1, c->kron_range_tiles / tps) * tps;
+      const int spill_tiles = std::min(ka.ntiles, range_tiles);
+      ZIGP_ENSURE(c, ks.spill, (rec[0] + (nlat == 2 ? rec[1] : 0)) * spill_tiles);
+      ka.lat[0].spill = ks.spill.p;
+      if (nlat == 2) ka.lat[1].spill = ks.spill.p + rec[0] * spill_tiles;
       ZIGP_ENSURE(c, ks.acc, (size_t)2 * nparts * nblk * 256);
       KflAccArgs aa;
       memset(&aa, 0, sizeof(aa));
@@ -1412,8 +1406,18 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
         L.nb0 = Mq[h][0] / 16; L.nb1 = Mq[h][1] / 16; L.D0 = D0; L.D1 = D1;
         for (int d = 0; d < MAXD; ++d) { L.zc0[d] = zc[h][0][d]; L.zc1[d] = zc[h][1][d]; }
       }
-      hipLaunchKernelGGL(k_kfl_accum, dim3((nblk + 3) / 4, nparts, nlat), dim3(256), 0, c->stream, aa);
-      ZIGP_HIP(c, hipGetLastError());
+      for (int t0 = 0; t0 < ka.ntiles; t0 += range_tiles) {
+        const int t1 = std::min(t0 + range_tiles, ka.ntiles), nt = t1 - t0;
+        const int rwaves = std::min(nt, 1024 / nlat);
+        ka.tile0 = t0; ka.tile1 = t1; ka.tpw = (nt + rwaves - 1) / rwaves;
+        const int rnw = (nt + ka.tpw - 1) / ka.tpw, rnwg = (rnw + KF_WAVES - 1) / KF_WAVES;
+        if (large_exact) hipLaunchKernelGGL((k_kfl_backward<1, 7, true, true>), dim3(rnwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
+        else hipLaunchKernelGGL((k_kfl_backward<1, 7, true, false>), dim3(rnwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
+        ZIGP_HIP(c, hipGetLastError());
+        aa.tile0 = t0; aa.tile1 = t1; aa.part0 = t0 / tps;
+        hipLaunchKernelGGL(k_kfl_accum, dim3((nblk + 3) / 4, (nt + tps - 1) / tps, nlat), dim3(256), 0, c->stream, aa);
+        ZIGP_HIP(c, hipGetLastError());
+      }
     }
     hipLaunchKernelGGL(k_kf_reduce, dim3(nblk * 256 / 16 + 1, nlat), dim3(256), 0, c->stream, ka.lat[0].acc, ka.lat[gl_].acc, nparts,
                        lat(0) + LAT_WORK, lat(gl_) + LAT_WORK, pl.nb0c, pl.nb1c, Mq[0][0] / 16, Mq[0][1] / 16, Mq[gl_][0] / 16, Mq[gl_][1] / 16,

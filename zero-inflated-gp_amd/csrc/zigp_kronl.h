@@ -92,15 +92,16 @@ k_kfl_backward(KfArgs a) {
   const int nb0 = EXACT ? NB0 : f0.nb, nb1 = EXACT ? NB1 : f1.nb;
   const int Mq0 = 16 * nb0, Mq1 = 16 * nb1;
   const int64_t rec = 64 * (int64_t)(Mq0 + Mq1);
-  const int t1 = min((w + 1) * a.tpw, a.ntiles);
+  const int tb = a.tile0 + w * a.tpw;                    // this launch covers tiles [tile0, tile1); its records are numbered from tile0
+  const int t1 = min(tb + a.tpw, a.tile1);
   KfTile<NB0, NB1> t;
   bool first = true;
-  if (w * a.tpw < t1) {          // K tiles of the first tile under the asynchronous staging copy
-    const int64_t pn = (int64_t)(w * a.tpw) * 16 + n;
+  if (tb < t1) {          // K tiles of the first tile under the asynchronous staging copy
+    const int64_t pn = (int64_t)tb * 16 + n;
     kf_forward_ktiles<NB0, NB1, EXACT>(t, L, F.Z0, F.Z1, a.X + (pn < a.N ? pn : 0) * a.ldx, pn < a.N, g);
   }
   if (STAGE) kf_stage_wait();
-  for (int tile = w * a.tpw; tile < t1; ++tile) {
+  for (int tile = tb; tile < t1; ++tile) {
     const int64_t pn = (int64_t)tile * 16 + n;
     const bool valid = pn < a.N;
     const double* xrow = a.X + (valid ? pn : 0) * a.ldx;
@@ -108,7 +109,7 @@ k_kfl_backward(KfArgs a) {
     first = false;
     kf_forward_products<NB0, NB1, EXACT>(t, L, F, slot);
     const double gmn = L.gm[pn], gvn = L.gv[pn], dq0n = L.dq0[pn], dq1n = L.dq1[pn];
-    double* R = L.spill + (int64_t)tile * rec;
+    double* R = L.spill + (int64_t)(tile - a.tile0) * rec;
     double* R1 = R + 64 * Mq0;
     kfl_spill<NB0>(R, t.K0, nb0, Mq0, g, n);
     kfl_spill<NB1>(R1, t.K1, nb1, Mq1, g, n);
@@ -148,7 +149,7 @@ k_kfl_backward(KfArgs a) {
 }
 
 struct KflAccLat { const double* spill; const double *gm, *gv; double* acc; int nb0, nb1, D0, D1; double zc0[MAXD], zc1[MAXD]; };
-struct KflAccArgs { KflAccLat lat[2]; const double* X; int64_t N; int ldx, ntiles, tps, nb0c, nb1c; };
+struct KflAccArgs { KflAccLat lat[2]; const double* X; int64_t N; int ldx, ntiles, tps, nb0c, nb1c; int tile0, tile1, part0; };   // tile range of this launch, its first part
 
 // sums over points for the larger grids: wave = one 16 x 16 output block over the tiles of one split
 //   dAlpha += K0 diag(gm) K1^T ; dS2 += A0^2 diag(gv) (A1^2)^T ; dP_p += E_p K_p^T ; moments_p += t_p Psi_p
@@ -177,11 +178,11 @@ k_kfl_accum(KflAccArgs a) {
     const int D = b.kind == 4 ? L.D0 : L.D1, col0 = b.kind == 4 ? 0 : L.D0;
     const double* zc = b.kind == 4 ? L.zc0 : L.zc1;
     const int psi_d = (bj == 0) ? -1 : ((bj <= D) ? bj - 1 : ((bj <= 2 * D) ? bj - 1 - D : -2));   // -1: constant 1, -2: 0
-    const int t0 = blockIdx.y * a.tps, t1 = min(t0 + a.tps, a.ntiles);
+    const int t0 = a.tile0 + blockIdx.y * a.tps, t1 = min(t0 + a.tps, a.tile1);
     const int oa = 16 * b.rb + 4 * ai, ob = 16 * b.cb + 4 * (bj & 3) + (bj >> 2);
 #pragma unroll 2
     for (int tile = t0; tile < t1; ++tile) {
-      const double* R = L.spill + (int64_t)tile * rec;
+      const double* R = L.spill + (int64_t)(tile - a.tile0) * rec;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int pt = 4 * ks + kk;
@@ -204,7 +205,7 @@ k_kfl_accum(KflAccArgs a) {
       }
     }
   }
-  double* out = L.acc + ((int64_t)blockIdx.y * nblk + blk) * 256;
+  double* out = L.acc + ((int64_t)(a.part0 + blockIdx.y) * nblk + blk) * 256;
 #pragma unroll
   for (int r = 0; r < 4; ++r) out[r * 64 + lane] = acc[r];
 }

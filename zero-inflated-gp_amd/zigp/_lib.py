@@ -83,10 +83,13 @@ SIGNATURES = {
     'zigp_comm_unique_id': (C.c_int, [C.c_void_p]),
     'zigp_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'zigp_comm_destroy': (C.c_int, [C.c_void_p]),
+    'zigp_comm_available': (C.c_int, [C.POINTER(C.c_int32)]),
+    'zigp_comm_set_timeout': (C.c_int, [C.c_void_p, C.c_double]),
     'zigp_comm_allreduce_host': (C.c_int, [C.c_void_p, dp, C.c_int64]),
     'zigp_comm_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     'zigp_set_overlap': (C.c_int, [C.c_void_p, C.c_int32]),
     'zigp_set_kron_panels': (C.c_int, [C.c_void_p, C.c_int32]),
+    'zigp_set_kron_range_tiles': (C.c_int, [C.c_void_p, C.c_int32]),
     'zigp_set_mean_function': (C.c_int, [C.c_void_p, dp, C.c_int32, C.c_double]),
     'zigp_get_mean_function_grad': (C.c_int, [C.c_void_p, dp, C.c_int32, dp]),
     'zigp_kron_head_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), C.c_int32, dp, dp, C.c_int64, C.c_double, C.c_double,
@@ -97,6 +100,7 @@ SIGNATURES = {
     'zigp_profile_reset': (C.c_int, [C.c_void_p]),
     'zigp_profile_totals': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'zigp_profile_sampling': (C.c_int, [C.c_void_p, C.c_int32]),
+    'zigp_clock_stamp': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'zigp_test_gemm': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, dp, dp, dp]),
     'zigp_test_potrf_trtri': (C.c_int, [C.c_void_p, C.c_int64, dp, dp, dp]),
 }

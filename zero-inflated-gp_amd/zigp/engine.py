@@ -191,6 +191,15 @@ class DenseEngine:
         buf = C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
         _check(self.lib, self.ctx, self.lib.zigp_comm_init(self.ctx, int(rank), int(nranks), C.cast(buf, C.c_void_p)))
 
+    def comm_available(self):
+        """True when RCCL can be bound in this process (zigp_comm_available): ranks agree on this before any of them enters comm_init"""
+        v = C.c_int32(0)
+        return self.lib.zigp_comm_available(C.byref(v)) == 0
+
+    def comm_set_timeout(self, seconds):
+        """how long comm_init waits for its peers before it gives up with a ZigpError (default 120 s)"""
+        _check(self.lib, self.ctx, self.lib.zigp_comm_set_timeout(self.ctx, float(seconds)))
+
     def comm_destroy(self):
         _check(self.lib, self.ctx, self.lib.zigp_comm_destroy(self.ctx))
 
@@ -469,16 +478,41 @@ class DenseEngine:
 
     # ---- measurement ----
     def set_overlap(self, on=True):
-        """stream overlap inside elbo(): False/0 off (default), True/1 the HBM-bound side kernels of a chunk on a second stream under
-        its rank-N updates; results are bit-identical either way"""
+        """stream overlap inside elbo(): True/1 (the library's DEFAULT since round 3) runs the side kernels of a chunk (kgrad, the next
+        chunk's Kuf panels) on a second stream under its rank-N updates; False/0 keeps every launch on one stream -- set this for
+        per-kernel timing with an external tracer (rocprofv3), where overlapped kernels stretch each other.  Results are bit-identical
+        either way."""
         _check(self.lib, self.ctx, self.lib.zigp_set_overlap(self.ctx, int(on)))
 
     def set_kron_panels(self, on=True):
         """diagnostic: route the Kronecker entry points through the GEMM-panel path also for grids the fused kernels cover"""
         _check(self.lib, self.ctx, self.lib.zigp_set_kron_panels(self.ctx, 1 if on else 0))
 
+    def set_kron_range_tiles(self, tiles=1024):
+        """diagnostic: rows per range (in 16-point tiles) of the larger-grid Kronecker gradient step; results do not depend on it"""
+        _check(self.lib, self.ctx, self.lib.zigp_set_kron_range_tiles(self.ctx, int(tiles)))
+
     def profile_enable(self, on=True):
         _check(self.lib, self.ctx, self.lib.zigp_profile_enable(self.ctx, 1 if on else 0))
+
+    def clock_stamp(self):
+        """{XCC id: (shader-clock counter, 100 MHz counter)} taken in stream order now (zigp_clock_stamp); see clock_mhz"""
+        out = np.zeros(24, dtype=np.int64)
+        _check(self.lib, self.ctx, self.lib.zigp_clock_stamp(self.ctx, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return {int(out[3 * i]): (int(out[3 * i + 1]), int(out[3 * i + 2])) for i in range(8)}
+
+    @staticmethod
+    def clock_mhz(a, b):
+        """sustained shader clock (MHz) between two clock_stamp() results: median over the XCDs both stamps saw; None if the counters
+        do not behave as a core-clock / constant-clock pair on this device"""
+        vals = []
+        for x in a:
+            if x in b and b[x][1] > a[x][1]:
+                vals.append((b[x][0] - a[x][0]) / ((b[x][1] - a[x][1]) / 1e8) / 1e6)
+        if not vals:
+            return None
+        v = float(np.median(vals))
+        return v if 300.0 < v < 4000.0 else None
 
     def profile_sampling(self, every=8):
         """every=1 times every launch of the chunk loop (exact sums); n > 1 samples every n-th full-size chunk"""

@@ -3,9 +3,9 @@
 The ELBO data term is a plain sum over points (tf.reduce_sum(var_exp), onoffgpf/OnOffSVGP.py:122;
 scripts/onoff.py:307), so rank r evaluates rows [lo_r, hi_r) of its resident shard with the replicated
 O(M^2) state and the packed vector [elbo_data, kl, d/d(params)...] (~82 KB at M=1024, D=3) is summed
-with ONE all-reduce: on a GPU run inside libzigp.so (ncclAllReduce on the packed DEVICE vector, zigp_comm_init --
-RCCL over xGMI; torch.distributed only carries the 128-byte communicator id), in the "gloo" rehearsals / CPU tests
-through torch.distributed on the packed host vector.  KL and its gradient are added on rank 0 only.  The reference
+with ONE all-reduce: by default through torch.distributed on the packed vector (backend "nccl" = RCCL over xGMI on a device
+tensor; "gloo" in the CPU rehearsals), optionally inside libzigp.so (ncclAllReduce on the packed DEVICE vector, zigp_comm_init;
+torch.distributed then only carries the 128-byte communicator id) -- see _Sharded.  KL and its gradient are added on rank 0 only.  The reference
 has no distributed code; this is new.
 """
 import numpy as np
@@ -73,25 +73,34 @@ def _unflatten_kron(vec, spec):
 class _Sharded:
     """Common part of the data-parallel wrappers: who am I, and where does the exchange run.
 
-    library_comm=True (the default on a GPU run with the 'nccl' backend): the exchange is ONE ncclAllReduce inside libzigp.so, on the
-    device, on the engine's stream (zigp_comm_init; the 128-byte id is broadcast over `dist`) -- engine calls then return the sums.
-    library_comm=False ('gloo' rehearsals, the CPU tests' fake engines): the packed host vector goes through torch.distributed."""
+    library_comm=False (the DEFAULT): the packed host vector goes through torch.distributed (backend 'nccl' = RCCL on a device tensor,
+    'gloo' in the CPU rehearsals) -- the path that has run with more than one rank.
+    library_comm=True (opt-in; also env ZIGP_LIBRARY_COMM=1): the exchange is ONE ncclAllReduce inside libzigp.so, on the device, on
+    the engine's stream (zigp_comm_init; the 128-byte id is broadcast over `dist`) -- engine calls then return the sums.  It saves the
+    host round trip per step, but until a run with two or more GPUs has been recorded it has only ever summed over ONE rank,
+    so it is not the default; bench.py --gpus N checks it against the torch.distributed sums after its timed region and reports the
+    result.  Setting it up is itself a sequence of agreements, so that no rank is left waiting inside a collective its peers never
+    enter: (1) all ranks agree (MIN) that RCCL is loadable BEFORE anyone calls comm_init; (2) comm_init gives up after the engine's
+    timeout (zigp_comm_set_timeout) if a peer does not arrive; (3) all ranks agree (MIN) on the outcome of comm_init and of a
+    self-check sum.  Any 'no' leaves every rank on the torch.distributed exchange."""
 
     def __init__(self, engine, dist=None, device=None, library_comm=None):
+        import os
         self.engine, self.dist, self.device = engine, dist, device
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self._buf = None
         self._host = None
         if library_comm is None:
-            library_comm = dist is not None and self.world >= 1 and dist.get_backend() == 'nccl' and hasattr(engine, 'comm_init')
+            library_comm = os.environ.get('ZIGP_LIBRARY_COMM', '0') not in ('', '0') and dist is not None and hasattr(engine, 'comm_init')
         self.library_comm = bool(library_comm) and dist is not None
         self._owns_comm = False
         if self.library_comm:
             info = engine.comm_info()
             if info['nranks'] == 0:
-                # Any failure on the way (RCCL not loadable, communicator not formed, a self-check sum that does not add up) leaves every
-                # rank on the torch.distributed exchange of the packed host vector instead: the decision is itself agreed on by all ranks.
+                if not self._agree(1.0 if (not hasattr(engine, 'comm_available') or engine.comm_available()) else 0.0):
+                    self.library_comm = False          # some rank cannot bind RCCL: nobody enters the collective comm_init
+                    return
                 ok = 1.0
                 try:
                     obj = [engine.comm_unique_id() if self.rank == 0 else None]
@@ -102,17 +111,14 @@ class _Sharded:
                     ok = 0.0
                 else:
                     try:
-                        engine.comm_init(self.rank, self.world, obj[0])
+                        engine.comm_init(self.rank, self.world, obj[0])     # gives up after the engine's timeout if a peer never joins
                         self._owns_comm = True
                         chk = engine.comm_allreduce([1.0, float(self.rank)])
                         if chk[0] != self.world or chk[1] != self.world * (self.world - 1) / 2.0:
                             ok = 0.0
                     except Exception:
                         ok = 0.0
-                import torch
-                flag = torch.tensor([ok], dtype=torch.float64, device=self.device or ('cuda' if dist.get_backend() == 'nccl' else 'cpu'))
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if float(flag.item()) != 1.0:
+                if not self._agree(ok):
                     if self._owns_comm:
                         try:
                             engine.comm_destroy()
@@ -122,6 +128,14 @@ class _Sharded:
                     self.library_comm = False
             elif (info['rank'], info['nranks']) != (self.rank, self.world):       # another wrapper of this engine set it up
                 raise ValueError('engine already has a communicator for rank %d of %d' % (info['rank'], info['nranks']))
+
+    def _agree(self, ok):
+        """True when every rank says ok (MIN over ranks through torch.distributed)"""
+        import torch
+        dist = self.dist
+        flag = torch.tensor([ok], dtype=torch.float64, device=self.device or ('cuda' if dist.get_backend() == 'nccl' else 'cpu'))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return float(flag.item()) == 1.0
 
     def close(self):
         if self._owns_comm:
@@ -150,9 +164,11 @@ class ShardedELBO(_Sharded):
     evaluating rows of ITS OWN resident shard; dist: torch.distributed (initialised) or None for 1 process."""
 
     def elbo(self, p, jitter=1e-6, scale=1.0, g_offset=0.0, rows=None):
+        # a rank whose shard is empty passes rows=(k, k): the engine then contributes zeros (and the KL on rank 0) but still takes part in
+        # the exchange -- every rank makes the same calls
         ed, kl, g = self.engine.elbo(p, jitter=jitter, scale=scale, g_offset=g_offset, rows=rows,
                                      include_kl=(self.rank == 0), need_grad=True)
-        if self.world == 1 or self.library_comm:      # library_comm: already summed over ranks on the device (zigp_comm_init)
+        if self.dist is None or self.library_comm:    # library_comm: already summed over ranks on the device (zigp_comm_init)
             return ed, kl, g
         vec, shapes = pack(ed, kl, g)
         return unpack(self._allreduce_host(vec), shapes)
@@ -165,7 +181,7 @@ class ShardedKronELBO(_Sharded):
     def kron_elbo(self, p, X=None, Y=None, jitter=1e-5, scale=1.0, g_offset=0.0, rows=None, f_mu=None):
         ed, kl, g = self.engine.kron_elbo(p, X, Y, jitter=jitter, scale=scale, g_offset=g_offset, rows=rows, f_mu=f_mu,
                                           include_kl=(self.rank == 0), need_grad=True)
-        if self.world == 1 or self.library_comm:
+        if self.dist is None or self.library_comm:
             return ed, kl, g
         gv, spec = _flatten_kron(g)
         out = self._allreduce_host(np.concatenate([np.array([ed, kl]), gv]))
