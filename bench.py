@@ -306,6 +306,20 @@ def other_configs(eng, X3, Y3, p3, jitter):
         t = timeit(lambda: st2(pk2, rows=(0, n5), jitter=1e-5), 10, 2)
         out['ref_grid_10x100_full'] = dict(workload='pptr N=%d full batch, the reference\'s [10,100] grid, value+gradient, data resident' % n5,
                                             ms_per_step=t * 1e3, rows_per_s=n5 / t, **kron_roofline(n5, t, 1, 7, True))
+        # the fit loop as onoff() runs it since round 4: 200 iterations per call on the device (zigp_kron_fit_steps), one synchronisation per call
+        from onofftf.model import KronDeviceFit
+        rbs = [int(r) for r in np.random.RandomState(3).randint(0, n5 - 1000, size=200)]
+        for key, grid in (('cfg5_mb1000', (32, 32)), ('ref_grid_10x100_mb1000', (10, 100))):
+            np.random.seed(0)
+            fitter = KronDeviceFit(eng, init_params(Xtr, grid, grid, kmeans_seed=1))
+            fitter.steps(rbs[:20], 1000, 1e-5, n5 / 1000.0)                      # warm-up
+            t0 = time.time()
+            ed_, kl_ = fitter.steps(rbs, 1000, 1e-5, n5 / 1000.0)
+            td = (time.time() - t0) / len(rbs)
+            out[key]['device_loop'] = dict(ms_per_step_amortised=td * 1e3, steps_per_s=1 / td, steps_per_call=len(rbs),
+                                           what='zigp_kron_fit_steps: gradient + Log1pe chain + per-learning-rate Adam update on the device, '
+                                                'ONE host synchronisation per call (ms_per_step above = one host call per iteration, no update)',
+                                           cost_first_last=[float(-(ed_[0] - kl_[0])), float(-(ed_[-1] - kl_[-1]))])
         t = timeit(lambda: eng.kron_predict(pk, Xtr, jitter=1e-6, g_offset=-1.0), 3, 1)
         out['cfg5_predict'] = dict(rows=n5, ms=t * 1e3, rows_per_s=n5 / t)
     except Exception as e:   # the Kronecker numbers are extras: never lose the headline line over them

@@ -148,6 +148,40 @@ int zigp_kron_elbo_rows(zigp_ctx* ctx, const zigp_kron_params* p, int64_t row_be
 int zigp_kron_predict(zigp_ctx* ctx, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter,
                       double g_offset, double f_mu, double* out9);
 
+/* ---- the fit loop on the device --------------------------------------------------------------------------------------------------
+ * Replaces the reference's training loop body, scripts/onoff.py:375-381 (`sess.run(train_op)` on `train_data.next_batch(num_minibatch)`),
+ * for n_steps consecutive iterations: gradient of cost = -(scale * sum var_exp - KL) (:318,334), chained through the Log1pe transform of
+ * the positive parameters (GPflow transforms.positive, :88-123), one tf.train.AdamOptimizer per learning rate (:325-350; lr_t =
+ * lr sqrt(1 - beta2^t) / (1 - beta1^t), m / (sqrt(v) + eps)).  The parameters live on the device for the whole call: every step's
+ * kernels read the parameter image the previous step's update wrote, the steps are enqueued back to back on one stream and the host
+ * synchronises ONCE, at the end of the call (the reference logs every 200 iterations, :418: call it with n_steps = 200).
+ *   shape        the model's sizes (M0f .. D1); its pointer and value fields are ignored
+ *   free_state   in/out [n_free]: the UNCONSTRAINED parameters in this block order -- for latent f, then g: Z0 (M0 x D0), Z1 (M1 x D1),
+ *                u_m (M0 M1), u_s_sqrt (M0 M1), ell0 (D0), ell1 (D1), var0, var1; then the likelihood variance (ZIGP_FIT_BLOCKS = 17 blocks)
+ *   adam_m, adam_v   in/out [n_free]: Adam moments (zeros at iteration 0)
+ *   t0           iterations done before this call (the first step of the call is Adam's t = t0 + 1)
+ *   row_begin    [n_steps]: step i uses rows [row_begin[i], row_begin[i] + batch) of the RESIDENT data set (zigp_set_data; the permuted
+ *                epoch, onofftf/main.py:98-133); a negative value -(1 + k) selects rows [k batch, (k + 1) batch) of the host arrays Xw, Yw
+ *                instead (the one wrap-around batch per epoch, which is a concatenation of the old and the new permutation, :125-129)
+ *   elbo_data, kl    out [n_steps] (nullable): scale * sum var_exp and KL of every step, evaluated at the parameters BEFORE its update
+ * Grids beyond the fused kernels (a factor of more than 32 points next to one of more than 16, or more than 112) return ZIGP_EARG: step
+ * them with zigp_kron_elbo_rows and a host optimiser.  A Cholesky failure returns ZIGP_ENOTPD; free_state / adam_* then hold the state
+ * before the failing step and the history entries from that step on are NaN.  With a communicator (zigp_comm_init) every step's result
+ * block is summed over the ranks before its update, so all ranks hold the same parameters (each passes its own rows, include_kl as usual
+ * is rank 0's). */
+#define ZIGP_FIT_BLOCKS 17
+typedef struct {
+  double lr[ZIGP_FIT_BLOCKS];          /* Adam learning rate of each block */
+  int32_t positive[ZIGP_FIT_BLOCKS];   /* 1: value = log(1 + exp(x)) + 1e-6 (Log1pe), 0: value = x */
+  int32_t reserved;
+  double beta1, beta2, eps;            /* TensorFlow's defaults: 0.9, 0.999, 1e-8 */
+} zigp_kron_fit_opts;
+int zigp_kron_fit_steps(zigp_ctx* ctx, const zigp_kron_params* shape, const zigp_kron_fit_opts* opts,
+                        double* free_state, double* adam_m, double* adam_v, int64_t n_free,
+                        int64_t t0, int32_t n_steps, const int64_t* row_begin, int64_t batch,
+                        const double* Xw, const double* Yw, double jitter, double scale, int32_t include_kl,
+                        double* elbo_data, double* kl);
+
 /* Mean function of the latent f: m(x) = b + a . x, added to fmean before the likelihood and in zigp_predict
  * (`fmean = fmean + self.mean_function(Xnew)`, onoffgpf/OnOffSVGP.py:29,134).  Covers GPflow's Zero (the reference default:
  * D = -1 -- the state after zigp_create; a and b are ignored), Constant (D = 0, b = c; enabled also when c == 0, so that the

@@ -116,6 +116,7 @@ struct KronPwArgs {
   double *gm_f, *gv_f, *gm_g, *gv_g, *dq0_f, *dq1_f, *dq0_g, *dq1_g;
   double* acc;   // [blocks][KPW_ACC]: var_exp, d noise, sum gv_f, sum gv_g, sum gm_f (= d / d f_mu)
   double* out9; int64_t ld9;
+  const double* hyp;   // nullable: device hyperparameter block (KH_*): knn_f, knn_g, noise are read from it instead of the fields above
 };
 
 template <bool PREDICT>
@@ -123,12 +124,14 @@ __global__ void __launch_bounds__(PW_THREADS)
 k_kron_pointwise(KronPwArgs p) {
   __shared__ double sh[4];
   const int64_t n = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  const double knn_f = p.hyp ? KF_CONST(p.hyp)[KH_KNN] : p.knn_f, knn_g = p.hyp ? KF_CONST(p.hyp)[KH_KNN + 1] : p.knn_g;
+  const double noise = p.hyp ? KF_CONST(p.hyp)[KH_NOISE] : p.noise;
   const double q0f = p.part_f[n], q1f = p.part_f[p.Nc + n], q0g = p.part_g[n], q1g = p.part_g[p.Nc + n];
-  const double fm = p.part_f[2 * p.Nc + n] + p.f_offset, fv = p.knn_f - q0f * q1f + p.part_f[3 * p.Nc + n];
-  const double gmn = p.part_g[2 * p.Nc + n] + p.g_offset, gvr = p.knn_g - q0g * q1g + p.part_g[3 * p.Nc + n];
+  const double fm = p.part_f[2 * p.Nc + n] + p.f_offset, fv = knn_f - q0f * q1f + p.part_f[3 * p.Nc + n];
+  const double gmn = p.part_g[2 * p.Nc + n] + p.g_offset, gvr = knn_g - q0g * q1g + p.part_g[3 * p.Nc + n];
   const bool valid = n < p.N;
   const double y = (valid && p.Y) ? p.Y[n] : 0.0;
-  PwOut o = pointwise_eval(fm, fv, gmn, gvr, y, p.noise);
+  PwOut o = pointwise_eval(fm, fv, gmn, gvr, y, noise);
   if (PREDICT) {
     if (valid) {
       double* q = p.out9 + n;
@@ -652,7 +655,7 @@ int kron_run_panels(zigp_ctx* c, const zigp_kron_params* p, const double* X, con
   a.knn_f = p->var0f * p->var1f; a.knn_g = p->var0g * p->var1g; a.noise = p->noise; a.g_offset = g_offset; a.f_offset = f_mu; a.scale = scale;
   a.gm_f = need_grad ? ks.lat[0].gm.p : nullptr; a.gv_f = ks.lat[0].gv.p; a.gm_g = ks.lat[gl_].gm.p; a.gv_g = ks.lat[gl_].gv.p;
   a.dq0_f = ks.lat[0].dq0.p; a.dq1_f = ks.lat[0].dq1.p; a.dq0_g = ks.lat[gl_].dq0.p; a.dq1_g = ks.lat[gl_].dq1.p;
-  a.acc = ks.acc.p; a.out9 = nullptr; a.ld9 = N;
+  a.acc = ks.acc.p; a.out9 = nullptr; a.ld9 = N; a.hyp = nullptr;
   if (predict) {
     const int rows = nlat == 2 ? 9 : 4;
     ZIGP_ENSURE(c, ks.out9, (size_t)rows * N);
@@ -803,6 +806,29 @@ int zigp_kron_elbo_rows(zigp_ctx* c, const zigp_kron_params* p, int64_t row_begi
   ZIGP_HIP(c, hipSetDevice(c->device));
   return kron_run(c, p, c->dX + row_begin * c->D, c->dY + row_begin, row_end - row_begin, jitter, scale, g_offset, f_mu, include_kl, false, nullptr,
                   elbo_data, kl, grads, ZIGP_LIK_ONOFF, d_f_mu, true);
+}
+
+int zigp_kron_fit_steps(zigp_ctx* c, const zigp_kron_params* p, const zigp_kron_fit_opts* opts, double* free_state, double* adam_m, double* adam_v,
+                        int64_t n_free, int64_t t0, int32_t n_steps, const int64_t* row_begin, int64_t batch, const double* Xw, const double* Yw,
+                        double jitter, double scale, int32_t include_kl, double* elbo_data, double* kl) {
+  if (!c) return ZIGP_EARG;
+  if (!p || !opts || !free_state || !adam_m || !adam_v || !row_begin) return fail_arg(c, "zigp_kron_fit_steps: NULL argument");
+  if (p->M0f <= 0 || p->M1f <= 0 || p->M0g <= 0 || p->M1g <= 0) return fail_arg(c, "inducing counts must be positive");
+  if (p->D0 <= 0 || p->D1 <= 0 || p->D0 > MAXD || p->D1 > MAXD) return fail_arg(c, "factor dimensions must be in [1, 8]");
+  if (n_steps <= 0 || batch <= 0 || t0 < 0) return fail_arg(c, "zigp_kron_fit_steps: need n_steps > 0, batch > 0, t0 >= 0");
+  if (!(jitter >= 0)) return fail_arg(c, "zigp_kron_fit_steps: jitter must be >= 0");
+  if (!(opts->beta1 >= 0 && opts->beta1 < 1 && opts->beta2 >= 0 && opts->beta2 < 1 && opts->eps > 0)) return fail_arg(c, "zigp_kron_fit_steps: bad Adam constants");
+  if (!c->dX) return fail_arg(c, "zigp_kron_fit_steps: no data set (call zigp_set_data first)");
+  if (p->D0 + p->D1 != c->D) return fail_arg(c, "zigp_kron_fit_steps: D0 + D1 differs from the data's D");
+  if (c->kron_panels || !kf_eligible(p, 2))
+    return fail_arg(c, "zigp_kron_fit_steps: this inducing grid is beyond the fused Kronecker kernels (<= 32 x <= 32 or <= 16 x <= 112 points): "
+                       "step it with zigp_kron_elbo_rows and a host optimiser");
+  for (int i = 0; i < n_steps; ++i) {
+    if (row_begin[i] >= 0 ? row_begin[i] + batch > c->N : (!Xw || !Yw)) return fail_arg(c, "zigp_kron_fit_steps: a row range leaves the resident data set (or a host batch without Xw / Yw)");
+  }
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  KfFitCall fit = {opts, free_state, adam_m, adam_v, n_free, t0, (int)n_steps, row_begin, batch, Xw, Yw, elbo_data, kl};
+  return kronf_run(c, p, c->dX, c->dY, batch, jitter, scale, 0.0, 0.0, include_kl, false, nullptr, nullptr, nullptr, nullptr, ZIGP_LIK_ONOFF, nullptr, true, &fit);
 }
 
 int zigp_kron_predict(zigp_ctx* c, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter, double g_offset, double f_mu, double* out9) {

@@ -26,9 +26,8 @@ constexpr int KF_WAVES = 4;       // waves per workgroup (each wave works alone 
 
 struct KfFac {
   int M, nb, D, col0;
-  double inv_ell[MAXD];
-  double var;
-  double zc[MAXD];          // centre of the moment sums (mid-range of Z_p): sum t (x - z)^k is rebuilt from sum t (x - zc)^k
+  const double* hyp;        // this factor's record of the device hyperparameter block (KH_INV, KH_ZC, KH_VAR; zigp_kernels.h): 1 / ell, the centre
+                            // zc of the moment sums (mid-range of Z_p: sum t (x - z)^k is rebuilt from sum t (x - zc)^k), the variance
   const double* Zs;         // [16 nb][D] inducing inputs divided by the lengthscales, zero rows beyond M (written by k_kf_factor)
   const double* PF;         // P_p in A-fragment order [nb][4 nb][16][4]
 };
@@ -40,7 +39,6 @@ struct KfLat {
   const double *gm, *gv, *dq0, *dq1;   // [Npad] cotangents from the point-wise kernel
   double* acc;                  // [waves][KF_ACC_BLOCKS][4][64] per-wave partial sums
   double* spill;                // larger grids: per-tile operand records of the sums over points (zigp_kronl.h)
-  double knn;
 };
 struct KfArgs {
   KfLat lat[2];
@@ -178,11 +176,13 @@ __device__ __forceinline__ void kf_ktile(double (&K)[Q], const KfFac& f, int nb,
   double xs[MAXD];
 #pragma unroll
   for (int d = 0; d < MAXD; ++d) xs[d] = 0.0;
-  if (SPEC && f.D == 1) xs[0] = xrow[f.col0] * f.inv_ell[0];
-  else if (SPEC && f.D == 2) { xs[0] = xrow[f.col0] * f.inv_ell[0]; xs[1] = xrow[f.col0 + 1] * f.inv_ell[1]; }
+  const auto inv_ell = KF_CONST(f.hyp) + KH_INV;
+  const double var = KF_CONST(f.hyp)[KH_VAR];
+  if (SPEC && f.D == 1) xs[0] = xrow[f.col0] * inv_ell[0];
+  else if (SPEC && f.D == 2) { xs[0] = xrow[f.col0] * inv_ell[0]; xs[1] = xrow[f.col0 + 1] * inv_ell[1]; }
   else {
 #pragma unroll
-    for (int d = 0; d < MAXD; ++d) xs[d] = (d < f.D) ? xrow[f.col0 + d] * f.inv_ell[d] : 0.0;
+    for (int d = 0; d < MAXD; ++d) xs[d] = (d < f.D) ? xrow[f.col0 + d] * inv_ell[d] : 0.0;
   }
   constexpr int B = Q < 8 ? Q : 8;
   const int mlast = 16 * nb - 1;             // zs holds 16 nb rows: blocks beyond nb (runtime block counts) read its last row and are zeroed below
@@ -204,7 +204,7 @@ __device__ __forceinline__ void kf_ktile(double (&K)[Q], const KfFac& f, int nb,
     for (int i = 0; i < B; ++i)
       if (q0 + i < Q) {
         const int m = 4 * (q0 + i) + g;
-        K[q0 + i] = (m < f.M && m <= mlast && valid) ? f.var * y[i] : 0.0;
+        K[q0 + i] = (m < f.M && m <= mlast && valid) ? var * y[i] : 0.0;
       }
   }
 }
@@ -428,7 +428,7 @@ k_kf_backward(KfArgs a) {
     const KfFac& f = L.f[p];
     const int d = (n == 0) ? 0 : ((n <= f.D) ? n - 1 : ((n <= 2 * f.D) ? n - 1 - f.D : 0));
     psi_kind[p] = (n == 0) ? 0 : ((n <= f.D) ? 1 : ((n <= 2 * f.D) ? 2 : 3));
-    psi_col[p] = f.col0 + d; psi_zc[p] = f.zc[d];
+    psi_col[p] = f.col0 + d; psi_zc[p] = KF_CONST(f.hyp)[KH_ZC + d];
   }
 
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
@@ -645,7 +645,7 @@ k_kf_reduce(const double* __restrict__ acc0, const double* __restrict__ acc1, in
 // M x M stages
 // =============================================================================================================================
 struct KfFactorJob {
-  const double* Z; int M, D, Mq; double inv_ell[MAXD]; double var;   // Mq = 16 nb
+  const double* Z; int M, D, Mq; const double* hyp;   // Mq = 16 nb; hyp: the factor's record of the device hyperparameter block
   double* K;        // [128][128] identity padded Kuu factor + jitter (kept for the Kuu-gradient reductions)
   double* P;        // [Mq][Mq] row-major K^-1 (zero padded)
   double* PF;       // fragment order
@@ -678,6 +678,8 @@ k_kf_factor(KfFactorArgs a) {
   __shared__ double red[16];
   const KfFactorJob& jb = a.job[blockIdx.x];
   const int t = threadIdx.x, M = jb.M, Mq = jb.Mq, D = jb.D;
+  const auto inv_ell = KF_CONST(jb.hyp) + KH_INV;
+  const double var = KF_CONST(jb.hyp)[KH_VAR];
   int* const info = a.own_slots ? a.info + 2 * blockIdx.x : a.info;
   if (a.own_slots && t == 0) { info[0] = 0; info[1] = 0; }       // ordered before the factorisation's atomicCAS by the barriers below
   // inducing inputs into LDS first (the T tiles are idle until the factorisation): with Z read from global memory inside the loop
@@ -688,7 +690,7 @@ k_kf_factor(KfFactorArgs a) {
     const int m = idx / D, d = idx - m * D;
     const double z = m < M ? jb.Z[idx] : 0.0;
     zl[idx] = z;
-    jb.Zs[idx] = z * jb.inv_ell[d];
+    jb.Zs[idx] = z * inv_ell[d];
   }
   __syncthreads();
   const int nreal = ((M + PNB - 1) / PNB) * PNB;   // the factorisation touches the 32-column panels that hold real rows only
@@ -698,8 +700,8 @@ k_kf_factor(KfFactorArgs a) {
     double v;
     if (i < M && j < M) {
       double r2 = 0.0;
-      for (int d = 0; d < D; ++d) { const double q = (zl[i * D + d] - zl[j * D + d]) * jb.inv_ell[d]; r2 = fma(q, q, r2); }
-      v = jb.var * exp(-0.5 * r2) + ((i == j) ? a.jitter : 0.0);     // same expression as k_rbf_matrix
+      for (int d = 0; d < D; ++d) { const double q = (zl[i * D + d] - zl[j * D + d]) * inv_ell[d]; r2 = fma(q, q, r2); }
+      v = var * exp(-0.5 * r2) + ((i == j) ? a.jitter : 0.0);     // same expression as k_rbf_matrix
     } else {
       v = (i == j) ? 1.0 : 0.0;
     }
@@ -708,7 +710,7 @@ k_kf_factor(KfFactorArgs a) {
     if (i != j) { jb.K[j * PB + i] = v; S[j * PBLD + i] = 0.0; }
   }
   __syncthreads();
-  if (!potrf_diag_lds(S, psh, 0, info, (M + PNB - 1) / PNB, true, a.piv_rtol * 2.220446049250313e-16 * (jb.var + a.jitter))) return;   // info = plain 1-based pivot, as on the panel path; the slot says which factor
+  if (!potrf_diag_lds(S, psh, 0, info, (M + PNB - 1) / PNB, true, a.piv_rtol * 2.220446049250313e-16 * (var + a.jitter))) return;   // info = plain 1-based pivot, as on the panel path; the slot says which factor
   // logdet K = sum log L_ii^2 (fixed order: strided partials, then 16 wave sums in order)
   {
     double ld = 0.0;
@@ -976,7 +978,7 @@ struct KfFinishJob {
   int M0, M1, Mq0, Mq1, D0, D1;
   const double *P0, *P1, *dvec0, *dvec1, *K0, *K1, *Z0, *Z1;
   const double *PF0, *PF1;
-  double zc0[MAXD], zc1[MAXD];
+  const double *hyp0, *hyp1;          // the two factors' records of the device hyperparameter block (zc: centre of the moment sums)
   const double *U, *S2, *T0, *T1, *Al, *s;
   const double* work;  // KF_W_TOTAL summed accumulators
   double *krow0, *krow1, *gu, *gs;     // outputs: [M0][2 + 2 D0], [M1][2 + 2 D1], [M0*M1], [M0*M1]
@@ -996,7 +998,7 @@ k_kf_finish(KfFinishArgs a) {
   const bool kl = a.with_kl != 0;
   const int M = p == 0 ? M0 : M1, Mq = p == 0 ? Mq0 : Mq1, Mo = p == 0 ? M1 : M0, D = p == 0 ? jb.D0 : jb.D1;
   const double* Z = p == 0 ? jb.Z0 : jb.Z1;
-  const double* zc = p == 0 ? jb.zc0 : jb.zc1;
+  const auto zc = KF_CONST(p == 0 ? jb.hyp0 : jb.hyp1) + KH_ZC;
   const double* Kr = jb.work + (p == 0 ? KF_W_K0 : KF_W_K1);
   double* krow = p == 0 ? jb.krow0 : jb.krow1;
   kf_lds_load(sP, p == 0 ? jb.P0 : jb.P1, Mq, Mq, Mq);
@@ -1104,10 +1106,10 @@ namespace zigp {
 // =============================================================================================================================
 constexpr size_t KF_BWD_LDS = sizeof(double) * (KF_WAVES * 4 * 16 * KF_NBMAX * KF_LD + 6 * KF_FRAG + 2 * KF_MQ_ * MAXD);
 struct KfState {
-  DevBuf in, mat, pts, acc, res, out, spill;
+  DevBuf in, mat, pts, acc, res, out, spill, fit;
 };
 static void kf_free(KfState* k) {
-  DevBuf* bs[] = {&k->in, &k->mat, &k->pts, &k->acc, &k->res, &k->out, &k->spill};
+  DevBuf* bs[] = {&k->in, &k->mat, &k->pts, &k->acc, &k->res, &k->out, &k->spill, &k->fit};
   for (DevBuf* b : bs) b->release();
   delete k;
 }
@@ -1168,16 +1170,179 @@ constexpr int KF_KROW_W = 2 + 2 * MAXD;
 __global__ void __launch_bounds__(256)
 k_kron_pw_reduce(const double* __restrict__ acc, int blocks, double kl_counted, double* __restrict__ pws) { kf_pw_reduce(acc, blocks, kl_counted, pws); }
 
+// =============================================================================================================================
+// device-resident fit loop (zigp_kron_fit_steps): free state -> parameter image, result block -> Adam update
+// =============================================================================================================================
+// The reference's fit is 50 000 minibatch steps of one model shape (scripts/onoff.py:375-381), each: gradient of cost = -(scale data - KL)
+// (:318,334), chained through the Log1pe transforms of the positive parameters (:88-123), one tf.train.AdamOptimizer per learning
+// rate (:325-350; TF defaults beta1 .9, beta2 .999, eps 1e-8, lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t)).  Here the parameter image
+// the kernels read is produced ON THE DEVICE from the free state (k_fit_update), so n steps are enqueued back to back on one stream and
+// the host synchronises once per call.  Block order of the flat free-state vector (ZIGP_FIT_BLOCKS = 17): for latent f, then g:
+// Z0, Z1, u, s, ell0, ell1, var0, var1; then the likelihood variance.
+constexpr int KFIT_BLOCKS = ZIGP_FIT_BLOCKS;
+struct KfFitDesc {
+  int off[KFIT_BLOCKS], n[KFIT_BLOCKS], dst[KFIT_BLOCKS], positive[KFIT_BLOCKS];   // offset in the free vector, size, offset in the parameter image
+  double lr[KFIT_BLOCKS];
+  int nlat, D0, D1, M[2][2], Mq[2][2];
+  int off_z[2][2], off_hyp;                    // parameter image
+  int res_size, res_krow0, res_krow1, res_gu, res_gs, res_pws, res_info;   // result block (doubles)
+  double beta1, beta2, eps;
+};
+struct KfFitArgs {
+  KfFitDesc d;
+  double *x, *m, *v;            // free state and Adam moments [n_free]
+  double* img;                  // parameter image (KfState::in)
+  const double* res;            // result block of the step that just ran
+  double* hist;                 // [n_steps][2]: data term, KL
+  int* fail;                    // [4]: 0 = fine, else {1 + step, factor job, pivot}
+  int step;                     // index within this call
+  double lr_sq, lr_den;         // sqrt(1 - beta2^t), 1 - beta1^t of this step (computed on the host exactly as zigp.optim.AdamGroups does)
+  int update;                   // 0: only free state -> image (first launch of a call)
+};
+
+// np.logaddexp(0, x) + 1e-6 (zigp/transforms.py Log1pe.forward; GPflow transforms.positive), branch structure of numpy's logaddexp
+__device__ __forceinline__ double kfit_softplus(double x) {
+#pragma clang fp contract(off)
+  const double sp = x < 0.0 ? log1p(exp(x)) : (x == 0.0 ? 0.6931471805599453 : x + log1p(exp(-x)));
+  return sp + 1e-6;
+}
+__device__ __forceinline__ double kfit_value(const KfFitDesc& d, int b, double x) { return d.positive[b] ? kfit_softplus(x) : x; }
+
+// free state -> parameter image: plain blocks are copied (transformed), the hyperparameter blocks fill their records of the hyper block
+__device__ __forceinline__ void kfit_write_image(const KfFitArgs& a) {
+  const KfFitDesc& d = a.d;
+  double* H = a.img + d.off_hyp;
+  for (int b = 0; b < KFIT_BLOCKS; ++b) {
+    const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8;      // 0 Z0, 1 Z1, 2 u, 3 s, 4 ell0, 5 ell1, 6 var0, 7 var1, 8 noise
+    const int h = b / 8;
+    for (int i = threadIdx.x; i < d.n[b]; i += blockDim.x) {
+#pragma clang fp contract(off)
+      const double val = kfit_value(d, b, a.x[d.off[b] + i]);
+      if (kind <= 3) a.img[d.dst[b] + i] = val;
+      else if (kind <= 5) { double* R = H + (2 * h + (kind - 4)) * KH_FAC; R[KH_ELL + i] = val; R[KH_INV + i] = 1.0 / val; }
+      else if (kind <= 7) H[(2 * h + (kind - 6)) * KH_FAC + KH_VAR] = val;
+      else H[KH_NOISE] = val;
+    }
+  }
+  __syncthreads();
+  // centre of the moment sums per (latent, factor, dimension): mid-range of the inducing inputs (as kronf_run computes it on the host);
+  // knn = var0 var1
+  const int t = threadIdx.x;
+  if (t < 4 * MAXD) {
+    const int h = t / (2 * MAXD), q = (t / MAXD) & 1, dd = t % MAXD, D = q == 0 ? d.D0 : d.D1;
+    if (h < d.nlat) {
+      double zc = 0.0;
+      if (dd < D) {
+        const double* Z = a.img + d.off_z[h][q];
+        double lo = Z[dd], hi = lo;
+        for (int mm = 1; mm < d.M[h][q]; ++mm) { const double z = Z[mm * D + dd]; lo = fmin(lo, z); hi = fmax(hi, z); }
+        zc = 0.5 * (lo + hi);
+      }
+      H[(2 * h + q) * KH_FAC + KH_ZC + dd] = zc;
+      if (dd >= D) { H[(2 * h + q) * KH_FAC + KH_INV + dd] = 0.0; H[(2 * h + q) * KH_FAC + KH_ELL + dd] = 0.0; }
+    }
+  }
+  if (t < d.nlat) H[KH_KNN + t] = H[(2 * t) * KH_FAC + KH_VAR] * H[(2 * t + 1) * KH_FAC + KH_VAR];
+}
+
+__global__ void __launch_bounds__(1024)
+k_fit_update(KfFitArgs a) {
+  const KfFitDesc& d = a.d;
+  const int t = threadIdx.x;
+  __shared__ int s_fail;
+  __shared__ double s_dl[2][2][MAXD], s_dv[2][2];
+  if (a.update) {
+    if (t == 0) {
+      int f = a.fail[0];
+      if (f == 0) {
+        const int* info = reinterpret_cast<const int*>(a.res + d.res_info);
+        for (int j = 0; j < 2 * d.nlat && f == 0; ++j)
+          if (info[2 * j] != 0) { f = 1 + a.step; a.fail[0] = f; a.fail[1] = j; a.fail[2] = info[2 * j]; }
+      }
+      s_fail = f;
+    }
+    __syncthreads();
+    if (s_fail) return;             // a Cholesky failed in this or an earlier step of the call: the state stays as it was before that step
+    const double* H = a.img + d.off_hyp;
+    const double* pws = a.res + d.res_pws;
+    // sums over the inducing rows (host order: m = 0, 1, ...), one thread each
+    if (t < 4 * (MAXD + 1)) {
+      const int h = t / (2 * (MAXD + 1)), q = (t / (MAXD + 1)) & 1, dd = t % (MAXD + 1), D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D;
+      if (h < d.nlat && dd <= D) {
+        const double* krow = a.res + h * d.res_size + (q == 0 ? d.res_krow0 : d.res_krow1);
+        double s = 0.0;
+        for (int mm = 0; mm < d.M[h][q]; ++mm) s += krow[mm * W + (dd == D ? 0 : 1 + D + dd)];
+        if (dd == D) s_dv[h][q] = s; else s_dl[h][q][dd] = s;
+      }
+    }
+    __syncthreads();
+    if (t == 0) {    // history of the step: data term, KL from its five scalars per latent (as kronf_run assembles it)
+#pragma clang fp contract(off)
+      double klsum = 0.0;
+      const double kl_ranks = pws[7];
+      if (kl_ranks > 0.0)
+        for (int h = 0; h < d.nlat; ++h) {
+          const double* vv = a.res + h * d.res_size;
+          const int M0 = d.M[h][0], M1 = d.M[h][1];
+          klsum += 0.5 * (vv[0] - kl_ranks * (double)M0 * M1 - vv[1] + vv[2] + (double)M1 * vv[3] + (double)M0 * vv[4]);
+        }
+      a.hist[2 * a.step] = pws[0];
+      a.hist[2 * a.step + 1] = klsum;
+    }
+    for (int b = 0; b < KFIT_BLOCKS; ++b) {
+      const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8;
+      const int h = b / 8;
+      if (h >= d.nlat && kind != 8) continue;
+      const double* R = a.res + h * d.res_size;
+      for (int i = t; i < d.n[b]; i += blockDim.x) {
+#pragma clang fp contract(off)
+        double gc;      // d ELBO / d (constrained value)
+        if (kind <= 1) {
+          const int q = kind, D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D, mm = i / D, dd = i - mm * D;
+          const double ell = H[(2 * h + q) * KH_FAC + KH_ELL + dd];
+          gc = R[(q == 0 ? d.res_krow0 : d.res_krow1) + mm * W + 1 + dd] / (ell * ell);
+        } else if (kind == 2) gc = R[d.res_gu + i];
+        else if (kind == 3) gc = R[d.res_gs + i];
+        else if (kind <= 5) { const int q = kind - 4; const double ell = H[(2 * h + q) * KH_FAC + KH_ELL + i]; gc = s_dl[h][q][i] / (ell * ell * ell); }
+        else if (kind <= 7) { const int q = kind - 6; gc = s_dv[h][q] / H[(2 * h + q) * KH_FAC + KH_VAR] + pws[2 + h] * H[(2 * h + 1 - q) * KH_FAC + KH_VAR]; }
+        else gc = pws[1];
+        const int e = d.off[b] + i;
+        const double x = a.x[e];
+        // cost = -ELBO; chain through the transform: d value / d x = sigmoid(x) for Log1pe (zigp/transforms.py)
+        const double g = -(d.positive[b] ? gc * (0.5 * (1.0 + tanh(0.5 * x))) : gc);
+        const double mnew = d.beta1 * a.m[e] + (1.0 - d.beta1) * g;
+        const double vnew = d.beta2 * a.v[e] + (1.0 - d.beta2) * g * g;
+        const double lr_t = d.lr[b] * a.lr_sq / a.lr_den;
+        a.m[e] = mnew; a.v[e] = vnew;
+        a.x[e] = x - lr_t * mnew / (sqrt(vnew) + d.eps);
+      }
+    }
+    __syncthreads();
+    __threadfence_block();
+  }
+  kfit_write_image(a);
+}
+
+struct KfFitCall {          // host side of one zigp_kron_fit_steps call
+  const zigp_kron_fit_opts* opts;
+  double *x, *m, *v; int64_t n_free;
+  int64_t t0; int n_steps; const int64_t* row_begin; int64_t batch;
+  const double *Xw, *Yw;     // host batches for steps with row_begin < 0 (batch -(1 + k) of them)
+  double *hist_data, *hist_kl;
+};
+
+// One ELBO step (or prediction) of the fused Kronecker path.  fit != nullptr: n_steps gradient steps with the Adam update on the device
+// (p then carries the sizes only; X / Y are the resident data set).
 static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, const double* Y, int64_t N, double jitter, double scale,
                      double g_offset, double f_mu, int include_kl, bool predict, double* out9, double* elbo_data, double* kl, zigp_kron_grads* grads,
-                     int lik, double* d_offset, bool dev_xy) {
+                     int lik, double* d_offset, bool dev_xy, const KfFitCall* fit = nullptr) {
   // dev_xy: X / Y are DEVICE pointers into the resident data set (zigp_set_data): nothing but the parameters is staged
   const int nlat = (lik == ZIGP_LIK_ONOFF) ? 2 : 1;
   const KfPlan pl = kf_plan(p, nlat);
   if (!c->kronf) { c->kronf = new (std::nothrow) KfState(); c->kronf_free = kf_free; if (!c->kronf) { c->err = "out of memory"; return ZIGP_EHIP; } }
   KfState& ks = *c->kronf;
   ZIGP_TRY(begin_staged_call(c));
-  const bool need_grad = grads != nullptr && !predict;
+  const bool need_grad = (grads != nullptr || fit != nullptr) && !predict;
   const int D0 = p->D0, D1 = p->D1, ldx = D0 + D1;
   const int64_t Npad = std::max<int64_t>(1024, round_up(N, 1024));
   KfHostLatent hl[2] = {{{p->M0f, p->M1f}, {p->Z0f, p->Z1f}, {p->ell0f, p->ell1f}, {p->var0f, p->var1f}, p->u_fm, p->u_fs_sqrt},
@@ -1197,8 +1362,9 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   // slots is summed over ranks in a data-parallel run; behind them, not downloaded: the point-wise block partials
   const size_t RES_KLV = 0, RES_KROW0 = 8, RES_KROW1 = RES_KROW0 + (size_t)R0 * KF_KROW_W, RES_GU = RES_KROW1 + (size_t)R1 * KF_KROW_W,
                RES_GS = RES_GU + r01, RES_SIZE = RES_GS + r01;
-  // ---- one staged host -> device copy: X, Y, per latent Z0, Z1, u, s
-  size_t off_x = 0, off_y = dev_xy ? 0 : (size_t)N * ldx, off = dev_xy ? 0 : off_y + (size_t)N;
+  // ---- the staged image (one host -> device copy): the PARAMETER IMAGE -- per latent Z0, Z1, u, s, then the hyperparameter block (KH_*) --
+  // followed by X, Y of a host minibatch.  In a fit call the parameter image is written by k_fit_update instead.
+  size_t off = 0;
   size_t off_z[2][2], off_u[2], off_s[2];
   for (int h = 0; h < nlat; ++h) {
     off_z[h][0] = off; off += (size_t)hl[h].M[0] * D0;
@@ -1206,20 +1372,47 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     off_u[h] = off; off += (size_t)hl[h].M[0] * hl[h].M[1];
     off_s[h] = off; off += (size_t)hl[h].M[0] * hl[h].M[1];
   }
-  const size_t n_in = off;
-  ZIGP_ENSURE(c, ks.in, n_in);
-  {
+  const size_t off_hyp = off; off += KH_SIZE;
+  const size_t n_par = off;
+  const size_t off_x = n_par, off_y = dev_xy ? off_x : off_x + (size_t)N * ldx;
+  const size_t n_in = dev_xy ? n_par : off_y + (size_t)N;
+  const size_t n_wrap = fit ? [&] { size_t k = 0; for (int i = 0; i < fit->n_steps; ++i) if (fit->row_begin[i] < 0) k = std::max<size_t>(k, (size_t)(-fit->row_begin[i])); return k; }() : 0;
+  ZIGP_ENSURE(c, ks.in, n_in + n_wrap * (size_t)N * (ldx + 1));
+  double* const d_hyp = ks.in.p + off_hyp;
+  double* const d_wrap = ks.in.p + n_in;      // fit: host batches [k][N][ldx], then their Y [k][N]
+  double zc[2][2][MAXD];
+  if (!fit) {
     ZIGP_PINNED(c, hin, n_in);
     if (!dev_xy) {
       memcpy(hin + off_x, X, sizeof(double) * N * ldx);
       if (Y) memcpy(hin + off_y, Y, sizeof(double) * N); else memset(hin + off_y, 0, sizeof(double) * N);
     }
+    double* H = hin + off_hyp;
+    memset(H, 0, sizeof(double) * KH_SIZE);
     for (int h = 0; h < nlat; ++h) {
       memcpy(hin + off_z[h][0], hl[h].Z[0], sizeof(double) * hl[h].M[0] * D0);
       memcpy(hin + off_z[h][1], hl[h].Z[1], sizeof(double) * hl[h].M[1] * D1);
       memcpy(hin + off_u[h], hl[h].u, sizeof(double) * hl[h].M[0] * hl[h].M[1]);
       memcpy(hin + off_s[h], hl[h].s, sizeof(double) * hl[h].M[0] * hl[h].M[1]);
+      for (int q = 0; q < 2; ++q) {
+        const int M = hl[h].M[q], D = q == 0 ? D0 : D1;
+        double* Rh = H + (2 * h + q) * KH_FAC;
+        for (int d = 0; d < MAXD; ++d) {
+          double lo = 0.0, hi = 0.0;
+          if (d < D) {
+            lo = hi = hl[h].Z[q][d];
+            for (int m = 1; m < M; ++m) { const double z = hl[h].Z[q][(size_t)m * D + d]; lo = std::min(lo, z); hi = std::max(hi, z); }
+          }
+          zc[h][q][d] = 0.5 * (lo + hi);
+          Rh[KH_ZC + d] = zc[h][q][d];
+          Rh[KH_INV + d] = d < D ? 1.0 / hl[h].ell[q][d] : 0.0;
+          Rh[KH_ELL + d] = d < D ? hl[h].ell[q][d] : 0.0;
+        }
+        Rh[KH_VAR] = hl[h].var[q];
+      }
+      H[KH_KNN + h] = hl[h].var[0] * hl[h].var[1];
     }
+    H[KH_NOISE] = p->noise;
     ZIGP_HIP(c, hipMemcpyAsync(ks.in.p, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, c->stream));
   }
   if (predict) ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
@@ -1234,7 +1427,6 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
   auto pts = [&](int h) { return ks.pts.p + (size_t)h * pts_lat; };
   auto res = [&](int h) { return ks.res.p + (size_t)h * RES_SIZE; };
   double* d_pwacc = ks.res.p + n_res;
-  if (c->comm && !predict) ZIGP_HIP(c, hipMemsetAsync(ks.res.p, 0, sizeof(double) * RES_INFO, c->stream));   // parts a value-only / single-latent step leaves unwritten
 
   int Mq[2][2];
   for (int h = 0; h < nlat; ++h)
@@ -1256,218 +1448,294 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_backward<1, 7, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_forward<1, 7, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_backward<1, 7, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_latent), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kfl_latent_lds(16 * 7)));
     attr_set = true;
   }
-  // ---- factor stage
-  double zc[2][2][MAXD];
-  {
-    KfFactorArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    for (int h = 0; h < nlat; ++h)
+  int* hinfo = nullptr;
+
+  // ---- the launches of ONE step on rows (Xd, Yd) -- everything else it reads lives on the device (parameter image, hyper block)
+  auto enqueue = [&](const double* Xd, const double* Yd) -> int {
+    if (c->comm && !predict) ZIGP_HIP(c, hipMemsetAsync(ks.res.p, 0, sizeof(double) * RES_INFO, c->stream));   // parts a value-only / single-latent step leaves unwritten
+    // ---- factor stage
+    {
+      KfFactorArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      for (int h = 0; h < nlat; ++h)
+        for (int q = 0; q < 2; ++q) {
+          KfFactorJob& jb = fa.job[2 * h + q];
+          jb.Z = ks.in.p + off_z[h][q]; jb.M = hl[h].M[q]; jb.D = q == 0 ? D0 : D1; jb.Mq = Mq[h][q];
+          jb.hyp = d_hyp + (2 * h + q) * KH_FAC;
+          jb.K = fac(h, q); jb.P = fac(h, q) + FAC_P; jb.PF = fac(h, q) + FAC_PF; jb.dvec = fac(h, q) + FAC_DV; jb.Zs = fac(h, q) + FAC_ZS;
+        }
+      fa.jitter = jitter; fa.piv_rtol = c->pivot_rtol;
+      if (predict) { fa.info = c->d_info; fa.own_slots = 0; }
+      else { fa.info = reinterpret_cast<int*>(ks.res.p + RES_INFO); fa.own_slots = 1; }
+      hipLaunchKernelGGL(k_kf_factor, dim3(2 * nlat), dim3(1024), sizeof(double) * PB * PBLD, c->stream, fa);
+      ZIGP_HIP(c, hipGetLastError());
+    }
+    if (predict) ZIGP_TRY(request_info(c, &hinfo));   // value / gradient steps: the status slots come back with the result block
+    {
+      KfLatentArgs la;
+      memset(&la, 0, sizeof(la));
+      for (int h = 0; h < nlat; ++h) {
+        KfLatentJob& jb = la.job[h];
+        jb.M0 = hl[h].M[0]; jb.M1 = hl[h].M[1]; jb.Mq0 = Mq[h][0]; jb.Mq1 = Mq[h][1];
+        jb.P0 = fac(h, 0) + FAC_P; jb.P1 = fac(h, 1) + FAC_P; jb.dvec0 = fac(h, 0) + FAC_DV; jb.dvec1 = fac(h, 1) + FAC_DV;
+        jb.PF0 = fac(h, 0) + FAC_PF; jb.PF1 = fac(h, 1) + FAC_PF;
+        jb.u = ks.in.p + off_u[h]; jb.s = ks.in.p + off_s[h];
+        double* L = lat(h);
+        jb.U = L + LAT_U; jb.S2 = L + LAT_S2; jb.T0 = L + LAT_T0; jb.T1 = L + LAT_T1; jb.Al = L + LAT_AL;
+        jb.AlF = L + LAT_ALF; jb.S2F = L + LAT_S2F; jb.AlTF = L + LAT_ALTF; jb.S2TF = L + LAT_S2TF;
+        jb.klv = res(h) + RES_KLV;
+      }
+      if (pl.large) {
+        int mq1 = 0;
+        for (int h = 0; h < nlat; ++h) mq1 = std::max(mq1, la.job[h].Mq1);
+        hipLaunchKernelGGL(k_kfl_latent, dim3(nlat), dim3(1024), kfl_latent_lds(mq1), c->stream, la);
+      }
+      else hipLaunchKernelGGL(k_kf_latent, dim3(nlat), dim3(1024), 0, c->stream, la);
+      ZIGP_HIP(c, hipGetLastError());
+    }
+    // ---- point stage
+    KfArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.X = Xd; ka.N = N; ka.Npad = Npad; ka.ldx = ldx; ka.ntiles = (int)(Npad / 16);
+    for (int h = 0; h < nlat; ++h) {
+      KfLat& L = ka.lat[h];
       for (int q = 0; q < 2; ++q) {
-        KfFactorJob& jb = fa.job[2 * h + q];
-        const int M = hl[h].M[q], D = q == 0 ? D0 : D1;
-        jb.Z = ks.in.p + off_z[h][q]; jb.M = M; jb.D = D; jb.Mq = Mq[h][q];
-        for (int d = 0; d < MAXD; ++d) jb.inv_ell[d] = d < D ? 1.0 / hl[h].ell[q][d] : 0.0;
-        jb.var = hl[h].var[q];
-        jb.K = fac(h, q); jb.P = fac(h, q) + FAC_P; jb.PF = fac(h, q) + FAC_PF; jb.dvec = fac(h, q) + FAC_DV; jb.Zs = fac(h, q) + FAC_ZS;
-        for (int d = 0; d < MAXD; ++d) {
-          double lo = 0.0, hi = 0.0;
-          if (d < D) {
-            lo = hi = hl[h].Z[q][d];
-            for (int m = 1; m < M; ++m) { const double z = hl[h].Z[q][(size_t)m * D + d]; lo = std::min(lo, z); hi = std::max(hi, z); }
-          }
-          zc[h][q][d] = 0.5 * (lo + hi);
+        KfFac& f = L.f[q];
+        f.M = hl[h].M[q]; f.nb = Mq[h][q] / 16; f.D = q == 0 ? D0 : D1; f.col0 = q == 0 ? 0 : D0;
+        f.hyp = d_hyp + (2 * h + q) * KH_FAC;
+        f.Zs = fac(h, q) + FAC_ZS; f.PF = fac(h, q) + FAC_PF;
+      }
+      double* Lm = lat(h);
+      L.AlF = Lm + LAT_ALF; L.S2F = Lm + LAT_S2F; L.AlTF = Lm + LAT_ALTF; L.S2TF = Lm + LAT_S2TF;
+      double* P = pts(h);
+      L.part = P; L.gm = P + 4 * Npad; L.gv = P + 5 * Npad; L.dq0 = P + 6 * Npad; L.dq1 = P + 7 * Npad;
+    }
+    {
+      const int waves = std::min(ka.ntiles, pl.large ? 1024 / nlat : 2048);
+      ka.tpw = (ka.ntiles + waves - 1) / waves;
+      const int nw = (ka.ntiles + ka.tpw - 1) / ka.tpw;
+      const dim3 grid((nw + KF_WAVES - 1) / KF_WAVES, nlat);
+      if (pl.large && large_exact) hipLaunchKernelGGL((k_kfl_forward<1, 7, true, true>), grid, dim3(64 * KF_WAVES), lds_fwd, c->stream, ka);
+      else if (pl.large) hipLaunchKernelGGL((k_kfl_forward<1, 7, true, false>), grid, dim3(64 * KF_WAVES), lds_fwd, c->stream, ka);
+      else ZIGP_TRY(kf_launch_small_latents(c, Mq, nlat, false, grid.x, ka));
+      ZIGP_HIP(c, hipGetLastError());
+    }
+    KronPwArgs a;
+    memset(&a, 0, sizeof(a));
+    const int gl_ = nlat - 1;   // latent whose buffers stand in for g (unused by the single-latent kernels)
+    a.part_f = pts(0); a.part_g = pts(gl_); a.Y = Yd; a.N = N; a.Nc = Npad;
+    a.hyp = d_hyp;              // knn_f, knn_g, noise: from the device block (the single-latent heads read the by-value fields below)
+    if (!fit) { a.knn_f = p->var0f * p->var1f; a.knn_g = p->var0g * p->var1g; a.noise = p->noise; }
+    a.g_offset = g_offset; a.f_offset = f_mu; a.scale = scale;
+    a.gm_f = need_grad ? pts(0) + 4 * Npad : nullptr; a.gv_f = pts(0) + 5 * Npad; a.gm_g = pts(gl_) + 4 * Npad; a.gv_g = pts(gl_) + 5 * Npad;
+    a.dq0_f = pts(0) + 6 * Npad; a.dq1_f = pts(0) + 7 * Npad; a.dq0_g = pts(gl_) + 6 * Npad; a.dq1_g = pts(gl_) + 7 * Npad;
+    a.acc = d_pwacc; a.out9 = nullptr; a.ld9 = N;
+    if (predict) {
+      const int rows = nlat == 2 ? 9 : 4;
+      ZIGP_ENSURE(c, ks.out, (size_t)rows * N);
+      a.out9 = ks.out.p;
+      if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<true>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
+      else hipLaunchKernelGGL(k_kron_head_pointwise<true>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
+      ZIGP_HIP(c, hipGetLastError());
+      return 0;
+    }
+    if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_kron_head_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
+    if (!need_grad) hipLaunchKernelGGL(k_kron_pw_reduce, dim3(1), dim3(256), 0, c->stream, d_pwacc, pw_blocks, include_kl ? 1.0 : 0.0, ks.res.p + RES_PWS);
+    ZIGP_HIP(c, hipGetLastError());
+    if (need_grad) {
+      const int waves = std::min(ka.ntiles, 1024 / nlat);   // one wave per SIMD of the chip: the kernels hold ~400-500 registers per lane
+      ka.tpw = (ka.ntiles + waves - 1) / waves;
+      const int nw = (ka.ntiles + ka.tpw - 1) / ka.tpw;
+      const int nwg = (nw + KF_WAVES - 1) / KF_WAVES;
+      int nparts;
+      if (!pl.large) {
+        nparts = nwg * KF_WAVES;
+        ZIGP_ENSURE(c, ks.acc, (size_t)2 * nparts * nblk * 256);
+        for (int h = 0; h < nlat; ++h) ka.lat[h].acc = ks.acc.p + (size_t)h * nparts * nblk * 256;
+        ZIGP_TRY(kf_launch_small_latents(c, Mq, nlat, true, (unsigned)nwg, ka));
+      } else {
+        // The backward kernel spills ~4 KB of operands per point and latent (at 10 x 100), which k_kfl_accum then sums over the points.  The
+        // rows go through in RANGES of <= 1024 tiles (16 384 rows: <= 128 MB of records for both latents, Infinity-Cache resident), one
+        // backward + one accumulate launch per range.  The split of the tiles into accumulation parts of tps tiles does not depend on the
+        // ranges (a range is a whole number of parts), so the partial sums -- and k_kf_reduce's fixed-order total -- are the same bits as
+        // with one range over everything; memory no longer grows with the row count (rounds 2-3: 0.86 GB for the pptr full batch, and a
+        // 64 GB cap with an error beyond it).
+        size_t rec[2] = {0, 0};
+        for (int h = 0; h < nlat; ++h) rec[h] = (size_t)64 * (Mq[h][0] + Mq[h][1]);
+        const int tps = std::max(4, std::min(64, ka.ntiles / 16));     // tiles per accumulation part (4 for a minibatch: the chain of dependent loads is short)
+        nparts = (ka.ntiles + tps - 1) / tps;
+        const int range_tiles = std::max(1, c->kron_range_tiles / tps) * tps;
+        const int spill_tiles = std::min(ka.ntiles, range_tiles);
+        ZIGP_ENSURE(c, ks.spill, (rec[0] + (nlat == 2 ? rec[1] : 0)) * spill_tiles);
+        ka.lat[0].spill = ks.spill.p;
+        if (nlat == 2) ka.lat[1].spill = ks.spill.p + rec[0] * spill_tiles;
+        ZIGP_ENSURE(c, ks.acc, (size_t)2 * nparts * nblk * 256);
+        KflAccArgs aa;
+        memset(&aa, 0, sizeof(aa));
+        aa.X = ka.X; aa.N = N; aa.ldx = ldx; aa.ntiles = ka.ntiles; aa.tps = tps; aa.nb0c = pl.nb0c; aa.nb1c = pl.nb1c;
+        for (int h = 0; h < nlat; ++h) {
+          KflAccLat& L = aa.lat[h];
+          L.spill = ka.lat[h].spill; L.gm = ka.lat[h].gm; L.gv = ka.lat[h].gv;
+          L.acc = ks.acc.p + (size_t)h * nparts * nblk * 256;
+          ka.lat[h].acc = L.acc;
+          L.nb0 = Mq[h][0] / 16; L.nb1 = Mq[h][1] / 16; L.D0 = D0; L.D1 = D1;
+          L.hyp0 = d_hyp + (2 * h) * KH_FAC; L.hyp1 = d_hyp + (2 * h + 1) * KH_FAC;
+        }
+        for (int t0 = 0; t0 < ka.ntiles; t0 += range_tiles) {
+          const int t1 = std::min(t0 + range_tiles, ka.ntiles), nt = t1 - t0;
+          const int rwaves = std::min(nt, 1024 / nlat);
+          ka.tile0 = t0; ka.tile1 = t1; ka.tpw = (nt + rwaves - 1) / rwaves;
+          const int rnw = (nt + ka.tpw - 1) / ka.tpw, rnwg = (rnw + KF_WAVES - 1) / KF_WAVES;
+          if (large_exact) hipLaunchKernelGGL((k_kfl_backward<1, 7, true, true>), dim3(rnwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
+          else hipLaunchKernelGGL((k_kfl_backward<1, 7, true, false>), dim3(rnwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
+          ZIGP_HIP(c, hipGetLastError());
+          aa.tile0 = t0; aa.tile1 = t1; aa.part0 = t0 / tps;
+          hipLaunchKernelGGL(k_kfl_accum, dim3((nblk + 3) / 4, (nt + tps - 1) / tps, nlat), dim3(256), 0, c->stream, aa);
+          ZIGP_HIP(c, hipGetLastError());
         }
       }
-    fa.jitter = jitter; fa.piv_rtol = c->pivot_rtol;
-    if (predict) { fa.info = c->d_info; fa.own_slots = 0; }
-    else { fa.info = reinterpret_cast<int*>(ks.res.p + RES_INFO); fa.own_slots = 1; }
-    hipLaunchKernelGGL(k_kf_factor, dim3(2 * nlat), dim3(1024), sizeof(double) * PB * PBLD, c->stream, fa);
-    ZIGP_HIP(c, hipGetLastError());
-  }
-  int* hinfo = nullptr;
-  if (predict) ZIGP_TRY(request_info(c, &hinfo));   // value / gradient steps: the status slots come back with the result block
-  {
-    KfLatentArgs la;
-    memset(&la, 0, sizeof(la));
-    for (int h = 0; h < nlat; ++h) {
-      KfLatentJob& jb = la.job[h];
-      jb.M0 = hl[h].M[0]; jb.M1 = hl[h].M[1]; jb.Mq0 = Mq[h][0]; jb.Mq1 = Mq[h][1];
-      jb.P0 = fac(h, 0) + FAC_P; jb.P1 = fac(h, 1) + FAC_P; jb.dvec0 = fac(h, 0) + FAC_DV; jb.dvec1 = fac(h, 1) + FAC_DV;
-      jb.PF0 = fac(h, 0) + FAC_PF; jb.PF1 = fac(h, 1) + FAC_PF;
-      jb.u = ks.in.p + off_u[h]; jb.s = ks.in.p + off_s[h];
-      double* L = lat(h);
-      jb.U = L + LAT_U; jb.S2 = L + LAT_S2; jb.T0 = L + LAT_T0; jb.T1 = L + LAT_T1; jb.Al = L + LAT_AL;
-      jb.AlF = L + LAT_ALF; jb.S2F = L + LAT_S2F; jb.AlTF = L + LAT_ALTF; jb.S2TF = L + LAT_S2TF;
-      jb.klv = res(h) + RES_KLV;
-    }
-    if (pl.large) {
-      static bool attr = false;
-      if (!attr) {
-        ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kfl_latent), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kfl_latent_lds(16 * 7)));
-        attr = true;
+      hipLaunchKernelGGL(k_kf_reduce, dim3(nblk * 256 / 16 + 1, nlat), dim3(256), 0, c->stream, ka.lat[0].acc, ka.lat[gl_].acc, nparts,
+                         lat(0) + LAT_WORK, lat(gl_) + LAT_WORK, pl.nb0c, pl.nb1c, Mq[0][0] / 16, Mq[0][1] / 16, Mq[gl_][0] / 16, Mq[gl_][1] / 16,
+                         d_pwacc, pw_blocks, include_kl ? 1.0 : 0.0, ks.res.p + RES_PWS);
+      ZIGP_HIP(c, hipGetLastError());
+      KflFinishArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      for (int h = 0; h < nlat; ++h) {
+        KfFinishJob& jb = fa.job[h];
+        jb.M0 = hl[h].M[0]; jb.M1 = hl[h].M[1]; jb.Mq0 = Mq[h][0]; jb.Mq1 = Mq[h][1]; jb.D0 = D0; jb.D1 = D1;
+        jb.P0 = fac(h, 0) + FAC_P; jb.P1 = fac(h, 1) + FAC_P; jb.dvec0 = fac(h, 0) + FAC_DV; jb.dvec1 = fac(h, 1) + FAC_DV;
+        jb.PF0 = fac(h, 0) + FAC_PF; jb.PF1 = fac(h, 1) + FAC_PF;
+        jb.K0 = fac(h, 0); jb.K1 = fac(h, 1); jb.Z0 = ks.in.p + off_z[h][0]; jb.Z1 = ks.in.p + off_z[h][1];
+        jb.hyp0 = d_hyp + (2 * h) * KH_FAC; jb.hyp1 = d_hyp + (2 * h + 1) * KH_FAC;
+        double* L = lat(h);
+        jb.U = L + LAT_U; jb.S2 = L + LAT_S2; jb.T0 = L + LAT_T0; jb.T1 = L + LAT_T1; jb.Al = L + LAT_AL; jb.s = ks.in.p + off_s[h];
+        jb.work = L + LAT_WORK;
+        jb.krow0 = res(h) + RES_KROW0; jb.krow1 = res(h) + RES_KROW1; jb.gu = res(h) + RES_GU; jb.gs = res(h) + RES_GS;
       }
-      int mq1 = 0;
-      for (int h = 0; h < nlat; ++h) mq1 = std::max(mq1, la.job[h].Mq1);
-      hipLaunchKernelGGL(k_kfl_latent, dim3(nlat), dim3(1024), kfl_latent_lds(mq1), c->stream, la);
+      fa.jitter = jitter; fa.with_kl = include_kl ? 1 : 0;
+      fa.ldw = wl.ldw; fa.wS2 = wl.S2; fa.wP0 = wl.P0; fa.wP1 = wl.P1; fa.wK0 = wl.K0; fa.wK1 = wl.K1;
+      fa.scratch_off = (int64_t)wl.total; fa.scratch_set = (int64_t)SCR_SET;
+      if (pl.large) {
+        int nbmax = 1;
+        for (int h = 0; h < nlat; ++h) nbmax = std::max(nbmax, std::max(Mq[h][0], Mq[h][1]) / 16);
+        const dim3 grid(nbmax, 2, nlat);
+        hipLaunchKernelGGL(k_kfl_finish<1>, grid, dim3(KFL_FIN_THREADS), 0, c->stream, fa);
+        hipLaunchKernelGGL(k_kfl_finish<2>, grid, dim3(KFL_FIN_THREADS), 0, c->stream, fa);
+        hipLaunchKernelGGL(k_kfl_finish<3>, grid, dim3(KFL_FIN_THREADS), 0, c->stream, fa);
+      } else {
+        KfFinishArgs fs;
+        memset(&fs, 0, sizeof(fs));
+        fs.job[0] = fa.job[0]; fs.job[1] = fa.job[1]; fs.jitter = fa.jitter; fs.with_kl = fa.with_kl;
+        hipLaunchKernelGGL(k_kf_finish, dim3(2, nlat), dim3(1024), KF_FIN_LDS, c->stream, fs);
+      }
+      ZIGP_HIP(c, hipGetLastError());
     }
-    else hipLaunchKernelGGL(k_kf_latent, dim3(nlat), dim3(1024), 0, c->stream, la);
-    ZIGP_HIP(c, hipGetLastError());
-  }
-  // ---- point stage
-  KfArgs ka;
-  memset(&ka, 0, sizeof(ka));
-  ka.X = dev_xy ? X : ks.in.p + off_x; ka.N = N; ka.Npad = Npad; ka.ldx = ldx; ka.ntiles = (int)(Npad / 16);
-  for (int h = 0; h < nlat; ++h) {
-    KfLat& L = ka.lat[h];
-    for (int q = 0; q < 2; ++q) {
-      KfFac& f = L.f[q];
-      const int D = q == 0 ? D0 : D1;
-      f.M = hl[h].M[q]; f.nb = Mq[h][q] / 16; f.D = D; f.col0 = q == 0 ? 0 : D0;
-      for (int d = 0; d < MAXD; ++d) { f.inv_ell[d] = d < D ? 1.0 / hl[h].ell[q][d] : 0.0; f.zc[d] = zc[h][q][d]; }
-      f.var = hl[h].var[q];
-      f.Zs = fac(h, q) + FAC_ZS; f.PF = fac(h, q) + FAC_PF;
+    if (c->comm) {   // data-parallel run: the block (cleared at the start of the step) is summed over ranks where it lies
+      // a rank that does not count the KL (include_kl = 0) must not add its scalars, which the latent kernel writes regardless
+      if (!include_kl) for (int h = 0; h < nlat; ++h) ZIGP_HIP(c, hipMemsetAsync(res(h) + RES_KLV, 0, sizeof(double) * 8, c->stream));
+      ZIGP_TRY(comm_allreduce(c, ks.res.p, RES_INFO));
     }
-    double* Lm = lat(h);
-    L.AlF = Lm + LAT_ALF; L.S2F = Lm + LAT_S2F; L.AlTF = Lm + LAT_ALTF; L.S2TF = Lm + LAT_S2TF;
-    double* P = pts(h);
-    L.part = P; L.gm = P + 4 * Npad; L.gv = P + 5 * Npad; L.dq0 = P + 6 * Npad; L.dq1 = P + 7 * Npad;
-    L.knn = hl[h].var[0] * hl[h].var[1];
-  }
-  {
-    const int waves = std::min(ka.ntiles, pl.large ? 1024 / nlat : 2048);
-    ka.tpw = (ka.ntiles + waves - 1) / waves;
-    const int nw = (ka.ntiles + ka.tpw - 1) / ka.tpw;
-    const dim3 grid((nw + KF_WAVES - 1) / KF_WAVES, nlat);
-    if (pl.large && large_exact) hipLaunchKernelGGL((k_kfl_forward<1, 7, true, true>), grid, dim3(64 * KF_WAVES), lds_fwd, c->stream, ka);
-    else if (pl.large) hipLaunchKernelGGL((k_kfl_forward<1, 7, true, false>), grid, dim3(64 * KF_WAVES), lds_fwd, c->stream, ka);
-    else ZIGP_TRY(kf_launch_small_latents(c, Mq, nlat, false, grid.x, ka));
+    return 0;
+  };
+
+  static const char* const fac_names[4] = {"Kronecker factor 0 of Kuu (latent f)", "Kronecker factor 1 of Kuu (latent f)",
+                                           "Kronecker factor 0 of Kuu (latent g)", "Kronecker factor 1 of Kuu (latent g)"};
+  // =========================================================================================================================
+  // fit call: n_steps steps back to back, parameters updated on the device, ONE synchronisation at the end
+  // =========================================================================================================================
+  if (fit) {
+    KfFitArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    KfFitDesc& d = fa.d;
+    d.nlat = nlat; d.D0 = D0; d.D1 = D1;
+    size_t o = 0;
+    for (int h = 0; h < 2; ++h) {
+      const int M0 = hl[h].M[0], M1 = hl[h].M[1];
+      const int sizes[8] = {M0 * D0, M1 * D1, M0 * M1, M0 * M1, D0, D1, 1, 1};
+      const size_t dsts[8] = {off_z[h][0], off_z[h][1], off_u[h], off_s[h], 0, 0, 0, 0};
+      for (int k = 0; k < 8; ++k) {
+        const int b = 8 * h + k;
+        d.off[b] = (int)o; d.n[b] = sizes[k]; d.dst[b] = (int)dsts[k]; d.positive[b] = fit->opts->positive[b]; d.lr[b] = fit->opts->lr[b];
+        o += sizes[k];
+      }
+      for (int q = 0; q < 2; ++q) { d.M[h][q] = hl[h].M[q]; d.Mq[h][q] = Mq[h][q]; d.off_z[h][q] = (int)off_z[h][q]; }
+    }
+    d.off[16] = (int)o; d.n[16] = 1; d.dst[16] = 0; d.positive[16] = fit->opts->positive[16]; d.lr[16] = fit->opts->lr[16];
+    o += 1;
+    if ((int64_t)o != fit->n_free) { c->err = "zigp_kron_fit_steps: n_free does not match the model sizes"; return ZIGP_EARG; }
+    d.off_hyp = (int)off_hyp;
+    d.res_size = (int)RES_SIZE; d.res_krow0 = (int)RES_KROW0; d.res_krow1 = (int)RES_KROW1; d.res_gu = (int)RES_GU; d.res_gs = (int)RES_GS;
+    d.res_pws = (int)RES_PWS; d.res_info = (int)RES_INFO;
+    d.beta1 = fit->opts->beta1; d.beta2 = fit->opts->beta2; d.eps = fit->opts->eps;
+    const size_t nf = (size_t)fit->n_free, n_hist = (size_t)2 * fit->n_steps;
+    const size_t n_state = 3 * nf + n_hist + 8;
+    ZIGP_ENSURE(c, ks.fit, n_state);
+    fa.x = ks.fit.p; fa.m = fa.x + nf; fa.v = fa.m + nf; fa.hist = fa.v + nf; fa.fail = reinterpret_cast<int*>(fa.hist + n_hist);
+    fa.img = ks.in.p; fa.res = ks.res.p;
+    {
+      ZIGP_PINNED(c, hst, n_state);
+      memcpy(hst, fit->x, sizeof(double) * nf); memcpy(hst + nf, fit->m, sizeof(double) * nf); memcpy(hst + 2 * nf, fit->v, sizeof(double) * nf);
+      memset(hst + 3 * nf, 0, sizeof(double) * (n_hist + 8));
+      ZIGP_HIP(c, hipMemcpyAsync(ks.fit.p, hst, sizeof(double) * n_state, hipMemcpyHostToDevice, c->stream));
+      if (n_wrap) {
+        const size_t nw = n_wrap * (size_t)N * (ldx + 1);
+        ZIGP_PINNED(c, hw, nw);
+        memcpy(hw, fit->Xw, sizeof(double) * n_wrap * N * ldx);
+        memcpy(hw + n_wrap * (size_t)N * ldx, fit->Yw, sizeof(double) * n_wrap * N);
+        ZIGP_HIP(c, hipMemcpyAsync(d_wrap, hw, sizeof(double) * nw, hipMemcpyHostToDevice, c->stream));
+      }
+    }
+    ZIGP_HIP(c, hipMemsetAsync(ks.in.p + off_hyp, 0, sizeof(double) * KH_SIZE, c->stream));
+    fa.update = 0; fa.step = 0;
+    hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(1024), 0, c->stream, fa);       // free state -> parameter image
     ZIGP_HIP(c, hipGetLastError());
+    fa.update = 1;
+    for (int i = 0; i < fit->n_steps; ++i) {
+      const int64_t rb = fit->row_begin[i];
+      const double* Xd = rb >= 0 ? X + rb * ldx : d_wrap + (size_t)(-rb - 1) * N * ldx;
+      const double* Yd = rb >= 0 ? Y + rb : d_wrap + n_wrap * (size_t)N * ldx + (size_t)(-rb - 1) * N;
+      ZIGP_TRY(enqueue(Xd, Yd));
+      // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), t counted from 1 (zigp/optim.py AdamGroups.step): the two t-dependent factors from the host
+      const double t = (double)(fit->t0 + i + 1);
+      fa.step = i; fa.lr_sq = std::sqrt(1.0 - std::pow(d.beta2, t)); fa.lr_den = 1.0 - std::pow(d.beta1, t);
+      hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(1024), 0, c->stream, fa);
+      ZIGP_HIP(c, hipGetLastError());
+    }
+    double* hst = nullptr;
+    ZIGP_TRY(download(c, ks.fit.p, n_state, &hst));
+    ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+    const int* hfail = reinterpret_cast<const int*>(hst + 3 * nf + n_hist);
+    memcpy(fit->x, hst, sizeof(double) * nf); memcpy(fit->m, hst + nf, sizeof(double) * nf); memcpy(fit->v, hst + 2 * nf, sizeof(double) * nf);
+    const int done = hfail[0] ? hfail[0] - 1 : fit->n_steps;       // steps whose update was applied
+    for (int i = 0; i < fit->n_steps; ++i) {
+      if (fit->hist_data) fit->hist_data[i] = i < done ? hst[3 * nf + 2 * i] : NAN;
+      if (fit->hist_kl) fit->hist_kl[i] = i < done ? hst[3 * nf + 2 * i + 1] : NAN;
+    }
+    if (hfail[0]) {
+      char b[256];
+      snprintf(b, sizeof(b), "Cholesky failed in step %d of this zigp_kron_fit_steps call (iteration %lld): %s not positive definite at pivot %d; "
+               "the state returned is the one before that step", hfail[0] - 1, (long long)(fit->t0 + hfail[0] - 1), fac_names[hfail[1] & 3], hfail[2]);
+      c->err = b; c->info = hfail[2];
+      return ZIGP_ENOTPD;
+    }
+    return 0;
   }
-  KronPwArgs a;
-  const int gl_ = nlat - 1;   // latent whose buffers stand in for g (unused by the single-latent kernels)
-  a.part_f = pts(0); a.part_g = pts(gl_); a.Y = Y ? (dev_xy ? Y : ks.in.p + off_y) : nullptr; a.N = N; a.Nc = Npad;
-  a.knn_f = p->var0f * p->var1f; a.knn_g = p->var0g * p->var1g; a.noise = p->noise; a.g_offset = g_offset; a.f_offset = f_mu; a.scale = scale;
-  a.gm_f = need_grad ? pts(0) + 4 * Npad : nullptr; a.gv_f = pts(0) + 5 * Npad; a.gm_g = pts(gl_) + 4 * Npad; a.gv_g = pts(gl_) + 5 * Npad;
-  a.dq0_f = pts(0) + 6 * Npad; a.dq1_f = pts(0) + 7 * Npad; a.dq0_g = pts(gl_) + 6 * Npad; a.dq1_g = pts(gl_) + 7 * Npad;
-  a.acc = d_pwacc; a.out9 = nullptr; a.ld9 = N;
+
+  ZIGP_TRY(enqueue(dev_xy ? X : ks.in.p + off_x, Y ? (dev_xy ? Y : ks.in.p + off_y) : nullptr));
   if (predict) {
     const int rows = nlat == 2 ? 9 : 4;
-    ZIGP_ENSURE(c, ks.out, (size_t)rows * N);
-    a.out9 = ks.out.p;
-    if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<true>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
-    else hipLaunchKernelGGL(k_kron_head_pointwise<true>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
-    ZIGP_HIP(c, hipGetLastError());
     ZIGP_HIP(c, hipMemcpyAsync(out9, ks.out.p, sizeof(double) * rows * N, hipMemcpyDeviceToHost, c->stream));
     ZIGP_HIP(c, hipStreamSynchronize(c->stream));
     return info_result(c, hinfo, "a Kronecker factor of Kuu");
   }
-  if (nlat == 2) hipLaunchKernelGGL(k_kron_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a);
-  else hipLaunchKernelGGL(k_kron_head_pointwise<false>, dim3(pw_blocks), dim3(PW_THREADS), 0, c->stream, a, lik);
-  if (!need_grad) hipLaunchKernelGGL(k_kron_pw_reduce, dim3(1), dim3(256), 0, c->stream, d_pwacc, pw_blocks, include_kl ? 1.0 : 0.0, ks.res.p + RES_PWS);
-  ZIGP_HIP(c, hipGetLastError());
-  if (need_grad) {
-    const int waves = std::min(ka.ntiles, 1024 / nlat);   // one wave per SIMD of the chip: the kernels hold ~400-500 registers per lane
-    ka.tpw = (ka.ntiles + waves - 1) / waves;
-    const int nw = (ka.ntiles + ka.tpw - 1) / ka.tpw;
-    const int nwg = (nw + KF_WAVES - 1) / KF_WAVES;
-    int nparts;
-    if (!pl.large) {
-      nparts = nwg * KF_WAVES;
-      ZIGP_ENSURE(c, ks.acc, (size_t)2 * nparts * nblk * 256);
-      for (int h = 0; h < nlat; ++h) ka.lat[h].acc = ks.acc.p + (size_t)h * nparts * nblk * 256;
-      ZIGP_TRY(kf_launch_small_latents(c, Mq, nlat, true, (unsigned)nwg, ka));
-    } else {
-      // The backward kernel spills ~4 KB of operands per point and latent (at 10 x 100), which k_kfl_accum then sums over the points.  The
-      // rows go through in RANGES of <= 1024 tiles (16 384 rows: <= 128 MB of records for both latents, Infinity-Cache resident), one
-      // backward + one accumulate launch per range.  The split of the tiles into accumulation parts of tps tiles does not depend on the
-      // ranges (a range is a whole number of parts), so the partial sums -- and k_kf_reduce's fixed-order total -- are the same bits as
-      // with one range over everything; memory no longer grows with the row count (rounds 2-3: 0.86 GB for the pptr full batch, and a
-      // 64 GB cap with an error beyond it).
-      size_t rec[2] = {0, 0};
-      for (int h = 0; h < nlat; ++h) rec[h] = (size_t)64 * (Mq[h][0] + Mq[h][1]);
-      const int tps = std::max(4, std::min(64, ka.ntiles / 16));     // tiles per accumulation part (4 for a minibatch: the chain of dependent loads is short)
-      nparts = (ka.ntiles + tps - 1) / tps;
-      const int range_tiles = std::max(1, c->kron_range_tiles / tps) * tps;
-      const int spill_tiles = std::min(ka.ntiles, range_tiles);
-      ZIGP_ENSURE(c, ks.spill, (rec[0] + (nlat == 2 ? rec[1] : 0)) * spill_tiles);
-      ka.lat[0].spill = ks.spill.p;
-      if (nlat == 2) ka.lat[1].spill = ks.spill.p + rec[0] * spill_tiles;
-      ZIGP_ENSURE(c, ks.acc, (size_t)2 * nparts * nblk * 256);
-      KflAccArgs aa;
-      memset(&aa, 0, sizeof(aa));
-      aa.X = ka.X; aa.N = N; aa.ldx = ldx; aa.ntiles = ka.ntiles; aa.tps = tps; aa.nb0c = pl.nb0c; aa.nb1c = pl.nb1c;
-      for (int h = 0; h < nlat; ++h) {
-        KflAccLat& L = aa.lat[h];
-        L.spill = ka.lat[h].spill; L.gm = ka.lat[h].gm; L.gv = ka.lat[h].gv;
-        L.acc = ks.acc.p + (size_t)h * nparts * nblk * 256;
-        ka.lat[h].acc = L.acc;
-        L.nb0 = Mq[h][0] / 16; L.nb1 = Mq[h][1] / 16; L.D0 = D0; L.D1 = D1;
-        for (int d = 0; d < MAXD; ++d) { L.zc0[d] = zc[h][0][d]; L.zc1[d] = zc[h][1][d]; }
-      }
-      for (int t0 = 0; t0 < ka.ntiles; t0 += range_tiles) {
-        const int t1 = std::min(t0 + range_tiles, ka.ntiles), nt = t1 - t0;
-        const int rwaves = std::min(nt, 1024 / nlat);
-        ka.tile0 = t0; ka.tile1 = t1; ka.tpw = (nt + rwaves - 1) / rwaves;
-        const int rnw = (nt + ka.tpw - 1) / ka.tpw, rnwg = (rnw + KF_WAVES - 1) / KF_WAVES;
-        if (large_exact) hipLaunchKernelGGL((k_kfl_backward<1, 7, true, true>), dim3(rnwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
-        else hipLaunchKernelGGL((k_kfl_backward<1, 7, true, false>), dim3(rnwg, nlat), dim3(64 * KF_WAVES), lds_bwd, c->stream, ka);
-        ZIGP_HIP(c, hipGetLastError());
-        aa.tile0 = t0; aa.tile1 = t1; aa.part0 = t0 / tps;
-        hipLaunchKernelGGL(k_kfl_accum, dim3((nblk + 3) / 4, (nt + tps - 1) / tps, nlat), dim3(256), 0, c->stream, aa);
-        ZIGP_HIP(c, hipGetLastError());
-      }
-    }
-    hipLaunchKernelGGL(k_kf_reduce, dim3(nblk * 256 / 16 + 1, nlat), dim3(256), 0, c->stream, ka.lat[0].acc, ka.lat[gl_].acc, nparts,
-                       lat(0) + LAT_WORK, lat(gl_) + LAT_WORK, pl.nb0c, pl.nb1c, Mq[0][0] / 16, Mq[0][1] / 16, Mq[gl_][0] / 16, Mq[gl_][1] / 16,
-                       d_pwacc, pw_blocks, include_kl ? 1.0 : 0.0, ks.res.p + RES_PWS);
-    ZIGP_HIP(c, hipGetLastError());
-    KflFinishArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    for (int h = 0; h < nlat; ++h) {
-      KfFinishJob& jb = fa.job[h];
-      jb.M0 = hl[h].M[0]; jb.M1 = hl[h].M[1]; jb.Mq0 = Mq[h][0]; jb.Mq1 = Mq[h][1]; jb.D0 = D0; jb.D1 = D1;
-      jb.P0 = fac(h, 0) + FAC_P; jb.P1 = fac(h, 1) + FAC_P; jb.dvec0 = fac(h, 0) + FAC_DV; jb.dvec1 = fac(h, 1) + FAC_DV;
-      jb.PF0 = fac(h, 0) + FAC_PF; jb.PF1 = fac(h, 1) + FAC_PF;
-      jb.K0 = fac(h, 0); jb.K1 = fac(h, 1); jb.Z0 = ks.in.p + off_z[h][0]; jb.Z1 = ks.in.p + off_z[h][1];
-      for (int d = 0; d < MAXD; ++d) { jb.zc0[d] = zc[h][0][d]; jb.zc1[d] = zc[h][1][d]; }
-      double* L = lat(h);
-      jb.U = L + LAT_U; jb.S2 = L + LAT_S2; jb.T0 = L + LAT_T0; jb.T1 = L + LAT_T1; jb.Al = L + LAT_AL; jb.s = ks.in.p + off_s[h];
-      jb.work = L + LAT_WORK;
-      jb.krow0 = res(h) + RES_KROW0; jb.krow1 = res(h) + RES_KROW1; jb.gu = res(h) + RES_GU; jb.gs = res(h) + RES_GS;
-    }
-    fa.jitter = jitter; fa.with_kl = include_kl ? 1 : 0;
-    fa.ldw = wl.ldw; fa.wS2 = wl.S2; fa.wP0 = wl.P0; fa.wP1 = wl.P1; fa.wK0 = wl.K0; fa.wK1 = wl.K1;
-    fa.scratch_off = (int64_t)wl.total; fa.scratch_set = (int64_t)SCR_SET;
-    if (pl.large) {
-      int nbmax = 1;
-      for (int h = 0; h < nlat; ++h) nbmax = std::max(nbmax, std::max(Mq[h][0], Mq[h][1]) / 16);
-      const dim3 grid(nbmax, 2, nlat);
-      hipLaunchKernelGGL(k_kfl_finish<1>, grid, dim3(KFL_FIN_THREADS), 0, c->stream, fa);
-      hipLaunchKernelGGL(k_kfl_finish<2>, grid, dim3(KFL_FIN_THREADS), 0, c->stream, fa);
-      hipLaunchKernelGGL(k_kfl_finish<3>, grid, dim3(KFL_FIN_THREADS), 0, c->stream, fa);
-    } else {
-      KfFinishArgs fs;
-      memset(&fs, 0, sizeof(fs));
-      fs.job[0] = fa.job[0]; fs.job[1] = fa.job[1]; fs.jitter = fa.jitter; fs.with_kl = fa.with_kl;
-      hipLaunchKernelGGL(k_kf_finish, dim3(2, nlat), dim3(1024), KF_FIN_LDS, c->stream, fs);
-    }
-    ZIGP_HIP(c, hipGetLastError());
-  }
-  if (c->comm) {   // data-parallel run: the block (cleared at the start of the call) is summed over ranks where it lies
-    // a rank that does not count the KL (include_kl = 0) must not add its scalars, which the latent kernel writes regardless
-    if (!include_kl) for (int h = 0; h < nlat; ++h) ZIGP_HIP(c, hipMemsetAsync(res(h) + RES_KLV, 0, sizeof(double) * 8, c->stream));
-    ZIGP_TRY(comm_allreduce(c, ks.res.p, RES_INFO));
-  }
   double* hres = nullptr;
   ZIGP_TRY(download(c, ks.res.p, n_res, &hres));
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
-  {
-    static const char* const names[4] = {"Kronecker factor 0 of Kuu (latent f)", "Kronecker factor 1 of Kuu (latent f)",
-                                         "Kronecker factor 0 of Kuu (latent g)", "Kronecker factor 1 of Kuu (latent g)"};
-    for (int j = 0; j < 2 * nlat; ++j) ZIGP_TRY(info_result(c, reinterpret_cast<const int*>(hres + RES_INFO) + 2 * j, names[j]));
-  }
+  for (int j = 0; j < 2 * nlat; ++j) ZIGP_TRY(info_result(c, reinterpret_cast<const int*>(hres + RES_INFO) + 2 * j, fac_names[j]));
   const double* pws = hres + RES_PWS;   // var_exp, d noise, sum gv_f, sum gv_g, sum gm_f (= d / d f_mu)
   const double s_ve = pws[0], s_dn = pws[1], s_gv[2] = {pws[2], pws[3]};
   if (elbo_data) *elbo_data = s_ve;

@@ -148,7 +148,7 @@ k_kfl_backward(KfArgs a) {
   }
 }
 
-struct KflAccLat { const double* spill; const double *gm, *gv; double* acc; int nb0, nb1, D0, D1; double zc0[MAXD], zc1[MAXD]; };
+struct KflAccLat { const double* spill; const double *gm, *gv; double* acc; int nb0, nb1, D0, D1; const double *hyp0, *hyp1; };   // hyp_p: factor records of the hyperparameter block (zc)
 struct KflAccArgs { KflAccLat lat[2]; const double* X; int64_t N; int ldx, ntiles, tps, nb0c, nb1c; int tile0, tile1, part0; };   // tile range of this launch, its first part
 
 // sums over points for the larger grids: wave = one 16 x 16 output block over the tiles of one split
@@ -176,7 +176,7 @@ k_kfl_accum(KflAccArgs a) {
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (b.rb < nbr && b.cb < nbc) {
     const int D = b.kind == 4 ? L.D0 : L.D1, col0 = b.kind == 4 ? 0 : L.D0;
-    const double* zc = b.kind == 4 ? L.zc0 : L.zc1;
+    const auto zc = KF_CONST(b.kind == 4 ? L.hyp0 : L.hyp1) + KH_ZC;
     const int psi_d = (bj == 0) ? -1 : ((bj <= D) ? bj - 1 : ((bj <= 2 * D) ? bj - 1 - D : -2));   // -1: constant 1, -2: 0
     const int t0 = a.tile0 + blockIdx.y * a.tps, t1 = min(t0 + a.tps, a.tile1);
     const int oa = 16 * b.rb + 4 * ai, ob = 16 * b.cb + 4 * (bj & 3) + (bj >> 2);
@@ -437,7 +437,7 @@ k_kfl_finish(KflFinishArgs a) {
   const int M = p == 0 ? M0 : M1, Mq = p == 0 ? Mq0 : Mq1, Mo = p == 0 ? M1 : M0, D = p == 0 ? jb.D0 : jb.D1;
   const int nb = Mq / 16, nb1 = Mq1 / 16;
   const double* Z = p == 0 ? jb.Z0 : jb.Z1;
-  const double* zc = p == 0 ? jb.zc0 : jb.zc1;
+  const auto zc = KF_CONST(p == 0 ? jb.hyp0 : jb.hyp1) + KH_ZC;
   const double* P = p == 0 ? jb.P0 : jb.P1;
   const double* Kuu = p == 0 ? jb.K0 : jb.K1;
   double* work = const_cast<double*>(jb.work);

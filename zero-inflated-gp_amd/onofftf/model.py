@@ -61,6 +61,57 @@ def named_grads(g):
     return out
 
 
+# block order of zigp_kron_fit_steps' free-state vector (include/zigp.h): per latent Z0, Z1, u, s, ell0, ell1, var0, var1; then the noise
+FIT_BLOCK_NAMES = tuple('%s_%s' % (tag, nm) for tag in ('f', 'g')
+                        for nm in ('ind/z_0', 'ind/z_1', 'ind/value', 'ind/variance', 'kern/lengthscale_0', 'kern/lengthscale_1',
+                                   'kern/variance_0', 'kern/variance_1')) + ('likelihood/variance',)
+
+
+class KronDeviceFit:
+    """The Adam state of the Kronecker on/off fit in the layout of zigp_kron_fit_steps, for a ParamSet made by init_params: the flat free
+    state x and the moments m, v live here between calls (the engine updates them in place), `steps` advances them on the device and
+    writes the constrained values back into the ParamSet.  zigp.optim.AdamGroups on the same ParamSet is the host-side checker."""
+
+    def __init__(self, engine, pset, beta1=0.9, beta2=0.999, eps=1e-8):
+        from zigp.transforms import Log1pe
+        self.engine, self.pset = engine, pset
+        self.beta1, self.beta2, self.eps = beta1, beta2, eps
+        ps = [pset.params[k] for k in FIT_BLOCK_NAMES]
+        if any(q.fixed for q in ps):
+            raise ValueError('the device fit loop trains every parameter (fixed parameters: use the host loop)')
+        for q in ps:
+            if not isinstance(q.transform, Log1pe) and type(q.transform).__name__ != 'Identity':
+                raise ValueError('unsupported transform %r' % (q.transform,))
+            if isinstance(q.transform, Log1pe) and q.transform._lower != 1e-6:
+                raise ValueError('the device fit loop implements Log1pe with lower = 1e-6')
+        self.positive = [isinstance(q.transform, Log1pe) for q in ps]
+        self.lr = [float(q.learning_rate) for q in ps]
+        self.sizes = [q.value.size for q in ps]
+        self.x = np.concatenate([q.free() for q in ps])
+        self.m, self.v = np.zeros_like(self.x), np.zeros_like(self.x)
+        self.t = 0
+        v = pset.params
+        self.shape = dict(M0f=v['f_ind/z_0'].value.shape[0], M1f=v['f_ind/z_1'].value.shape[0], M0g=v['g_ind/z_0'].value.shape[0],
+                          M1g=v['g_ind/z_1'].value.shape[0], D0=v['f_ind/z_0'].value.shape[1], D1=v['f_ind/z_1'].value.shape[1])
+
+    def steps(self, row_begin, batch, jitter, scale, Xw=None, Yw=None):
+        """len(row_begin) iterations on the resident data set (engine.set_data): returns (elbo_data, kl) per step; the ParamSet holds the
+        constrained values after the last one.  If the engine raises (a Cholesky failure), x / m / v are the state before the failing step."""
+        try:
+            out = self.engine.kron_fit_steps(self.shape, self.x, self.m, self.v, self.lr, self.positive, self.t, row_begin, batch, jitter=jitter,
+                                             scale=scale, Xw=Xw, Yw=Yw, beta1=self.beta1, beta2=self.beta2, eps=self.eps)
+            self.t += len(row_begin)
+        finally:
+            self.sync_params()
+        return out
+
+    def sync_params(self):
+        o = 0
+        for k, n in zip(FIT_BLOCK_NAMES, self.sizes):
+            self.pset.params[k].set_free(self.x[o:o + n])
+            o += n
+
+
 def save_checkpoint(pset, path):
     np.savez(path, **{k.replace('/', '__'): q.value for k, q in pset.params.items()})
     return path if str(path).endswith('.npz') else str(path) + '.npz'

@@ -58,6 +58,14 @@ class zigp_kron_grads(C.Structure):
                 ('u_fm', dp), ('u_gm', dp), ('u_fs_sqrt', dp), ('u_gs_sqrt', dp), ('noise', C.c_double)]
 
 
+FIT_BLOCKS = 17   # include/zigp.h ZIGP_FIT_BLOCKS
+
+
+class zigp_kron_fit_opts(C.Structure):
+    _fields_ = [('lr', C.c_double * FIT_BLOCKS), ('positive', C.c_int32 * FIT_BLOCKS), ('reserved', C.c_int32),
+                ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double)]
+
+
 # name -> (restype, argtypes); mirrors include/zigp.h and include/zigp_diag.h exactly (tests check every declared symbol resolves)
 SIGNATURES = {
     'zigp_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
@@ -77,6 +85,8 @@ SIGNATURES = {
                                  C.c_int32, dp, dp, C.POINTER(zigp_kron_grads), dp]),
     'zigp_kron_elbo_rows': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_int32, dp, dp, C.POINTER(zigp_kron_grads), dp]),
+    'zigp_kron_fit_steps': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), C.POINTER(zigp_kron_fit_opts), dp, dp, dp, C.c_int64, C.c_int64, C.c_int32,
+                                      C.c_void_p, C.c_int64, dp, dp, C.c_double, C.c_double, C.c_int32, dp, dp]),
     'zigp_kron_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, C.c_int64, C.c_double, C.c_double, C.c_double, dp]),
     'zigp_get_chunk': (C.c_int64, [C.c_void_p, C.c_int32]),
     'zigp_set_pivot_rtol': (C.c_int, [C.c_void_p, C.c_double]),

@@ -416,6 +416,42 @@ class DenseEngine:
                 out['u_%ss_sqrt' % tag] = a['us']
         return ed.value, kl.value, out
 
+    def kron_fit_steps(self, shape, x, m, v, lr, positive, t0, row_begin, batch, jitter=1e-5, scale=1.0, Xw=None, Yw=None,
+                       beta1=0.9, beta2=0.999, eps=1e-8, include_kl=True):
+        """n = len(row_begin) Adam steps of the Kronecker on/off fit ON THE DEVICE (zigp_kron_fit_steps; the loop body of
+        scripts/onoff.py:375-381): one synchronisation for the whole call.
+        shape: dict(M0f, M1f, M0g, M1g, D0, D1); x, m, v: float64 [n_free] free state and Adam moments, UPDATED IN PLACE, in the block
+        order of include/zigp.h (per latent Z0, Z1, u, s, ell0, ell1, var0, var1; then the noise variance); lr, positive: 17 per-block
+        learning rates / Log1pe flags; t0: iterations done so far; row_begin[i] >= 0: rows of the resident data set, -(1 + k): batch k of
+        the host arrays (Xw, Yw).  Returns (elbo_data[n], kl[n]) -- the history, each at the parameters before that step's update."""
+        s = _lib.zigp_kron_params()
+        for k in ('M0f', 'M1f', 'M0g', 'M1g', 'D0', 'D1'):
+            setattr(s, k, int(shape[k]))
+        o = _lib.zigp_kron_fit_opts()
+        for b in range(_lib.FIT_BLOCKS):
+            o.lr[b] = float(lr[b]); o.positive[b] = int(bool(positive[b]))
+        o.beta1, o.beta2, o.eps = float(beta1), float(beta2), float(eps)
+        for a in (x, m, v):
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.ndim == 1 and a.size == x.size):
+                raise ValueError('x, m, v must be contiguous float64 vectors of one length')
+        rb = np.ascontiguousarray(np.asarray(row_begin, dtype=np.int64))
+        n = rb.size
+        xw = yw = None
+        if Xw is not None:
+            xw, yw = as_f64(Xw), as_f64(Yw).reshape(-1)
+            if xw.ndim != 2 or xw.shape[0] % int(batch) or yw.size != xw.shape[0]:
+                raise ValueError('Xw must hold whole batches of `batch` rows, Yw one value per row')
+            if rb.min() < -(xw.shape[0] // int(batch)):
+                raise ValueError('row_begin refers to a host batch beyond Xw')
+        elif n and rb.min() < 0:
+            raise ValueError('negative row_begin needs Xw, Yw')
+        ed, kl = np.zeros(n), np.zeros(n)
+        rc = self.lib.zigp_kron_fit_steps(self.ctx, C.byref(s), C.byref(o), ptr(x), ptr(m), ptr(v), x.size, int(t0), n, rb.ctypes.data, int(batch),
+                                          ptr(xw) if xw is not None else None, ptr(yw) if yw is not None else None, float(jitter), float(scale),
+                                          1 if include_kl else 0, ptr(ed), ptr(kl))
+        _check(self.lib, self.ctx, rc)
+        return ed, kl
+
     def kron_stepper(self, p):
         """A prepared Kronecker step for a FIXED model shape (the training loop: scripts/onoff.py:375-431 calls sess.run on one graph 50 000
         times): parameter buffers, the ctypes structs and the gradient arrays are set up once; a call copies the new parameter values in

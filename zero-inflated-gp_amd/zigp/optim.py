@@ -81,10 +81,15 @@ def lbfgsb(pset, value_and_grad, maxiter=1000, disp=False, callback=None, ftol=2
 
 
 class AdamGroups:
+    """One Adam per learning rate on the FREE state (TensorFlow's variables are the unconstrained values: scripts/onoff.py:88-123 builds
+    the positive parameters as transforms of them, and the optimisers of :325-350 update the variables).  The free vectors are kept
+    across steps (initialised from the constrained values once); every step writes the constrained values back into the ParamSet."""
+
     def __init__(self, pset, beta1=0.9, beta2=0.999, eps=1e-8):
         self.pset = pset
         self.b1, self.b2, self.eps = beta1, beta2, eps
         self.t = 0
+        self.x = {k: pset.params[k].free().copy() for k in pset.names()}
         self.m = {k: np.zeros(pset.params[k].value.size) for k in pset.names()}
         self.v = {k: np.zeros(pset.params[k].value.size) for k in pset.names()}
 
@@ -93,9 +98,10 @@ class AdamGroups:
         self.t += 1
         for k in self.pset.names():
             p = self.pset.params[k]
-            x = p.free()
+            x = self.x[k]
             g = -np.asarray(p.transform.grad_free(x, np.asarray(grads[k], dtype=np.float64).reshape(-1))).reshape(-1)
             self.m[k] = self.b1 * self.m[k] + (1 - self.b1) * g
             self.v[k] = self.b2 * self.v[k] + (1 - self.b2) * g * g
             lr_t = p.learning_rate * np.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
-            p.set_free(x - lr_t * self.m[k] / (np.sqrt(self.v[k]) + self.eps))
+            self.x[k] = x - lr_t * self.m[k] / (np.sqrt(self.v[k]) + self.eps)
+            p.set_free(self.x[k])
