@@ -71,7 +71,7 @@ def _host_steps(engine, pset, rows_seq, batch, jitter, scale, Xres, Yres, wraps=
 def test_device_fit_loop_equals_host_adam_loop(engine, grid, n_steps, tol):
     """zigp_kron_fit_steps (gradient -> Log1pe chain -> per-learning-rate Adam update, every step on the device, ONE synchronisation) against
     the same iterations stepped from the host with zigp.optim.AdamGroups (scripts/onoff.py:325-350,375-381): after n_steps every parameter
-    agrees to 1e-12 of its block's magnitude and the ELBO history to 1e-10.  Well-conditioned synthetic factors (cond ~1e2-1e4): the two
+    agrees to 1e-12 of its block's magnitude and the ELBO history to 1e-10.  Well-conditioned synthetic factors (cond ~1e2-1e3): the two
     loops feed the kernels values that differ in the last bit (numpy's vs the device's log1p / tanh), and the gradient amplifies that by
     cond(K_p); the pptr initialisation is compared (looser) in the next test.  Includes a wrap-around batch (host rows) mid-way."""
     from test_gpu_kron import make_kron_problem
@@ -82,7 +82,7 @@ def test_device_fit_loop_equals_host_adam_loop(engine, grid, n_steps, tol):
     psets = [init_params(X, grid, grid, kmeans_seed=3, rng=np.random.RandomState(9)) for _ in range(2)]
     for ps in psets:                                   # away from the reference's (ill-conditioned) lengthscale: 8 degrees on a 10-degree domain
         for tag in ('f', 'g'):
-            ps.params['%s_kern/lengthscale_0' % tag].value = np.array([2.0, 2.5])
+            ps.params['%s_kern/lengthscale_0' % tag].value = np.array([1.2, 1.5])
             ps.params['%s_kern/lengthscale_1' % tag].value = np.array([1.5 / max(grid[1] - 1, 1)])
             ps.params['%s_kern/variance_0' % tag].value = np.array([2.0])
             ps.params['%s_kern/variance_1' % tag].value = np.array([1.5])
@@ -114,7 +114,7 @@ def test_device_fit_loop_equals_host_adam_loop(engine, grid, n_steps, tol):
     moved = max(float(np.max(np.abs(psets[0].params[n].value - init_params(X, grid, grid, kmeans_seed=3, rng=np.random.RandomState(9)).params[n].value)))
                 for n in ('f_ind/value', 'g_ind/value'))
     print('grid %s: %d device steps vs host AdamGroups: worst parameter block %.2e, ELBO history %.2e (u moved by up to %.3f)' % (grid, n_steps, worst, eh, moved))
-    assert eh <= 1e-10 and moved > 1e-2
+    assert worst <= tol and eh <= 1e-10 and moved > 1e-2, (worst, eh, moved)
 
 
 def test_device_fit_loop_at_the_pptr_init_and_failure_report(engine):
