@@ -1208,75 +1208,98 @@ __device__ __forceinline__ double kfit_softplus(double x) {
 }
 __device__ __forceinline__ double kfit_value(const KfFitDesc& d, int b, double x) { return d.positive[b] ? kfit_softplus(x) : x; }
 
-// free state -> parameter image: plain blocks are copied (transformed), the hyperparameter blocks fill their records of the hyper block
-__device__ __forceinline__ void kfit_write_image(const KfFitArgs& a) {
+// block of element e of the free vector (17 blocks: a short scan; all lanes of a wave mostly agree)
+__device__ __forceinline__ int kfit_block_of(const KfFitDesc& d, int e) {
+  int b = 0;
+#pragma unroll
+  for (int k = 1; k < KFIT_BLOCKS; ++k) b += (e >= d.off[k]) ? 1 : 0;
+  return b;
+}
+
+// free state -> parameter image: plain blocks are copied (transformed), the hyperparameter blocks fill their records of the hyper block.
+// ONE flat loop over the elements: every load of the pass is in flight at once (a loop per block was a memory round trip per block --
+// 17 of them in a single workgroup, most for one or two elements).
+__device__ __forceinline__ void kfit_write_image(const KfFitArgs& a, int n_free) {
   const KfFitDesc& d = a.d;
   double* H = a.img + d.off_hyp;
-  for (int b = 0; b < KFIT_BLOCKS; ++b) {
+  for (int e = threadIdx.x; e < n_free; e += blockDim.x) {
+#pragma clang fp contract(off)
+    const int b = kfit_block_of(d, e), i = e - d.off[b];
     const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8;      // 0 Z0, 1 Z1, 2 u, 3 s, 4 ell0, 5 ell1, 6 var0, 7 var1, 8 noise
     const int h = b / 8;
-    for (int i = threadIdx.x; i < d.n[b]; i += blockDim.x) {
-#pragma clang fp contract(off)
-      const double val = kfit_value(d, b, a.x[d.off[b] + i]);
-      if (kind <= 3) a.img[d.dst[b] + i] = val;
-      else if (kind <= 5) { double* R = H + (2 * h + (kind - 4)) * KH_FAC; R[KH_ELL + i] = val; R[KH_INV + i] = 1.0 / val; }
-      else if (kind <= 7) H[(2 * h + (kind - 6)) * KH_FAC + KH_VAR] = val;
-      else H[KH_NOISE] = val;
-    }
+    const double val = kfit_value(d, b, a.x[e]);
+    if (kind <= 3) a.img[d.dst[b] + i] = val;
+    else if (kind <= 5) { double* R = H + (2 * h + (kind - 4)) * KH_FAC; R[KH_ELL + i] = val; R[KH_INV + i] = 1.0 / val; }
+    else if (kind <= 7) H[(2 * h + (kind - 6)) * KH_FAC + KH_VAR] = val;
+    else H[KH_NOISE] = val;
   }
   __syncthreads();
   // centre of the moment sums per (latent, factor, dimension): mid-range of the inducing inputs (as kronf_run computes it on the host);
-  // knn = var0 var1
-  const int t = threadIdx.x;
-  if (t < 4 * MAXD) {
-    const int h = t / (2 * MAXD), q = (t / MAXD) & 1, dd = t % MAXD, D = q == 0 ? d.D0 : d.D1;
-    if (h < d.nlat) {
-      double zc = 0.0;
-      if (dd < D) {
-        const double* Z = a.img + d.off_z[h][q];
-        double lo = Z[dd], hi = lo;
-        for (int mm = 1; mm < d.M[h][q]; ++mm) { const double z = Z[mm * D + dd]; lo = fmin(lo, z); hi = fmax(hi, z); }
-        zc = 0.5 * (lo + hi);
-      }
+  // knn = var0 var1.  A wave per (h, q, dimension): lanes take the rows, min / max by shuffles (exact, order-free).
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int job = wave; job < 4 * MAXD; job += nw) {
+    const int h = job / (2 * MAXD), q = (job / MAXD) & 1, dd = job % MAXD, D = q == 0 ? d.D0 : d.D1;
+    if (h >= d.nlat) continue;
+    double zc = 0.0;
+    if (dd < D) {
+      const double* Z = a.img + d.off_z[h][q];
+      double lo = Z[dd], hi = lo;
+      for (int mm = lane; mm < d.M[h][q]; mm += 64) { const double z = Z[mm * D + dd]; lo = fmin(lo, z); hi = fmax(hi, z); }
+#pragma unroll
+      for (int sft = 32; sft >= 1; sft >>= 1) { lo = fmin(lo, __shfl_xor(lo, sft, 64)); hi = fmax(hi, __shfl_xor(hi, sft, 64)); }
+      zc = 0.5 * (lo + hi);
+    }
+    if (lane == 0) {
       H[(2 * h + q) * KH_FAC + KH_ZC + dd] = zc;
       if (dd >= D) { H[(2 * h + q) * KH_FAC + KH_INV + dd] = 0.0; H[(2 * h + q) * KH_FAC + KH_ELL + dd] = 0.0; }
     }
   }
-  if (t < d.nlat) H[KH_KNN + t] = H[(2 * t) * KH_FAC + KH_VAR] * H[(2 * t + 1) * KH_FAC + KH_VAR];
+  if (threadIdx.x < d.nlat) {
+    const int t = threadIdx.x;
+    H[KH_KNN + t] = H[(2 * t) * KH_FAC + KH_VAR] * H[(2 * t + 1) * KH_FAC + KH_VAR];
+  }
 }
 
+constexpr int KFIT_MROWS = 16 * 7;       // most inducing rows per factor on the fused path (kf_plan)
 __global__ void __launch_bounds__(1024)
-k_fit_update(KfFitArgs a) {
+k_fit_update(KfFitArgs a, int n_free) {
   const KfFitDesc& d = a.d;
   const int t = threadIdx.x;
   __shared__ int s_fail;
+  __shared__ double s_col[2][2][MAXD + 1][KFIT_MROWS];      // the columns of krow that are summed over the inducing rows
   __shared__ double s_dl[2][2][MAXD], s_dv[2][2];
   if (a.update) {
     if (t == 0) {
       int f = a.fail[0];
       if (f == 0) {
         const int* info = reinterpret_cast<const int*>(a.res + d.res_info);
-        for (int j = 0; j < 2 * d.nlat && f == 0; ++j)
-          if (info[2 * j] != 0) { f = 1 + a.step; a.fail[0] = f; a.fail[1] = j; a.fail[2] = info[2 * j]; }
+        int bad = -1;
+        for (int j = 2 * d.nlat - 1; j >= 0; --j) bad = info[2 * j] != 0 ? j : bad;      // independent loads, first failing job wins
+        if (bad >= 0) { f = 1 + a.step; a.fail[0] = f; a.fail[1] = bad; a.fail[2] = info[2 * bad]; }
       }
       s_fail = f;
+    }
+    // stage the krow columns whose sums over the rows make d ell / d var (all loads in flight together) ...
+    for (int idx = t; idx < 4 * (MAXD + 1) * KFIT_MROWS; idx += blockDim.x) {
+      const int mm = idx % KFIT_MROWS, c = (idx / KFIT_MROWS) % (MAXD + 1), q = (idx / (KFIT_MROWS * (MAXD + 1))) & 1, h = idx / (2 * KFIT_MROWS * (MAXD + 1));
+      const int D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D;
+      if (h < d.nlat && c <= D && mm < d.M[h][q])
+        s_col[h][q][c][mm] = a.res[h * d.res_size + (q == 0 ? d.res_krow0 : d.res_krow1) + mm * W + (c == D ? 0 : 1 + D + c)];
     }
     __syncthreads();
     if (s_fail) return;             // a Cholesky failed in this or an earlier step of the call: the state stays as it was before that step
     const double* H = a.img + d.off_hyp;
     const double* pws = a.res + d.res_pws;
-    // sums over the inducing rows (host order: m = 0, 1, ...), one thread each
+    // ... and sum them in the host's order (m = 0, 1, ...), one thread each, from LDS
     if (t < 4 * (MAXD + 1)) {
-      const int h = t / (2 * (MAXD + 1)), q = (t / (MAXD + 1)) & 1, dd = t % (MAXD + 1), D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D;
+      const int h = t / (2 * (MAXD + 1)), q = (t / (MAXD + 1)) & 1, dd = t % (MAXD + 1), D = q == 0 ? d.D0 : d.D1;
       if (h < d.nlat && dd <= D) {
-        const double* krow = a.res + h * d.res_size + (q == 0 ? d.res_krow0 : d.res_krow1);
         double s = 0.0;
-        for (int mm = 0; mm < d.M[h][q]; ++mm) s += krow[mm * W + (dd == D ? 0 : 1 + D + dd)];
+        for (int mm = 0; mm < d.M[h][q]; ++mm) s += s_col[h][q][dd][mm];
         if (dd == D) s_dv[h][q] = s; else s_dl[h][q][dd] = s;
       }
     }
-    __syncthreads();
-    if (t == 0) {    // history of the step: data term, KL from its five scalars per latent (as kronf_run assembles it)
+    if (t == 64) {    // history of the step: data term, KL from its five scalars per latent (as kronf_run assembles it)
 #pragma clang fp contract(off)
       double klsum = 0.0;
       const double kl_ranks = pws[7];
@@ -1289,38 +1312,35 @@ k_fit_update(KfFitArgs a) {
       a.hist[2 * a.step] = pws[0];
       a.hist[2 * a.step + 1] = klsum;
     }
-    for (int b = 0; b < KFIT_BLOCKS; ++b) {
+    __syncthreads();
+    for (int e = t; e < n_free; e += blockDim.x) {
+#pragma clang fp contract(off)
+      const int b = kfit_block_of(d, e), i = e - d.off[b];
       const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8;
       const int h = b / 8;
-      if (h >= d.nlat && kind != 8) continue;
       const double* R = a.res + h * d.res_size;
-      for (int i = t; i < d.n[b]; i += blockDim.x) {
-#pragma clang fp contract(off)
-        double gc;      // d ELBO / d (constrained value)
-        if (kind <= 1) {
-          const int q = kind, D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D, mm = i / D, dd = i - mm * D;
-          const double ell = H[(2 * h + q) * KH_FAC + KH_ELL + dd];
-          gc = R[(q == 0 ? d.res_krow0 : d.res_krow1) + mm * W + 1 + dd] / (ell * ell);
-        } else if (kind == 2) gc = R[d.res_gu + i];
-        else if (kind == 3) gc = R[d.res_gs + i];
-        else if (kind <= 5) { const int q = kind - 4; const double ell = H[(2 * h + q) * KH_FAC + KH_ELL + i]; gc = s_dl[h][q][i] / (ell * ell * ell); }
-        else if (kind <= 7) { const int q = kind - 6; gc = s_dv[h][q] / H[(2 * h + q) * KH_FAC + KH_VAR] + pws[2 + h] * H[(2 * h + 1 - q) * KH_FAC + KH_VAR]; }
-        else gc = pws[1];
-        const int e = d.off[b] + i;
-        const double x = a.x[e];
-        // cost = -ELBO; chain through the transform: d value / d x = sigmoid(x) for Log1pe (zigp/transforms.py)
-        const double g = -(d.positive[b] ? gc * (0.5 * (1.0 + tanh(0.5 * x))) : gc);
-        const double mnew = d.beta1 * a.m[e] + (1.0 - d.beta1) * g;
-        const double vnew = d.beta2 * a.v[e] + (1.0 - d.beta2) * g * g;
-        const double lr_t = d.lr[b] * a.lr_sq / a.lr_den;
-        a.m[e] = mnew; a.v[e] = vnew;
-        a.x[e] = x - lr_t * mnew / (sqrt(vnew) + d.eps);
-      }
+      double gc;      // d ELBO / d (constrained value)
+      if (kind <= 1) {
+        const int q = kind, D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D, mm = i / D, dd = i - mm * D;
+        const double ell = H[(2 * h + q) * KH_FAC + KH_ELL + dd];
+        gc = R[(q == 0 ? d.res_krow0 : d.res_krow1) + mm * W + 1 + dd] / (ell * ell);
+      } else if (kind == 2) gc = R[d.res_gu + i];
+      else if (kind == 3) gc = R[d.res_gs + i];
+      else if (kind <= 5) { const int q = kind - 4; const double ell = H[(2 * h + q) * KH_FAC + KH_ELL + i]; gc = s_dl[h][q][i] / (ell * ell * ell); }
+      else if (kind <= 7) { const int q = kind - 6; gc = s_dv[h][q] / H[(2 * h + q) * KH_FAC + KH_VAR] + pws[2 + h] * H[(2 * h + 1 - q) * KH_FAC + KH_VAR]; }
+      else gc = pws[1];
+      const double x = a.x[e];
+      // cost = -ELBO; chain through the transform: d value / d x = sigmoid(x) for Log1pe (zigp/transforms.py)
+      const double g = -(d.positive[b] ? gc * (0.5 * (1.0 + tanh(0.5 * x))) : gc);
+      const double mnew = d.beta1 * a.m[e] + (1.0 - d.beta1) * g;
+      const double vnew = d.beta2 * a.v[e] + (1.0 - d.beta2) * g * g;
+      const double lr_t = d.lr[b] * a.lr_sq / a.lr_den;
+      a.m[e] = mnew; a.v[e] = vnew;
+      a.x[e] = x - lr_t * mnew / (sqrt(vnew) + d.eps);
     }
-    __syncthreads();
-    __threadfence_block();
+    __syncthreads();      // (block-scope visibility of a.x for the pass below)
   }
-  kfit_write_image(a);
+  kfit_write_image(a, n_free);
 }
 
 struct KfFitCall {          // host side of one zigp_kron_fit_steps call
@@ -1691,7 +1711,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     }
     ZIGP_HIP(c, hipMemsetAsync(ks.in.p + off_hyp, 0, sizeof(double) * KH_SIZE, c->stream));
     fa.update = 0; fa.step = 0;
-    hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(1024), 0, c->stream, fa);       // free state -> parameter image
+    hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(1024), 0, c->stream, fa, (int)nf);       // free state -> parameter image
     ZIGP_HIP(c, hipGetLastError());
     fa.update = 1;
     for (int i = 0; i < fit->n_steps; ++i) {
@@ -1702,7 +1722,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), t counted from 1 (zigp/optim.py AdamGroups.step): the two t-dependent factors from the host
       const double t = (double)(fit->t0 + i + 1);
       fa.step = i; fa.lr_sq = std::sqrt(1.0 - std::pow(d.beta2, t)); fa.lr_den = 1.0 - std::pow(d.beta1, t);
-      hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(1024), 0, c->stream, fa);
+      hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(1024), 0, c->stream, fa, (int)nf);
       ZIGP_HIP(c, hipGetLastError());
     }
     double* hst = nullptr;
