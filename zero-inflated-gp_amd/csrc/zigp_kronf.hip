@@ -1216,26 +1216,24 @@ __device__ __forceinline__ int kfit_block_of(const KfFitDesc& d, int e) {
   return b;
 }
 
-// free state -> parameter image: plain blocks are copied (transformed), the hyperparameter blocks fill their records of the hyper block.
-// ONE flat loop over the elements: every load of the pass is in flight at once (a loop per block was a memory round trip per block --
-// 17 of them in a single workgroup, most for one or two elements).
-__device__ __forceinline__ void kfit_write_image(const KfFitArgs& a, int n_free) {
+// value of element (block b, index i) into the parameter image: plain blocks are copied, the hyperparameter blocks fill their records
+__device__ __forceinline__ void kfit_store_value(const KfFitArgs& a, int b, int i, double val) {
+#pragma clang fp contract(off)
   const KfFitDesc& d = a.d;
   double* H = a.img + d.off_hyp;
-  for (int e = threadIdx.x; e < n_free; e += blockDim.x) {
-#pragma clang fp contract(off)
-    const int b = kfit_block_of(d, e), i = e - d.off[b];
-    const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8;      // 0 Z0, 1 Z1, 2 u, 3 s, 4 ell0, 5 ell1, 6 var0, 7 var1, 8 noise
-    const int h = b / 8;
-    const double val = kfit_value(d, b, a.x[e]);
-    if (kind <= 3) a.img[d.dst[b] + i] = val;
-    else if (kind <= 5) { double* R = H + (2 * h + (kind - 4)) * KH_FAC; R[KH_ELL + i] = val; R[KH_INV + i] = 1.0 / val; }
-    else if (kind <= 7) H[(2 * h + (kind - 6)) * KH_FAC + KH_VAR] = val;
-    else H[KH_NOISE] = val;
-  }
-  __syncthreads();
-  // centre of the moment sums per (latent, factor, dimension): mid-range of the inducing inputs (as kronf_run computes it on the host);
-  // knn = var0 var1.  A wave per (h, q, dimension): lanes take the rows, min / max by shuffles (exact, order-free).
+  const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8;      // 0 Z0, 1 Z1, 2 u, 3 s, 4 ell0, 5 ell1, 6 var0, 7 var1, 8 noise
+  const int h = b / 8;
+  if (kind <= 3) a.img[d.dst[b] + i] = val;
+  else if (kind <= 5) { double* R = H + (2 * h + (kind - 4)) * KH_FAC; R[KH_ELL + i] = val; R[KH_INV + i] = 1.0 / val; }
+  else if (kind <= 7) H[(2 * h + (kind - 6)) * KH_FAC + KH_VAR] = val;
+  else H[KH_NOISE] = val;
+}
+// what the image holds besides the parameter values: the centre of the moment sums per (latent, factor, dimension) = mid-range of the
+// inducing inputs (as kronf_run computes it on the host), and knn = var0 var1.  Call after a __syncthreads() behind the value stores.
+// A wave per (h, q, dimension): lanes take the rows, min / max by shuffles (exact, order-free).
+__device__ __forceinline__ void kfit_finish_image(const KfFitArgs& a) {
+  const KfFitDesc& d = a.d;
+  double* H = a.img + d.off_hyp;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   for (int job = wave; job < 4 * MAXD; job += nw) {
     const int h = job / (2 * MAXD), q = (job / MAXD) & 1, dd = job % MAXD, D = q == 0 ? d.D0 : d.D1;
@@ -1261,6 +1259,7 @@ __device__ __forceinline__ void kfit_write_image(const KfFitArgs& a, int n_free)
 }
 
 constexpr int KFIT_MROWS = 16 * 7;       // most inducing rows per factor on the fused path (kf_plan)
+constexpr int KFIT_EPT = 6;              // elements per thread and pass of the update (6144 per pass: the 32 x 32 model has 4237, the 10 x 100 one 4469)
 __global__ void __launch_bounds__(1024)
 k_fit_update(KfFitArgs a, int n_free) {
   const KfFitDesc& d = a.d;
@@ -1268,6 +1267,7 @@ k_fit_update(KfFitArgs a, int n_free) {
   __shared__ int s_fail;
   __shared__ double s_col[2][2][MAXD + 1][KFIT_MROWS];      // the columns of krow that are summed over the inducing rows
   __shared__ double s_dl[2][2][MAXD], s_dv[2][2];
+  __shared__ double s_ell[2][2][MAXD], s_var[2][2];         // the hyperparameters the step was evaluated at (the pass below overwrites the image)
   if (a.update) {
     if (t == 0) {
       int f = a.fail[0];
@@ -1286,9 +1286,14 @@ k_fit_update(KfFitArgs a, int n_free) {
       if (h < d.nlat && c <= D && mm < d.M[h][q])
         s_col[h][q][c][mm] = a.res[h * d.res_size + (q == 0 ? d.res_krow0 : d.res_krow1) + mm * W + (c == D ? 0 : 1 + D + c)];
     }
+    if (t < 4 * MAXD) {
+      const int h = t / (2 * MAXD), q = (t / MAXD) & 1, dd = t % MAXD;
+      const double* Hq = a.img + d.off_hyp + (2 * h + q) * KH_FAC;
+      s_ell[h][q][dd] = Hq[KH_ELL + dd];
+      if (dd == 0) s_var[h][q] = Hq[KH_VAR];
+    }
     __syncthreads();
     if (s_fail) return;             // a Cholesky failed in this or an earlier step of the call: the state stays as it was before that step
-    const double* H = a.img + d.off_hyp;
     const double* pws = a.res + d.res_pws;
     // ... and sum them in the host's order (m = 0, 1, ...), one thread each, from LDS
     if (t < 4 * (MAXD + 1)) {
@@ -1313,34 +1318,65 @@ k_fit_update(KfFitArgs a, int n_free) {
       a.hist[2 * a.step + 1] = klsum;
     }
     __syncthreads();
-    for (int e = t; e < n_free; e += blockDim.x) {
+    // KFIT_EPT elements per thread and pass: ALL loads of the pass first (one memory round trip for the workgroup -- with a load, compute,
+    // store body per element the single workgroup paid a round trip per 1024 elements, 5 in a row at 32 x 32), then arithmetic and stores;
+    // the parameter image gets the transformed NEW value directly (no second pass over x)
+    for (int base = 0; base < n_free; base += KFIT_EPT * 1024) {
+      double xv[KFIT_EPT], mv[KFIT_EPT], vv[KFIT_EPT], gcv[KFIT_EPT], aux[KFIT_EPT];
+      int bb[KFIT_EPT];
+#pragma unroll
+      for (int k = 0; k < KFIT_EPT; ++k) {
+        const int e = base + k * 1024 + t;
+        bb[k] = -1; xv[k] = 0.0; mv[k] = 0.0; vv[k] = 0.0; gcv[k] = 0.0; aux[k] = 1.0;
+        if (e < n_free) {
+          const int b = kfit_block_of(d, e), i = e - d.off[b];
+          const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8;
+          const int h = b / 8;
+          const double* R = a.res + h * d.res_size;
+          bb[k] = b; xv[k] = a.x[e]; mv[k] = a.m[e]; vv[k] = a.v[e];
+          // gcv: the numerator, aux: what it is divided by (Z, ell) -- or, for the variances, gcv = dv, aux = var (the second term below)
+          if (kind <= 1) {
+            const int q = kind, D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D, mm = i / D, dd = i - mm * D;
+            aux[k] = s_ell[h][q][dd];
+            gcv[k] = R[(q == 0 ? d.res_krow0 : d.res_krow1) + mm * W + 1 + dd];
+          } else if (kind == 2) gcv[k] = R[d.res_gu + i];
+          else if (kind == 3) gcv[k] = R[d.res_gs + i];
+          else if (kind <= 5) { const int q = kind - 4; aux[k] = s_ell[h][q][i]; gcv[k] = s_dl[h][q][i]; }
+          else if (kind <= 7) { const int q = kind - 6; aux[k] = s_var[h][q]; gcv[k] = s_dv[h][q]; }
+          else gcv[k] = pws[1];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KFIT_EPT; ++k) {
 #pragma clang fp contract(off)
-      const int b = kfit_block_of(d, e), i = e - d.off[b];
-      const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8;
-      const int h = b / 8;
-      const double* R = a.res + h * d.res_size;
-      double gc;      // d ELBO / d (constrained value)
-      if (kind <= 1) {
-        const int q = kind, D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D, mm = i / D, dd = i - mm * D;
-        const double ell = H[(2 * h + q) * KH_FAC + KH_ELL + dd];
-        gc = R[(q == 0 ? d.res_krow0 : d.res_krow1) + mm * W + 1 + dd] / (ell * ell);
-      } else if (kind == 2) gc = R[d.res_gu + i];
-      else if (kind == 3) gc = R[d.res_gs + i];
-      else if (kind <= 5) { const int q = kind - 4; const double ell = H[(2 * h + q) * KH_FAC + KH_ELL + i]; gc = s_dl[h][q][i] / (ell * ell * ell); }
-      else if (kind <= 7) { const int q = kind - 6; gc = s_dv[h][q] / H[(2 * h + q) * KH_FAC + KH_VAR] + pws[2 + h] * H[(2 * h + 1 - q) * KH_FAC + KH_VAR]; }
-      else gc = pws[1];
-      const double x = a.x[e];
-      // cost = -ELBO; chain through the transform: d value / d x = sigmoid(x) for Log1pe (zigp/transforms.py)
-      const double g = -(d.positive[b] ? gc * (0.5 * (1.0 + tanh(0.5 * x))) : gc);
-      const double mnew = d.beta1 * a.m[e] + (1.0 - d.beta1) * g;
-      const double vnew = d.beta2 * a.v[e] + (1.0 - d.beta2) * g * g;
-      const double lr_t = d.lr[b] * a.lr_sq / a.lr_den;
-      a.m[e] = mnew; a.v[e] = vnew;
-      a.x[e] = x - lr_t * mnew / (sqrt(vnew) + d.eps);
+        const int e = base + k * 1024 + t, b = bb[k];
+        if (b >= 0) {
+          const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8, h = b / 8;
+          double gc;      // d ELBO / d (constrained value)
+          if (kind <= 1) gc = gcv[k] / (aux[k] * aux[k]);
+          else if (kind <= 3 || kind == 8) gc = gcv[k];
+          else if (kind <= 5) gc = gcv[k] / (aux[k] * aux[k] * aux[k]);
+          else gc = gcv[k] / aux[k] + pws[2 + h] * s_var[h][1 - (kind - 6)];
+          const double x = xv[k];
+          // cost = -ELBO; chain through the transform: d value / d x = sigmoid(x) for Log1pe (zigp/transforms.py)
+          const double g = -(d.positive[b] ? gc * (0.5 * (1.0 + tanh(0.5 * x))) : gc);
+          const double mnew = d.beta1 * mv[k] + (1.0 - d.beta1) * g;
+          const double vnew = d.beta2 * vv[k] + (1.0 - d.beta2) * g * g;
+          const double lr_t = d.lr[b] * a.lr_sq / a.lr_den;
+          const double xnew = x - lr_t * mnew / (sqrt(vnew) + d.eps);
+          a.m[e] = mnew; a.v[e] = vnew; a.x[e] = xnew;
+          kfit_store_value(a, b, e - d.off[b], kfit_value(d, b, xnew));
+        }
+      }
     }
-    __syncthreads();      // (block-scope visibility of a.x for the pass below)
+  } else {
+    for (int e = t; e < n_free; e += blockDim.x) {      // first launch of a call: free state -> parameter image
+      const int b = kfit_block_of(d, e);
+      kfit_store_value(a, b, e - d.off[b], kfit_value(d, b, a.x[e]));
+    }
   }
-  kfit_write_image(a, n_free);
+  __syncthreads();
+  kfit_finish_image(a);
 }
 
 struct KfFitCall {          // host side of one zigp_kron_fit_steps call
