@@ -14,11 +14,11 @@ constexpr int MAXD = 8;       // max input dimension handled by the fused kernel
 // on the device and enqueue the next step without a round trip (zigp_kron_fit_steps).  Layout in doubles: a record of KH_FAC per
 // (latent h, factor q) at (2 h + q) KH_FAC --
 //   [KH_INV, +MAXD) 1 / ell_d    [KH_ZC, +MAXD) centre of the moment sums (mid-range of Z_p)    [KH_ELL, +MAXD) ell_d    KH_VAR: var_p
-// -- then KH_NOISE: likelihood variance, KH_KNN + h: var_0 var_1 of latent h.
+// (KH_ZC is written by k_kf_factor, the first kernel of a step) -- then KH_NOISE: the likelihood variance.
 // Read through the CONSTANT address space (scalar loads, exactly as kernel arguments are fetched): the block is written by an earlier
 // launch or copy, never by a kernel that reads it.
 constexpr int KH_INV = 0, KH_ZC = MAXD, KH_ELL = 2 * MAXD, KH_VAR = 3 * MAXD, KH_FAC = 3 * MAXD + 2;
-constexpr int KH_NOISE = 4 * KH_FAC, KH_KNN = KH_NOISE + 1, KH_SIZE = KH_NOISE + 4;
+constexpr int KH_NOISE = 4 * KH_FAC, KH_SIZE = KH_NOISE + 4;
 #define KF_CONST(p) ((const __attribute__((address_space(4))) double*)(p))
 constexpr int PW_THREADS = 256;
 

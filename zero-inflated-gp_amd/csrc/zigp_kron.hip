@@ -124,7 +124,9 @@ __global__ void __launch_bounds__(PW_THREADS)
 k_kron_pointwise(KronPwArgs p) {
   __shared__ double sh[4];
   const int64_t n = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
-  const double knn_f = p.hyp ? KF_CONST(p.hyp)[KH_KNN] : p.knn_f, knn_g = p.hyp ? KF_CONST(p.hyp)[KH_KNN + 1] : p.knn_g;
+  // Knn = var_0 var_1 (scripts/onoff.py:196-200): the product of the two factor variances of the latent's records
+  const double knn_f = p.hyp ? KF_CONST(p.hyp)[KH_VAR] * KF_CONST(p.hyp)[KH_FAC + KH_VAR] : p.knn_f;
+  const double knn_g = p.hyp ? KF_CONST(p.hyp)[2 * KH_FAC + KH_VAR] * KF_CONST(p.hyp)[3 * KH_FAC + KH_VAR] : p.knn_g;
   const double noise = p.hyp ? KF_CONST(p.hyp)[KH_NOISE] : p.noise;
   const double q0f = p.part_f[n], q1f = p.part_f[p.Nc + n], q0g = p.part_g[n], q1g = p.part_g[p.Nc + n];
   const double fm = p.part_f[2 * p.Nc + n] + p.f_offset, fv = knn_f - q0f * q1f + p.part_f[3 * p.Nc + n];

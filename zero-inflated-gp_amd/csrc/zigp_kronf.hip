@@ -646,6 +646,7 @@ k_kf_reduce(const double* __restrict__ acc0, const double* __restrict__ acc1, in
 // =============================================================================================================================
 struct KfFactorJob {
   const double* Z; int M, D, Mq; const double* hyp;   // Mq = 16 nb; hyp: the factor's record of the device hyperparameter block
+  double* zc_out;   // = hyp + KH_ZC, written here: centre of the moment sums (mid-range of Z_p), read by the kernels BEHIND this one
   double* K;        // [128][128] identity padded Kuu factor + jitter (kept for the Kuu-gradient reductions)
   double* P;        // [Mq][Mq] row-major K^-1 (zero padded)
   double* PF;       // fragment order
@@ -693,6 +694,15 @@ k_kf_factor(KfFactorArgs a) {
     jb.Zs[idx] = z * inv_ell[d];
   }
   __syncthreads();
+  if (t < MAXD) {      // zc_d = mid-range of the inducing inputs (min / max are exact: any order gives the same bits)
+    double zc = 0.0;
+    if (t < D) {
+      double lo = zl[t], hi = lo;
+      for (int m = 1; m < M; ++m) { const double z = zl[m * D + t]; lo = fmin(lo, z); hi = fmax(hi, z); }
+      zc = 0.5 * (lo + hi);
+    }
+    jb.zc_out[t] = zc;
+  }
   const int nreal = ((M + PNB - 1) / PNB) * PNB;   // the factorisation touches the 32-column panels that hold real rows only
   for (int idx = t; idx < (nreal / 2) * (nreal + 1); idx += 1024) {
     int i = idx / (nreal + 1), j = idx - i * (nreal + 1);
@@ -1184,7 +1194,8 @@ struct KfFitDesc {
   int off[KFIT_BLOCKS], n[KFIT_BLOCKS], dst[KFIT_BLOCKS], positive[KFIT_BLOCKS];   // offset in the free vector, size, offset in the parameter image
   double lr[KFIT_BLOCKS];
   int nlat, D0, D1, M[2][2], Mq[2][2];
-  int off_z[2][2], off_hyp;                    // parameter image
+  int off_z[2][2], off_hyp, off_hyp2;          // parameter image; the two hyperparameter blocks (step i reads block i % 2, its update writes the other)
+  int big_blk[8], big_off[9], hyp_blk[9], hyp_off[10];   // thread -> element map of k_fit_update: the big blocks (Z, u, s) in order, then the hyperparameter blocks in a workgroup of their own
   int res_size, res_krow0, res_krow1, res_gu, res_gs, res_pws, res_info;   // result block (doubles)
   double beta1, beta2, eps;
 };
@@ -1208,100 +1219,104 @@ __device__ __forceinline__ double kfit_softplus(double x) {
 }
 __device__ __forceinline__ double kfit_value(const KfFitDesc& d, int b, double x) { return d.positive[b] ? kfit_softplus(x) : x; }
 
-// block of element e of the free vector (17 blocks: a short scan; all lanes of a wave mostly agree)
-__device__ __forceinline__ int kfit_block_of(const KfFitDesc& d, int e) {
-  int b = 0;
-#pragma unroll
-  for (int k = 1; k < KFIT_BLOCKS; ++k) b += (e >= d.off[k]) ? 1 : 0;
-  return b;
+// Thread -> element of the free vector.  Workgroups 0 .. G - 2 walk the big blocks (Z0, Z1, u, s of f, then of g) one element per thread;
+// the LAST workgroup owns every hyperparameter element (ell, var of both latents, the noise: <= 33), which need the sums over the
+// inducing rows.  Returns the block (or -1) and the index inside it.
+__device__ __forceinline__ int kfit_element(const KfFitDesc& d, int& i) {
+  const bool hyper_wg = blockIdx.x == gridDim.x - 1;
+  const int j = hyper_wg ? (int)threadIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int nb = hyper_wg ? 9 : 8;
+  const int* off = hyper_wg ? d.hyp_off : d.big_off;
+  const int* blk = hyper_wg ? d.hyp_blk : d.big_blk;
+  if (j >= off[nb]) { i = 0; return -1; }
+  int k = 0;
+  for (int q = 1; q < nb; ++q) k += (j >= off[q]) ? 1 : 0;
+  i = j - off[k];
+  return blk[k];
 }
 
-// value of element (block b, index i) into the parameter image: plain blocks are copied, the hyperparameter blocks fill their records
-__device__ __forceinline__ void kfit_store_value(const KfFitArgs& a, int b, int i, double val) {
+// value of element (block b, index i) into the parameter image: plain blocks are copied, the hyperparameter blocks fill their records of
+// the hyper block Hn the NEXT step reads (the block the current step was evaluated at stays intact: two blocks, used in turn)
+__device__ __forceinline__ void kfit_store_value(const KfFitArgs& a, double* Hn, int b, int i, double val) {
 #pragma clang fp contract(off)
   const KfFitDesc& d = a.d;
-  double* H = a.img + d.off_hyp;
   const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8;      // 0 Z0, 1 Z1, 2 u, 3 s, 4 ell0, 5 ell1, 6 var0, 7 var1, 8 noise
   const int h = b / 8;
   if (kind <= 3) a.img[d.dst[b] + i] = val;
-  else if (kind <= 5) { double* R = H + (2 * h + (kind - 4)) * KH_FAC; R[KH_ELL + i] = val; R[KH_INV + i] = 1.0 / val; }
-  else if (kind <= 7) H[(2 * h + (kind - 6)) * KH_FAC + KH_VAR] = val;
-  else H[KH_NOISE] = val;
-}
-// what the image holds besides the parameter values: the centre of the moment sums per (latent, factor, dimension) = mid-range of the
-// inducing inputs (as kronf_run computes it on the host), and knn = var0 var1.  Call after a __syncthreads() behind the value stores.
-// A wave per (h, q, dimension): lanes take the rows, min / max by shuffles (exact, order-free).
-__device__ __forceinline__ void kfit_finish_image(const KfFitArgs& a) {
-  const KfFitDesc& d = a.d;
-  double* H = a.img + d.off_hyp;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  for (int job = wave; job < 4 * MAXD; job += nw) {
-    const int h = job / (2 * MAXD), q = (job / MAXD) & 1, dd = job % MAXD, D = q == 0 ? d.D0 : d.D1;
-    if (h >= d.nlat) continue;
-    double zc = 0.0;
-    if (dd < D) {
-      const double* Z = a.img + d.off_z[h][q];
-      double lo = Z[dd], hi = lo;
-      for (int mm = lane; mm < d.M[h][q]; mm += 64) { const double z = Z[mm * D + dd]; lo = fmin(lo, z); hi = fmax(hi, z); }
-#pragma unroll
-      for (int sft = 32; sft >= 1; sft >>= 1) { lo = fmin(lo, __shfl_xor(lo, sft, 64)); hi = fmax(hi, __shfl_xor(hi, sft, 64)); }
-      zc = 0.5 * (lo + hi);
-    }
-    if (lane == 0) {
-      H[(2 * h + q) * KH_FAC + KH_ZC + dd] = zc;
-      if (dd >= D) { H[(2 * h + q) * KH_FAC + KH_INV + dd] = 0.0; H[(2 * h + q) * KH_FAC + KH_ELL + dd] = 0.0; }
-    }
-  }
-  if (threadIdx.x < d.nlat) {
-    const int t = threadIdx.x;
-    H[KH_KNN + t] = H[(2 * t) * KH_FAC + KH_VAR] * H[(2 * t + 1) * KH_FAC + KH_VAR];
-  }
+  else if (kind <= 5) { double* R = Hn + (2 * h + (kind - 4)) * KH_FAC; R[KH_ELL + i] = val; R[KH_INV + i] = 1.0 / val; }
+  else if (kind <= 7) Hn[(2 * h + (kind - 6)) * KH_FAC + KH_VAR] = val;
+  else Hn[KH_NOISE] = val;
 }
 
+// Grid: KFIT_THREADS-wide workgroups, one element of the free vector per thread (the update is ~300 fp64 instructions per element --
+// tanh, log1p, exp, sqrt, divisions: in ONE workgroup it took 20 us of a 105 us step, VALU-bound on a single compute unit).  The blocks
+// are laid out so that the few hyperparameter elements (ell, var, noise: those that need the sums over the inducing rows) come LAST
+// in the element order handled by the last workgroup, which also writes the history entry and the failure record.
 constexpr int KFIT_MROWS = 16 * 7;       // most inducing rows per factor on the fused path (kf_plan)
-constexpr int KFIT_EPT = 6;              // elements per thread and pass of the update (6144 per pass: the 32 x 32 model has 4237, the 10 x 100 one 4469)
-__global__ void __launch_bounds__(1024)
-k_fit_update(KfFitArgs a, int n_free) {
+constexpr int KFIT_THREADS = 256;
+__global__ void __launch_bounds__(KFIT_THREADS)
+k_fit_update(KfFitArgs a) {
   const KfFitDesc& d = a.d;
   const int t = threadIdx.x;
+  const double* Ho = a.img + (a.step & 1 ? d.off_hyp2 : d.off_hyp);      // the block this step's kernels read
+  double* Hn = a.img + (a.update ? (a.step & 1 ? d.off_hyp : d.off_hyp2) : d.off_hyp);      // the block the next step will read
+  int i = 0;
+  const int b = kfit_element(d, i);
+  const int e = b >= 0 ? d.off[b] + i : 0;
+  if (!a.update) {                       // first launch of a call: free state -> parameter image
+    if (b >= 0) kfit_store_value(a, Hn, b, i, kfit_value(d, b, a.x[e]));
+    return;
+  }
   __shared__ int s_fail;
   __shared__ double s_col[2][2][MAXD + 1][KFIT_MROWS];      // the columns of krow that are summed over the inducing rows
   __shared__ double s_dl[2][2][MAXD], s_dv[2][2];
-  __shared__ double s_ell[2][2][MAXD], s_var[2][2];         // the hyperparameters the step was evaluated at (the pass below overwrites the image)
-  if (a.update) {
-    if (t == 0) {
-      int f = a.fail[0];
-      if (f == 0) {
-        const int* info = reinterpret_cast<const int*>(a.res + d.res_info);
-        int bad = -1;
-        for (int j = 2 * d.nlat - 1; j >= 0; --j) bad = info[2 * j] != 0 ? j : bad;      // independent loads, first failing job wins
-        if (bad >= 0) { f = 1 + a.step; a.fail[0] = f; a.fail[1] = bad; a.fail[2] = info[2 * bad]; }
-      }
-      s_fail = f;
+  const bool hyper_wg = blockIdx.x == gridDim.x - 1;         // owns every ell / var / noise element (see the host side: those blocks are its last elements)
+  if (t == 0) {
+    int f = a.fail[0];
+    if (f == 0) {
+      const int* info = reinterpret_cast<const int*>(a.res + d.res_info);
+      int bad = -1;
+      for (int j = 2 * d.nlat - 1; j >= 0; --j) bad = info[2 * j] != 0 ? j : bad;      // independent loads, first failing job wins
+      if (bad >= 0) { f = 1 + a.step; if (hyper_wg) { a.fail[1] = bad; a.fail[2] = info[2 * bad]; a.fail[0] = f; } }
     }
-    // stage the krow columns whose sums over the rows make d ell / d var (all loads in flight together) ...
-    for (int idx = t; idx < 4 * (MAXD + 1) * KFIT_MROWS; idx += blockDim.x) {
+    s_fail = f;
+  }
+  if (hyper_wg) {   // stage the krow columns whose sums over the rows make d ell / d var (all loads in flight together) ...
+    for (int idx = t; idx < 4 * (MAXD + 1) * KFIT_MROWS; idx += KFIT_THREADS) {
       const int mm = idx % KFIT_MROWS, c = (idx / KFIT_MROWS) % (MAXD + 1), q = (idx / (KFIT_MROWS * (MAXD + 1))) & 1, h = idx / (2 * KFIT_MROWS * (MAXD + 1));
       const int D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D;
       if (h < d.nlat && c <= D && mm < d.M[h][q])
         s_col[h][q][c][mm] = a.res[h * d.res_size + (q == 0 ? d.res_krow0 : d.res_krow1) + mm * W + (c == D ? 0 : 1 + D + c)];
     }
-    if (t < 4 * MAXD) {
-      const int h = t / (2 * MAXD), q = (t / MAXD) & 1, dd = t % MAXD;
-      const double* Hq = a.img + d.off_hyp + (2 * h + q) * KH_FAC;
-      s_ell[h][q][dd] = Hq[KH_ELL + dd];
-      if (dd == 0) s_var[h][q] = Hq[KH_VAR];
-    }
-    __syncthreads();
-    if (s_fail) return;             // a Cholesky failed in this or an earlier step of the call: the state stays as it was before that step
-    const double* pws = a.res + d.res_pws;
+  }
+  // this thread's element: every load up front
+  int kind = 0, h = 0;
+  double x = 0.0, mv = 0.0, vv = 0.0, gnum = 0.0, aux = 1.0;
+  const double* pws = a.res + d.res_pws;
+  if (b >= 0) {
+    kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8; h = b / 8;
+    const double* R = a.res + h * d.res_size;
+    x = a.x[e]; mv = a.m[e]; vv = a.v[e];
+    if (kind <= 1) {
+      const int q = kind, D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D, mm = i / D, dd = i - mm * D;
+      aux = Ho[(2 * h + q) * KH_FAC + KH_ELL + dd];
+      gnum = R[(q == 0 ? d.res_krow0 : d.res_krow1) + mm * W + 1 + dd];
+    } else if (kind == 2) gnum = R[d.res_gu + i];
+    else if (kind == 3) gnum = R[d.res_gs + i];
+    else if (kind <= 5) aux = Ho[(2 * h + (kind - 4)) * KH_FAC + KH_ELL + i];
+    else if (kind <= 7) aux = Ho[(2 * h + (kind - 6)) * KH_FAC + KH_VAR];
+    else gnum = pws[1];
+  }
+  __syncthreads();
+  if (s_fail) return;             // a Cholesky failed in this or an earlier step of the call: the state stays as it was before that step
+  if (hyper_wg) {
     // ... and sum them in the host's order (m = 0, 1, ...), one thread each, from LDS
     if (t < 4 * (MAXD + 1)) {
-      const int h = t / (2 * (MAXD + 1)), q = (t / (MAXD + 1)) & 1, dd = t % (MAXD + 1), D = q == 0 ? d.D0 : d.D1;
-      if (h < d.nlat && dd <= D) {
-        double s = 0.0;
-        for (int mm = 0; mm < d.M[h][q]; ++mm) s += s_col[h][q][dd][mm];
-        if (dd == D) s_dv[h][q] = s; else s_dl[h][q][dd] = s;
+      const int hh = t / (2 * (MAXD + 1)), q = (t / (MAXD + 1)) & 1, dd = t % (MAXD + 1), D = q == 0 ? d.D0 : d.D1;
+      if (hh < d.nlat && dd <= D) {
+        double sm = 0.0;
+        for (int mm = 0; mm < d.M[hh][q]; ++mm) sm += s_col[hh][q][dd][mm];
+        if (dd == D) s_dv[hh][q] = sm; else s_dl[hh][q][dd] = sm;
       }
     }
     if (t == 64) {    // history of the step: data term, KL from its five scalars per latent (as kronf_run assembles it)
@@ -1309,74 +1324,33 @@ k_fit_update(KfFitArgs a, int n_free) {
       double klsum = 0.0;
       const double kl_ranks = pws[7];
       if (kl_ranks > 0.0)
-        for (int h = 0; h < d.nlat; ++h) {
-          const double* vv = a.res + h * d.res_size;
-          const int M0 = d.M[h][0], M1 = d.M[h][1];
-          klsum += 0.5 * (vv[0] - kl_ranks * (double)M0 * M1 - vv[1] + vv[2] + (double)M1 * vv[3] + (double)M0 * vv[4]);
+        for (int hh = 0; hh < d.nlat; ++hh) {
+          const double* vk = a.res + hh * d.res_size;
+          const int M0 = d.M[hh][0], M1 = d.M[hh][1];
+          klsum += 0.5 * (vk[0] - kl_ranks * (double)M0 * M1 - vk[1] + vk[2] + (double)M1 * vk[3] + (double)M0 * vk[4]);
         }
       a.hist[2 * a.step] = pws[0];
       a.hist[2 * a.step + 1] = klsum;
     }
     __syncthreads();
-    // KFIT_EPT elements per thread and pass: ALL loads of the pass first (one memory round trip for the workgroup -- with a load, compute,
-    // store body per element the single workgroup paid a round trip per 1024 elements, 5 in a row at 32 x 32), then arithmetic and stores;
-    // the parameter image gets the transformed NEW value directly (no second pass over x)
-    for (int base = 0; base < n_free; base += KFIT_EPT * 1024) {
-      double xv[KFIT_EPT], mv[KFIT_EPT], vv[KFIT_EPT], gcv[KFIT_EPT], aux[KFIT_EPT];
-      int bb[KFIT_EPT];
-#pragma unroll
-      for (int k = 0; k < KFIT_EPT; ++k) {
-        const int e = base + k * 1024 + t;
-        bb[k] = -1; xv[k] = 0.0; mv[k] = 0.0; vv[k] = 0.0; gcv[k] = 0.0; aux[k] = 1.0;
-        if (e < n_free) {
-          const int b = kfit_block_of(d, e), i = e - d.off[b];
-          const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8;
-          const int h = b / 8;
-          const double* R = a.res + h * d.res_size;
-          bb[k] = b; xv[k] = a.x[e]; mv[k] = a.m[e]; vv[k] = a.v[e];
-          // gcv: the numerator, aux: what it is divided by (Z, ell) -- or, for the variances, gcv = dv, aux = var (the second term below)
-          if (kind <= 1) {
-            const int q = kind, D = q == 0 ? d.D0 : d.D1, W = 2 + 2 * D, mm = i / D, dd = i - mm * D;
-            aux[k] = s_ell[h][q][dd];
-            gcv[k] = R[(q == 0 ? d.res_krow0 : d.res_krow1) + mm * W + 1 + dd];
-          } else if (kind == 2) gcv[k] = R[d.res_gu + i];
-          else if (kind == 3) gcv[k] = R[d.res_gs + i];
-          else if (kind <= 5) { const int q = kind - 4; aux[k] = s_ell[h][q][i]; gcv[k] = s_dl[h][q][i]; }
-          else if (kind <= 7) { const int q = kind - 6; aux[k] = s_var[h][q]; gcv[k] = s_dv[h][q]; }
-          else gcv[k] = pws[1];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < KFIT_EPT; ++k) {
-#pragma clang fp contract(off)
-        const int e = base + k * 1024 + t, b = bb[k];
-        if (b >= 0) {
-          const int kind = b == KFIT_BLOCKS - 1 ? 8 : b % 8, h = b / 8;
-          double gc;      // d ELBO / d (constrained value)
-          if (kind <= 1) gc = gcv[k] / (aux[k] * aux[k]);
-          else if (kind <= 3 || kind == 8) gc = gcv[k];
-          else if (kind <= 5) gc = gcv[k] / (aux[k] * aux[k] * aux[k]);
-          else gc = gcv[k] / aux[k] + pws[2 + h] * s_var[h][1 - (kind - 6)];
-          const double x = xv[k];
-          // cost = -ELBO; chain through the transform: d value / d x = sigmoid(x) for Log1pe (zigp/transforms.py)
-          const double g = -(d.positive[b] ? gc * (0.5 * (1.0 + tanh(0.5 * x))) : gc);
-          const double mnew = d.beta1 * mv[k] + (1.0 - d.beta1) * g;
-          const double vnew = d.beta2 * vv[k] + (1.0 - d.beta2) * g * g;
-          const double lr_t = d.lr[b] * a.lr_sq / a.lr_den;
-          const double xnew = x - lr_t * mnew / (sqrt(vnew) + d.eps);
-          a.m[e] = mnew; a.v[e] = vnew; a.x[e] = xnew;
-          kfit_store_value(a, b, e - d.off[b], kfit_value(d, b, xnew));
-        }
-      }
-    }
-  } else {
-    for (int e = t; e < n_free; e += blockDim.x) {      // first launch of a call: free state -> parameter image
-      const int b = kfit_block_of(d, e);
-      kfit_store_value(a, b, e - d.off[b], kfit_value(d, b, a.x[e]));
-    }
   }
-  __syncthreads();
-  kfit_finish_image(a);
+  if (b < 0) return;
+  {
+#pragma clang fp contract(off)
+    double gc;      // d ELBO / d (constrained value)
+    if (kind <= 1) gc = gnum / (aux * aux);
+    else if (kind <= 3 || kind == 8) gc = gnum;
+    else if (kind <= 5) gc = s_dl[h][kind - 4][i] / (aux * aux * aux);
+    else gc = s_dv[h][kind - 6] / aux + pws[2 + h] * Ho[(2 * h + 1 - (kind - 6)) * KH_FAC + KH_VAR];   // Knn = var0 var1 enters var_n directly (scripts/onoff.py:196-200)
+    // cost = -ELBO; chain through the transform: d value / d x = sigmoid(x) for Log1pe (zigp/transforms.py)
+    const double g = -(d.positive[b] ? gc * (0.5 * (1.0 + tanh(0.5 * x))) : gc);
+    const double mnew = d.beta1 * mv + (1.0 - d.beta1) * g;
+    const double vnew = d.beta2 * vv + (1.0 - d.beta2) * g * g;
+    const double lr_t = d.lr[b] * a.lr_sq / a.lr_den;
+    const double xnew = x - lr_t * mnew / (sqrt(vnew) + d.eps);
+    a.m[e] = mnew; a.v[e] = vnew; a.x[e] = xnew;
+    kfit_store_value(a, Hn, b, i, kfit_value(d, b, xnew));
+  }
 }
 
 struct KfFitCall {          // host side of one zigp_kron_fit_steps call
@@ -1429,14 +1403,14 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     off_s[h] = off; off += (size_t)hl[h].M[0] * hl[h].M[1];
   }
   const size_t off_hyp = off; off += KH_SIZE;
+  const size_t off_hyp2 = off; off += KH_SIZE;      // second hyperparameter block (fit calls: step i reads block i % 2, its update writes the other)
   const size_t n_par = off;
   const size_t off_x = n_par, off_y = dev_xy ? off_x : off_x + (size_t)N * ldx;
   const size_t n_in = dev_xy ? n_par : off_y + (size_t)N;
   const size_t n_wrap = fit ? [&] { size_t k = 0; for (int i = 0; i < fit->n_steps; ++i) if (fit->row_begin[i] < 0) k = std::max<size_t>(k, (size_t)(-fit->row_begin[i])); return k; }() : 0;
   ZIGP_ENSURE(c, ks.in, n_in + n_wrap * (size_t)N * (ldx + 1));
-  double* const d_hyp = ks.in.p + off_hyp;
+  double* d_hyp = ks.in.p + off_hyp;          // the hyperparameter block the next enqueue()'s kernels read
   double* const d_wrap = ks.in.p + n_in;      // fit: host batches [k][N][ldx], then their Y [k][N]
-  double zc[2][2][MAXD];
   if (!fit) {
     ZIGP_PINNED(c, hin, n_in);
     if (!dev_xy) {
@@ -1453,20 +1427,13 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
       for (int q = 0; q < 2; ++q) {
         const int M = hl[h].M[q], D = q == 0 ? D0 : D1;
         double* Rh = H + (2 * h + q) * KH_FAC;
-        for (int d = 0; d < MAXD; ++d) {
-          double lo = 0.0, hi = 0.0;
-          if (d < D) {
-            lo = hi = hl[h].Z[q][d];
-            for (int m = 1; m < M; ++m) { const double z = hl[h].Z[q][(size_t)m * D + d]; lo = std::min(lo, z); hi = std::max(hi, z); }
-          }
-          zc[h][q][d] = 0.5 * (lo + hi);
-          Rh[KH_ZC + d] = zc[h][q][d];
+        for (int d = 0; d < MAXD; ++d) {      // (KH_ZC, the centre of the moment sums, is filled in by k_kf_factor)
           Rh[KH_INV + d] = d < D ? 1.0 / hl[h].ell[q][d] : 0.0;
           Rh[KH_ELL + d] = d < D ? hl[h].ell[q][d] : 0.0;
         }
         Rh[KH_VAR] = hl[h].var[q];
+        (void)M;
       }
-      H[KH_KNN + h] = hl[h].var[0] * hl[h].var[1];
     }
     H[KH_NOISE] = p->noise;
     ZIGP_HIP(c, hipMemcpyAsync(ks.in.p, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, c->stream));
@@ -1520,7 +1487,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
         for (int q = 0; q < 2; ++q) {
           KfFactorJob& jb = fa.job[2 * h + q];
           jb.Z = ks.in.p + off_z[h][q]; jb.M = hl[h].M[q]; jb.D = q == 0 ? D0 : D1; jb.Mq = Mq[h][q];
-          jb.hyp = d_hyp + (2 * h + q) * KH_FAC;
+          jb.hyp = d_hyp + (2 * h + q) * KH_FAC; jb.zc_out = d_hyp + (2 * h + q) * KH_FAC + KH_ZC;
           jb.K = fac(h, q); jb.P = fac(h, q) + FAC_P; jb.PF = fac(h, q) + FAC_PF; jb.dvec = fac(h, q) + FAC_DV; jb.Zs = fac(h, q) + FAC_ZS;
         }
       fa.jitter = jitter; fa.piv_rtol = c->pivot_rtol;
@@ -1723,7 +1690,16 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     d.off[16] = (int)o; d.n[16] = 1; d.dst[16] = 0; d.positive[16] = fit->opts->positive[16]; d.lr[16] = fit->opts->lr[16];
     o += 1;
     if ((int64_t)o != fit->n_free) { c->err = "zigp_kron_fit_steps: n_free does not match the model sizes"; return ZIGP_EARG; }
-    d.off_hyp = (int)off_hyp;
+    d.off_hyp = (int)off_hyp; d.off_hyp2 = (int)off_hyp2;
+    {
+      int nbig = 0, nhyp = 0, kb = 0, kh = 0;
+      for (int b = 0; b < KFIT_BLOCKS; ++b) {
+        const bool big = b != 16 && b % 8 <= 3;
+        if (big) { d.big_blk[kb] = b; d.big_off[kb++] = nbig; nbig += d.n[b]; }
+        else { d.hyp_blk[kh] = b; d.hyp_off[kh++] = nhyp; nhyp += d.n[b]; }
+      }
+      d.big_off[8] = nbig; d.hyp_off[9] = nhyp;
+    }
     d.res_size = (int)RES_SIZE; d.res_krow0 = (int)RES_KROW0; d.res_krow1 = (int)RES_KROW1; d.res_gu = (int)RES_GU; d.res_gs = (int)RES_GS;
     d.res_pws = (int)RES_PWS; d.res_info = (int)RES_INFO;
     d.beta1 = fit->opts->beta1; d.beta2 = fit->opts->beta2; d.eps = fit->opts->eps;
@@ -1745,20 +1721,22 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
         ZIGP_HIP(c, hipMemcpyAsync(d_wrap, hw, sizeof(double) * nw, hipMemcpyHostToDevice, c->stream));
       }
     }
-    ZIGP_HIP(c, hipMemsetAsync(ks.in.p + off_hyp, 0, sizeof(double) * KH_SIZE, c->stream));
+    ZIGP_HIP(c, hipMemsetAsync(ks.in.p + off_hyp, 0, sizeof(double) * 2 * KH_SIZE, c->stream));
+    const dim3 ugrid((d.big_off[8] + KFIT_THREADS - 1) / KFIT_THREADS + 1);
     fa.update = 0; fa.step = 0;
-    hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(1024), 0, c->stream, fa, (int)nf);       // free state -> parameter image
+    hipLaunchKernelGGL(k_fit_update, ugrid, dim3(KFIT_THREADS), 0, c->stream, fa);       // free state -> parameter image (hyper block 0)
     ZIGP_HIP(c, hipGetLastError());
     fa.update = 1;
     for (int i = 0; i < fit->n_steps; ++i) {
       const int64_t rb = fit->row_begin[i];
       const double* Xd = rb >= 0 ? X + rb * ldx : d_wrap + (size_t)(-rb - 1) * N * ldx;
       const double* Yd = rb >= 0 ? Y + rb : d_wrap + n_wrap * (size_t)N * ldx + (size_t)(-rb - 1) * N;
+      d_hyp = ks.in.p + ((i & 1) ? off_hyp2 : off_hyp);       // written by the previous step's update (step 0: by the launch above)
       ZIGP_TRY(enqueue(Xd, Yd));
       // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), t counted from 1 (zigp/optim.py AdamGroups.step): the two t-dependent factors from the host
       const double t = (double)(fit->t0 + i + 1);
       fa.step = i; fa.lr_sq = std::sqrt(1.0 - std::pow(d.beta2, t)); fa.lr_den = 1.0 - std::pow(d.beta1, t);
-      hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(1024), 0, c->stream, fa, (int)nf);
+      hipLaunchKernelGGL(k_fit_update, ugrid, dim3(KFIT_THREADS), 0, c->stream, fa);
       ZIGP_HIP(c, hipGetLastError());
     }
     double* hst = nullptr;
