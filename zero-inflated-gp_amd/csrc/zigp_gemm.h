@@ -361,7 +361,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
   constexpr int WTN = Shape<WAVES>::WTN, TNW = Shape<WAVES>::TNW, CHUNKS = Shape<WAVES>::CHUNKS;
   constexpr int RW = Shape<WAVES>::RW, TMW = Shape<WAVES>::TMW, WMW = Shape<WAVES>::WMW;
   // the 4-base A map costs 3 VGPRs more: used where the B tile is m/n-contiguous (1 base register), not in the K/K kernels
-  constexpr bool A_NEWMAP = (BLAY == LAY_MNCONTIG);
+#ifndef ZIGP_KK_NEWMAP
+#define ZIGP_KK_NEWMAP 0
+#endif
+  constexpr bool A_NEWMAP = (BLAY == LAY_MNCONTIG) || (ZIGP_KK_NEWMAP != 0 && KSCALE && TRI == TRI_C_LOWER);   // the rank-N update only: the O(M^3) K/K products spill with it
   constexpr bool B_PAD = (ZIGP_BPAD != 0) && (BLAY == LAY_KCONTIG);
   const GemmSeg& sg = g.seg[0];
   const int64_t row0 = (int64_t)tl.bi * BM, col0 = (int64_t)tl.bj * BN;
@@ -435,9 +438,50 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
   };
   // One BK step of this wave's RW x 64 sub-tile, fully unrolled.  The loop has ONE body (runtime predicates inside the unrolled nest,
   // and a choice of bodies, spill and pessimise its schedule: the 4-wave kernels sit close to 256 VGPRs).
+#ifndef ZIGP_KK_PIPE
+#define ZIGP_KK_PIPE 0
+#endif
   auto body = [&](const double* As) {
     const double* Bs = As + TILE_DOUBLES;
     const int (&a_base)[4] = a_base_; const int (&b_base)[4] = b_base_;
+    if constexpr (ZIGP_KK_PIPE != 0 && WAVES == 4 && ALAY == LAY_KCONTIG && BLAY == LAY_KCONTIG && KSCALE && TRI == TRI_C_LOWER) {
+      // explicit two-deep fragment pipeline of the k-contiguous / k-contiguous kernels (the symmetric rank-N update): the 20 LDS reads of
+      // k-step ks + 1 are issued one per three MFMAs of k-step ks (sched_group_barrier), into the other fragment set
+      double afb[2][TMW][4], bfb[2][TNW];
+      auto load = [&](int ks, double (&af)[TMW][4], double (&bf)[TNW]) {
+#pragma unroll
+        for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + tn * (B_PAD ? 258 : 256)];
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) af[tm][r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
+        if (KSCALE) {
+          const double sc = As[2 * TILE_DOUBLES + ks * 4 + kq];
+#pragma unroll
+          for (int tn = 0; tn < TNW; ++tn) bf[tn] *= sc;
+        }
+      };
+      load(0, afb[0], bfb[0]);
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        if (ks + 1 < BK / 4) load(ks + 1, afb[(ks + 1) & 1], bfb[(ks + 1) & 1]);
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TNW; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(afb[ks & 1][tm][r], bfb[ks & 1][tn], acc[tm][tn][r], 0, 0, 0);
+        if (ks + 1 < BK / 4) {
+#pragma unroll
+          for (int i = 0; i < TMW * 4 + TNW + (KSCALE ? 1 : 0); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);    // three MFMAs
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       const int k = ks * 4 + kq;
