@@ -221,3 +221,21 @@ def test_factored_kronecker_algebra_differs_from_literal_order_even_with_the_ora
     print('factored fmean vs literal oracle: with np.linalg.inv %.2e, with Cholesky %.2e' % (e_lu, e_ch))
     assert e_lu > 1e-6               # the oracle's own inverse does not reach 1e-6 in factored order either
     assert e_ch < 3.0 * e_lu         # and Cholesky is in the same accuracy class
+
+
+def test_gauss_hermite_expectation_equals_the_closed_form_the_reference_uses():
+    """north_star mentions a 'Gauss-Hermite-quadrature OnOff likelihood expectation'.  GPflow 0.4.0's Likelihood.variational_expectations
+    is 20-node Gauss-Hermite of logp(F, Y) -- but OnOffLikelihood defines no logp and OVERRIDES it with the closed form
+    (onoffgpf/OnOffLikelihood.py:28-32, four arguments).  For the Gaussian observation density that closed form stands for,
+    log N(y | f, s2) with f ~ N(Fmu, Fvar + Fmuvar), the integrand is a quadratic in f and 20-node Gauss-Hermite integrates it exactly:
+    a quadrature mode could only reproduce the numbers of the closed form, which is why the engine has none."""
+    import zigp_oracle as o
+    rs = np.random.RandomState(0)
+    Fmu, Fvar, Fmuvar, Y = rs.randn(50, 1), rs.rand(50, 1) + 0.01, rs.rand(50, 1), rs.randn(50, 1)
+    s2 = 0.37
+    closed = o.variational_expectations(Fmu, Fvar, Fmuvar, Y, s2)
+    x, w = np.polynomial.hermite.hermgauss(20)                      # GPflow: hermgauss(num_gauss_hermite_points = 20), weights / sqrt(pi)
+    f = Fmu + np.sqrt(2.0 * (Fvar + Fmuvar)) * x[None, :]
+    logp = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(s2) - 0.5 * (Y - f) ** 2 / s2
+    gh = (logp * (w / np.sqrt(np.pi))[None, :]).sum(1, keepdims=True)
+    assert np.max(np.abs(gh - closed)) < 1e-12 * np.max(np.abs(closed))
