@@ -31,6 +31,22 @@
 namespace zigp {
 
 constexpr int BM = 128, BN = 128, BK = 16;
+// ZIGP_MFMA16 (round 4): the 16 x 16 x 4 products are issued as ONE v_mfma_f64_16x16x4_f64 instead of four v_mfma_f64_4x4x4_4b_f64.
+// Round 1 had measured the 16x16x4 instruction at ~48 TFLOP/s chip-wide and built the core on the 4x4x4 form -- but that microbenchmark's
+// loop copied every accumulator between VGPRs and AGPRs around each MFMA (compiler artefact of its launch bounds); in the VGPR form the
+// kernels here compile to, 16x16x4 sustains 77.5 TFLOP/s (tools/ubench/mfma_f64_tile.hip, profiles/r04k_ubench_mfma_tile.log), and
+// rocBLAS' gfx950 DGEMM kernels (MI16x16x4x1) reach 74-77 TFLOP/s (tools/dgemm_probe.py).  With it the A operand of a 16-row sub-tile is
+// ONE ds_read_b64 per lane (lane -> row l % 16, k l / 16) instead of four broadcast reads, and a BK step issues 64 instead of 256 MFMAs.
+// The accumulator layout is the same (element r of lane l = C[4 r + l / 16][l % 16]), so epilogues are unchanged.
+#ifndef ZIGP_MFMA16
+#define ZIGP_MFMA16 1
+#endif
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma16(double (&c)[4], double a, double b) {
+  mfma_d4 v = {c[0], c[1], c[2], c[3]};
+  v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, v, 0, 0, 0);
+  c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
+}
 // Workgroup shapes (template parameter WAVES of the kernel): WAVES/2 (M) x 2 (N) waves, wave tiles 64 columns wide.
 //   WAVES = 4: wave tile 64x64, 64 accumulators/lane, <= 256 VGPRs, 2 waves/SIMD with 2 workgroups/CU
 //   WAVES = 8: wave tile 32x64, 32 accumulators/lane, <= 128 VGPRs, 4 waves/SIMD with 2 workgroups/CU; triangular
@@ -322,6 +338,15 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
 #pragma unroll
         for (int c = 0; c < NC2; ++c) bf[c] *= sc;
       }
+      if constexpr (ZIGP_MFMA16 != 0) {
+        // the A operand of sub-tile row R is the SAME read as the B operand of column sub-tile R (one image, both roles): lane -> (row, k)
+        (void)af1; (void)af2;
+        const double a2 = As[b_base[ks] + R2 * 256], a1 = As[b_base[ks] + R1 * 256];
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) mfma16(acc2[0][c], a2, bf[c]);
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) mfma16(acc1[0][c], a1, bf[c]);
+      } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         af1[r] = As[a_base + (R1 * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r))];
@@ -335,6 +360,7 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
       for (int c = 0; c < NC1; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc1[0][c][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af1[r], bf[c], acc1[0][c][r], 0, 0, 0);
+      }
     }
   };
 #pragma unroll
@@ -364,7 +390,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 #ifndef ZIGP_KK_NEWMAP
 #define ZIGP_KK_NEWMAP 0
 #endif
-  constexpr bool A_NEWMAP = (BLAY == LAY_MNCONTIG) || (ZIGP_KK_NEWMAP != 0 && KSCALE && TRI == TRI_C_LOWER);   // the rank-N update only: the O(M^3) K/K products spill with it
+  constexpr bool M16 = ZIGP_MFMA16 != 0;
+  // 16x16x4 form: a k-contiguous A image is read exactly as a k-contiguous B image (16 rows x 4 k per wave read): the plain map, padded
+  constexpr bool A_NEWMAP = !M16 && ((BLAY == LAY_MNCONTIG) || (ZIGP_KK_NEWMAP != 0 && KSCALE && TRI == TRI_C_LOWER));   // (the rank-N update only: the O(M^3) K/K products spill with it)
+  constexpr bool A_PAD = M16 && (ZIGP_BPAD != 0) && (ALAY == LAY_KCONTIG);
   constexpr bool B_PAD = (ZIGP_BPAD != 0) && (BLAY == LAY_KCONTIG);
   const GemmSeg& sg = g.seg[0];
   const int64_t row0 = (int64_t)tl.bi * BM, col0 = (int64_t)tl.bj * BN;
@@ -383,6 +412,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
     a_base_[x] = (ALAY == LAY_KCONTIG) ? (A_NEWMAP ? ((wrow + a_i) * 16 + 2 * ((a_i ^ (kq >> 1)) ^ x) + (kq & 1))
                                                     : ((wrow + a_i) * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1)))
                                       : (kq * LDMN + wrow + a_i);
+  // 16x16x4 form: lane -> (row wrow + b_j, k = 4 ks + kq) of the A image; one base per k-step for a k-contiguous image (as for B), one in all
+  // for an m-contiguous one; the 16-row sub-tile tm is a compile-time offset
+  int a16_base_[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    a16_base_[ks] = (ALAY == LAY_KCONTIG) ? ((wrow + b_j) * 16 + (A_PAD ? (wrow / 16) * 2 : 0) + 2 * (((2 * ks) | (kq >> 1)) ^ kswz<false>(b_j)) + (kq & 1))
+                                         : (kq * LDMN + wrow + b_j + ks * 4 * LDMN);
   int b_base_[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
@@ -412,7 +448,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 
   auto issue = [&](int it) {
     double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
-    glds_tile<ALAY, WAVES>(st, baseA + it * strideA, offA, csA, wave);
+    glds_tile<ALAY, WAVES, A_PAD>(st, baseA + it * strideA, offA, csA, wave);
     glds_tile<BLAY, WAVES, B_PAD>(st + TILE_DOUBLES, baseB + it * strideB, offB, csB, wave);
     if (KSCALE) {   // 16 doubles of the scale vector; every wave issues the same 128 B (uniform vmcnt accounting)
       uint32_t so = 16 * ln;
@@ -479,6 +515,27 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);    // three MFMAs
           }
         }
+      }
+      return;
+    }
+    if constexpr (M16) {
+      const int (&a16_base)[4] = a16_base_;
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        double bf[TNW], af[TMW];
+#pragma unroll
+        for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * (B_PAD ? 258 : 256) : tn * 16)];
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm) af[tm] = As[a16_base[ks] + ((ALAY == LAY_KCONTIG) ? tm * (A_PAD ? 258 : 256) : tm * 16)];
+        if (KSCALE) {
+          const double sc = As[2 * TILE_DOUBLES + ks * 4 + kq];
+#pragma unroll
+          for (int tn = 0; tn < TNW; ++tn) bf[tn] *= sc;
+        }
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TNW; ++tn) mfma16(acc[tm][tn], af[tm], bf[tn]);
       }
       return;
     }
