@@ -280,7 +280,12 @@ template <int W, int NSTAGE, bool KSCALE, class Epi>
 __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile& tl, double* lds, int wave, int lane, const Epi& epi) {
   constexpr int WAVES = 4, CHUNKS = Shape<WAVES>::CHUNKS;
   constexpr int R1 = W, R2 = 7 - W, NC1 = W + 1, NC2 = 8 - W;   // this wave's two sub-tile rows and the column sub-tiles 0..NC-1 each needs
-  constexpr int SCALE_OFF = 128 * 16;                            // k-scale slice of an image: behind its 2048 doubles (TILE_DOUBLES = 2304)
+#ifndef ZIGP_DIAG_PAD
+#define ZIGP_DIAG_PAD 1
+#endif
+  constexpr bool DPAD = (ZIGP_DIAG_PAD != 0) && (ZIGP_MFMA16 != 0) && (ZIGP_BPAD != 0);   // 16 B in front of every 16-row block, as for the B images of the generic path
+  constexpr int SUB = DPAD ? 258 : 256;                          // doubles from one 16-row block of the image to the next
+  constexpr int SCALE_OFF = 128 * 16 + 16;                       // k-scale slice of an image: behind its 2048 (+ 16 of padding) doubles (TILE_DOUBLES = 2304)
   static_assert(TILE_DOUBLES >= SCALE_OFF + BK, "no room for the k-scale slice behind the operand image");
   const GemmSeg& sg = g.seg[0];
   int ln = lane;
@@ -311,7 +316,7 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
   const char* baseS = (const char*)(g.kscale + kfirst);
   const int64_t strideA = kd * BK * 8;
   auto issue_slice = [&](double* img, int sl) {   // BK slice `sl` of the tile's k range into the image at img
-    glds_tile<LAY_KCONTIG, WAVES>(img, baseA + sl * strideA, offA, csA, wave);
+    glds_tile<LAY_KCONTIG, WAVES, DPAD>(img, baseA + sl * strideA, offA, csA, wave);
     if (KSCALE) {
       uint32_t so = 16 * ln;
       asm volatile("" : "+v"(so));
@@ -332,7 +337,7 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
     for (int ks = 0; ks < BK / 4; ++ks) {
       double bf[NC2], af1[4], af2[4];
 #pragma unroll
-      for (int c = 0; c < NC2; ++c) bf[c] = As[b_base[ks] + c * 256];
+      for (int c = 0; c < NC2; ++c) bf[c] = As[b_base[ks] + c * SUB];
       if (KSCALE) {
         const double sc = As[SCALE_OFF + ks * 4 + kq];
 #pragma unroll
@@ -341,7 +346,7 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
       if constexpr (ZIGP_MFMA16 != 0) {
         // the A operand of sub-tile row R is the SAME read as the B operand of column sub-tile R (one image, both roles): lane -> (row, k)
         (void)af1; (void)af2;
-        const double a2 = As[b_base[ks] + R2 * 256], a1 = As[b_base[ks] + R1 * 256];
+        const double a2 = As[b_base[ks] + R2 * SUB], a1 = As[b_base[ks] + R1 * SUB];
 #pragma unroll
         for (int c = 0; c < NC2; ++c) mfma16(acc2[0][c], a2, bf[c]);
 #pragma unroll

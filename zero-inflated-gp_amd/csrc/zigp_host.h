@@ -56,6 +56,9 @@ constexpr int NST = ZIGP_NSTAGE;   // LDS ring depth of the GEMM core (2 -> 64 K
 template <int AL, int BL, bool KS> struct WavesFor { static constexpr int value = ZIGP_WAVES_DEFAULT; };
 #ifndef ZIGP_NO_8WAVE
 template <> struct WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false> { static constexpr int value = 8; };
+#ifdef ZIGP_SYRK_8W
+template <> struct WavesFor<LAY_KCONTIG, LAY_KCONTIG, true> { static constexpr int value = 8; };
+#endif
 #ifdef ZIGP_8WAVE_LOWER
 template <> struct WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false> { static constexpr int value = 8; };
 #endif
