@@ -146,7 +146,10 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
   const bool paired = trmm_paired_pays(nbm, nbn);
   ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, tl, paired));
   ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu, paired));
-  ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu_lpt, false));   // J': its epilogue loads an A2 tile, which the lockstep of the paired order makes coincide
+#ifndef ZIGP_J_PAIRED
+#define ZIGP_J_PAIRED 0
+#endif
+  ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu_lpt, ZIGP_J_PAIRED != 0 && paired));   // J': its epilogue loads an A2 tile, which the lockstep of the paired order makes coincide (LPT by default)
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {
     ProfScope ps(c, PC_GEMM_A1, fl);   // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
