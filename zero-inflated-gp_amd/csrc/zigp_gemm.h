@@ -2,16 +2,18 @@
 // product on the zero-inflated-GP ELBO path (replaces TF's MatMul / MatrixTriangularSolve call sites,
 // onofftf/main.py:271,284,287 and their tf.gradients twins, scripts/onoff.py:334).
 //
-// Design (measured on MI355X, profiles/r01_ubench_mfma_f64_*.log):
-//   * v_mfma_f64_16x16x4_f64 sustains only ~50 TFLOP/s (~97 cycles/instr/SIMD);
-//     v_mfma_f64_4x4x4_4b_f64 sustains ~75 TFLOP/s (~16.9 cycles/instr/SIMD, 512 flop each).
-//     cbsz/abid broadcast is ignored for f64, so a 16x16x4 product is issued as FOUR 4x4x4(4-block)
-//     instructions whose A operand is a 4-row block read from LDS with the same address in all four
-//     16-lane groups (LDS broadcast is free).  The accumulator layout then equals the 16x16x4 one:
-//     acc[r] of lane l = C[4r + l/16][l%16].
+// Design (measured on MI355X):
+//   * round 4: a 16 x 16 x 4 product is ONE v_mfma_f64_16x16x4_f64 (ZIGP_MFMA16, below): 77.5 TFLOP/s chip-wide in the VGPR form these
+//     kernels compile to (tools/ubench/mfma_f64_tile.hip, profiles/r04k_ubench_mfma_tile.log); the A operand of a 16-row sub-tile is one
+//     ds_read_b64 per lane (row l % 16, k l / 16), the B operand one (k l / 16, column l % 16), the accumulator element r of lane l is
+//     C[4 r + l / 16][l % 16].
+//   * rounds 1-3 (ZIGP_MFMA16 = 0, kept): the same product as FOUR v_mfma_f64_4x4x4_4b_f64 (~75 TFLOP/s, ~16.9 cycles/instr/SIMD) whose
+//     A operand is a 4-row block read from LDS with the same address in all four 16-lane groups (LDS broadcast is free; cbsz / abid
+//     broadcast is ignored for f64) -- chosen because round 1's rate test showed 16x16x4 at ~50 TFLOP/s, which turned out to measure the
+//     VGPR <-> AGPR copies the compiler had put around every MFMA of that test, not the instruction.
 //   * workgroup tile 128x128, BK = 16, as 4 waves (2x2, 64x64 wave tiles, 64 accumulators/lane) or 8 waves
 //     (4x2, 32x64 wave tiles, 32 accumulators/lane); two workgroups share a CU.  MFMA issue is never
-//     dependency-bound (>= 32 independent accumulators).
+//     dependency-bound (>= 8 independent 16x16 accumulator blocks).
 //   * operand tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into an
 //     NSTAGE-deep ring.  One wave-instruction writes 1 KB linearly, so bank conflicts are removed
 //     (a) for k-contiguous tiles ([128 rows][16 k], 8 rows per instruction) by an XOR swizzle of the 16-byte
