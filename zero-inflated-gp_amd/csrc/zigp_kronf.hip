@@ -1,7 +1,7 @@
 // Fused Kronecker (space x time) path for small inducing grids (every factor <= 16 * KF_NBMAX points): scripts/onoff.py:143-319,
 // onofftf/main.py:350-387, onofftf/onoffpred.py:127-200.  Same factored algebra as zigp_kron.hip (see its header), but nothing
 // of size O(M N) ever reaches HBM: a WAVE owns a tile of 16 points and keeps every per-point vector in registers in the
-// operand layout of v_mfma_f64_4x4x4 (4 blocks), whose B operand and D result share one lane layout
+// operand layout of v_mfma_f64_16x16x4 (round 4; rounds 2-3: four v_mfma_f64_4x4x4 per product), whose B operand and D result share one lane layout
 //     V[q] of lane l  =  V(row 4 q + l / 16, point l % 16)
 // so the result of one product feeds the next one with no shuffle or LDS round trip.  The M_p x M_p / M_0 x M_1 matrices
 // (P_p = K_p^-1, Alpha, S2 and the transposes) are read from global memory (L1 / L2 resident: 8 KB each at 32 x 32) in
@@ -60,6 +60,13 @@ constexpr int KF_ACC_BLOCKS = KF_B_K1 + KF_NBMAX;
 constexpr int KF_ACC_DOUBLES = KF_ACC_BLOCKS * 256;
 
 __device__ __forceinline__ double kf_mfma(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+// one 16 x 16 x 4 product: c[0..3] (rows 4 r + l / 16 of a 16-row block, point / column l % 16) += A(row l % 16, k l / 16) . B(k l / 16, column l % 16).
+// Since round 4 the point kernels issue this form (zigp_gemm.h has the story): one A value per lane and product instead of four.
+__device__ __forceinline__ void kf_mfma16(double* c, double a, double b) {
+  mfma_d4 v = {c[0], c[1], c[2], c[3]};
+  v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, v, 0, 0, 0);
+  c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
+}
 
 // order LDS traffic of ONE wave: the stores above must be visible to (and not sink below) the loads that follow
 __device__ __forceinline__ void kf_wave_sync() {
@@ -73,36 +80,29 @@ __device__ __forceinline__ void kf_wave_sync() {
 // them there, then come the 16 MFMAs of chunk c.  Left alone the compiler either waits for every load right before its MFMAs (runtime
 // bounds: one LDS round trip per k-step) or hoists all loads of the tile (compile-time bounds: hundreds of live registers, spills).
 template <int NBA, int QK>
-__device__ __forceinline__ void kf_frag_mm(double (&out)[4 * NBA], const double* __restrict__ F, int nba, int ksn, const double (&in)[QK], int slot) {
+__device__ __forceinline__ void kf_frag_mm(double (&out)[4 * NBA], const double* __restrict__ F, int nba, int ksn, const double (&in)[QK], int lane) {
   static_assert(QK % 4 == 0, "k-steps come in multiples of four (16-row blocks)");
-  const double4* __restrict__ F4 = reinterpret_cast<const double4*>(F);
 #pragma unroll
   for (int rb = 0; rb < NBA; ++rb) {
     if (rb < nba) {
-      const double4* __restrict__ Fr = F4 + rb * ksn * 16 + slot;
-      double4 cur[4];
+      const double* __restrict__ Fr = F + rb * ksn * 64 + lane;      // fragment order: one value per lane and (row block, k-step)
+      double cur[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) cur[u] = Fr[u * 16];
+      for (int u = 0; u < 4; ++u) cur[u] = Fr[u * 64];
 #pragma unroll
       for (int kc = 0; kc < QK / 4; ++kc) {
         if (4 * kc < ksn) {
-          double4 nxt[4];
+          double nxt[4];
           if (4 * (kc + 1) < ksn && kc + 1 < QK / 4) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) nxt[u] = Fr[(4 * (kc + 1) + u) * 16];
+            for (int u = 0; u < 4; ++u) nxt[u] = Fr[(4 * (kc + 1) + u) * 64];
           } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) nxt[u] = cur[u];
           }
           asm volatile("" ::: "memory");
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double b = in[4 * kc + u];
-            out[4 * rb + 0] = kf_mfma(cur[u].x, b, out[4 * rb + 0]);
-            out[4 * rb + 1] = kf_mfma(cur[u].y, b, out[4 * rb + 1]);
-            out[4 * rb + 2] = kf_mfma(cur[u].z, b, out[4 * rb + 2]);
-            out[4 * rb + 3] = kf_mfma(cur[u].w, b, out[4 * rb + 3]);
-          }
+          for (int u = 0; u < 4; ++u) kf_mfma16(&out[4 * rb], cur[u], in[4 * kc + u]);
 #pragma unroll
           for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
         }
@@ -311,7 +311,7 @@ k_kf_forward(KfArgs a) {
     kf_stage_z(sz[0], L.f[0]); kf_stage_z(sz[1], L.f[1]);
   }
   const KfFrags F = {sfr, sfr + KF_FRAG, sfr + 2 * KF_FRAG, sfr + 3 * KF_FRAG, nullptr, nullptr, sz[0], sz[1]};
-  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = lane;      // slot: this lane's position in a fragment block
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
   KfTile<NB0, NB1> t;
@@ -351,7 +351,7 @@ __device__ __forceinline__ void kf_store_tile(double* T, const double (&V)[Q], i
 // per-point scale on B;  MODE 0: plain, 1: both squared
 template <int NBR, int NBC, int MODE, bool SCALED>
 __device__ __forceinline__ void kf_accum(double (&acc)[NBR * NBC][4], const double* TA, const double* TB, const double (&sck)[4], int lane) {
-  const int ai = lane & 3, kk = lane >> 4, bj = lane & 15;
+  const int kk = lane >> 4, bj = lane & 15;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     double bf[NBC];
@@ -364,17 +364,10 @@ __device__ __forceinline__ void kf_accum(double (&acc)[NBR * NBC][4], const doub
     }
 #pragma unroll
     for (int rb = 0; rb < NBR; ++rb) {
-      double af[4];
+      double v = TA[(16 * rb + bj) * KF_LD + 4 * ks + kk];      // A operand: (row l % 16, point 4 ks + l / 16)
+      if (MODE == 1) v *= v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double v = TA[(16 * rb + 4 * r + ai) * KF_LD + 4 * ks + kk];
-        if (MODE == 1) v *= v;
-        af[r] = v;
-      }
-#pragma unroll
-      for (int cb = 0; cb < NBC; ++cb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[rb * NBC + cb][r] = kf_mfma(af[r], bf[cb], acc[rb * NBC + cb][r]);
+      for (int cb = 0; cb < NBC; ++cb) kf_mfma16(acc[rb * NBC + cb], v, bf[cb]);
     }
   }
 }
@@ -390,7 +383,7 @@ k_kf_backward(KfArgs a) {
   extern __shared__ double lds[];
   const KfLat& L = a.lat[a.lat0 + blockIdx.y];
   const KfFac &f0 = L.f[0], &f1 = L.f[1];
-  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = lane;      // slot: this lane's position in a fragment block
   const int wib = threadIdx.x >> 6;
   const int w = blockIdx.x * KF_WAVES + wib;
   constexpr int Q0 = 4 * NB0, Q1 = 4 * NB1;
@@ -513,15 +506,9 @@ k_kf_backward(KfArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int rb = 0; rb < NB0; ++rb)
+      for (int rb = 0; rb < NB0; ++rb) kf_mfma16(accK0[rb], c0[(16 * rb + n) * KF_LD + 4 * ks + g], psi[0][ks]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          accK0[rb][r] = kf_mfma(c0[(16 * rb + 4 * r + (lane & 3)) * KF_LD + 4 * ks + g], psi[0][ks], accK0[rb][r]);
-#pragma unroll
-      for (int rb = 0; rb < NB1; ++rb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          accK1[rb][r] = kf_mfma(c1[(16 * rb + 4 * r + (lane & 3)) * KF_LD + 4 * ks + g], psi[1][ks], accK1[rb][r]);
+      for (int rb = 0; rb < NB1; ++rb) kf_mfma16(accK1[rb], c1[(16 * rb + n) * KF_LD + 4 * ks + g], psi[1][ks]);
     }
     kf_wave_sync();
   }
@@ -658,13 +645,13 @@ struct KfFactorJob {
 // a step needs neither a memset launch nor a separate status copy.
 struct KfFactorArgs { KfFactorJob job[4]; double jitter; double piv_rtol; int* info; int own_slots; };
 
-// fragment image of a row-major matrix: F[((rb * ksn + ks) * 16 + slot) * 4 + r] = A(16 rb + 4 r + slot % 4, 4 ks + slot / 4)
+// fragment image of a row-major matrix: F[(rb * ksn + ks) * 64 + lane] = A(16 rb + lane % 16, 4 ks + lane / 16)   (the A operand of v_mfma_f64_16x16x4)
 __device__ __forceinline__ void kf_write_frag(double* __restrict__ F, int nbr, int ksn, int t, int nthreads, const double* __restrict__ A, int64_t lda,
                                               bool transposed) {
   const int total = nbr * ksn * 64;
   for (int idx = t; idx < total; idx += nthreads) {
-    const int r = idx & 3, slot = (idx >> 2) & 15, blk = idx >> 6, ks = blk % ksn, rb = blk / ksn;
-    const int row = 16 * rb + 4 * r + (slot & 3), k = 4 * ks + (slot >> 2);
+    const int ln = idx & 63, blk = idx >> 6, ks = blk % ksn, rb = blk / ksn;
+    const int row = 16 * rb + (ln & 15), k = 4 * ks + (ln >> 4);
     F[idx] = transposed ? A[(int64_t)k * lda + row] : A[(int64_t)row * lda + k];
   }
 }
@@ -782,21 +769,19 @@ k_kf_factor(KfFactorArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[r] = kf_mfma(av[u][r], bv[u], acc[r]);
       }
-      double4 o;
-      double* ov = reinterpret_cast<double*>(&o);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * rb + 4 * r + g;
         const double v = (i < M && j < M) ? acc[r] : 0.0;
-        ov[r] = v;
         jb.P[i * Mq + j] = v;
+        // fragment image (kf_write_frag): element (row R, column C) -> block (R / 16, C / 4), lane R % 16 + 16 (C % 4)
+        jb.PF[(int64_t)(rb * ksn + 4 * cb + (n >> 2)) * 64 + 4 * r + g + 16 * (n & 3)] = v;           // (row i, column j)
         if (rb != cb) {
           jb.P[j * Mq + i] = v;
-          jb.PF[((int64_t)((cb * ksn + 4 * rb + r) * 16 + (n & 3) + 4 * g)) * 4 + (n >> 2)] = v;     // element (row j, column i) of block (cb, rb)
+          jb.PF[(int64_t)(cb * ksn + 4 * rb + r) * 64 + n + 16 * g] = v;                              // (row j, column i): the mirror
         }
         if (i == j) jb.dvec[i] = v;
       }
-      *reinterpret_cast<double4*>(jb.PF + ((int64_t)((rb * ksn + 4 * cb + (n >> 2)) * 16 + g + 4 * (n & 3))) * 4) = o;
     }
   }
 }
@@ -912,8 +897,8 @@ __device__ __forceinline__ void kf_lds_store(double* __restrict__ dst, const dou
 __device__ __forceinline__ void kf_lds_frag(double* __restrict__ F, int nbr, int ksn, const double* A, bool transposed) {
   const int total = nbr * ksn * 64;
   for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    const int r = idx & 3, slot = (idx >> 2) & 15, blk = idx >> 6, ks = blk % ksn, rb = blk / ksn;
-    const int row = 16 * rb + 4 * r + (slot & 3), k = 4 * ks + (slot >> 2);
+    const int ln = idx & 63, blk = idx >> 6, ks = blk % ksn, rb = blk / ksn;
+    const int row = 16 * rb + (ln & 15), k = 4 * ks + (ln >> 4);
     F[idx] = transposed ? A[k * KF_SLD + row] : A[row * KF_SLD + k];
   }
 }

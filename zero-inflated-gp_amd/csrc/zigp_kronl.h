@@ -37,7 +37,7 @@ k_kfl_forward(KfArgs a) {
   extern __shared__ double lds[];
   const KfLat& L = a.lat[a.lat0 + blockIdx.y];
   const KfFrags F = kfl_stage_frags<STAGE>(lds, L, false);
-  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = lane;      // slot: this lane's position in a fragment block
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
   const int t1 = min((w + 1) * a.tpw, a.ntiles);
   KfTile<NB0, NB1> t;
@@ -87,7 +87,7 @@ k_kfl_backward(KfArgs a) {
   const KfLat& L = a.lat[a.lat0 + blockIdx.y];
   const KfFac &f0 = L.f[0], &f1 = L.f[1];
   const KfFrags F = kfl_stage_frags<STAGE>(lds, L, true);
-  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = lane;      // slot: this lane's position in a fragment block
   const int w = blockIdx.x * KF_WAVES + (threadIdx.x >> 6);
   const int nb0 = EXACT ? NB0 : f0.nb, nb1 = EXACT ? NB1 : f1.nb;
   const int Mq0 = 16 * nb0, Mq1 = 16 * nb1;
@@ -156,7 +156,7 @@ struct KflAccArgs { KflAccLat lat[2]; const double* X; int64_t N; int ldx, ntile
 __global__ void __launch_bounds__(256)
 k_kfl_accum(KflAccArgs a) {
   const KflAccLat& L = a.lat[blockIdx.z];
-  const int lane = threadIdx.x & 63, ai = lane & 3, kk = lane >> 4, bj = lane & 15;
+  const int lane = threadIdx.x & 63, kk = lane >> 4, bj = lane & 15;
   const int nblk = kf_nblocks(a.nb0c, a.nb1c);
   const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= nblk) return;
@@ -179,7 +179,7 @@ k_kfl_accum(KflAccArgs a) {
     const auto zc = KF_CONST(b.kind == 4 ? L.hyp0 : L.hyp1) + KH_ZC;
     const int psi_d = (bj == 0) ? -1 : ((bj <= D) ? bj - 1 : ((bj <= 2 * D) ? bj - 1 - D : -2));   // -1: constant 1, -2: 0
     const int t0 = a.tile0 + blockIdx.y * a.tps, t1 = min(t0 + a.tps, a.tile1);
-    const int oa = 16 * b.rb + 4 * ai, ob = 16 * b.cb + 4 * (bj & 3) + (bj >> 2);
+    const int oa = 16 * b.rb + 4 * (bj & 3) + (bj >> 2), ob = 16 * b.cb + 4 * (bj & 3) + (bj >> 2);     // both roles: row / column l % 16 of the block (permuted image, kfl_spill)
 #pragma unroll 2
     for (int tile = t0; tile < t1; ++tile) {
       const double* R = L.spill + (int64_t)(tile - a.tile0) * rec;
@@ -187,12 +187,12 @@ k_kfl_accum(KflAccArgs a) {
       for (int ks = 0; ks < 4; ++ks) {
         const int pt = 4 * ks + kk;
         const int64_t pn = (int64_t)tile * 16 + pt;
-        double4 av = *reinterpret_cast<const double4*>(R + offA + pt * MqA + oa);
+        double av = R[offA + pt * MqA + oa];          // A operand of v_mfma_f64_16x16x4: (row l % 16, point 4 ks + l / 16)
         double bv;
         if (b.kind <= 3) {
           bv = R[offB + pt * MqB + ob];
           if (b.kind == 0) bv *= L.gm[pn];
-          if (b.kind == 1) { bv = bv * bv * L.gv[pn]; av.x *= av.x; av.y *= av.y; av.z *= av.z; av.w *= av.w; }
+          if (b.kind == 1) { bv = bv * bv * L.gv[pn]; av *= av; }
         } else {
           bv = 0.0;
           if (pn < a.N) {
@@ -200,8 +200,7 @@ k_kfl_accum(KflAccArgs a) {
             else if (psi_d >= 0) { const double xv = a.X[pn * a.ldx + col0 + psi_d] - zc[psi_d]; bv = (bj <= D) ? xv : xv * xv; }
           }
         }
-        acc[0] = kf_mfma(av.x, bv, acc[0]); acc[1] = kf_mfma(av.y, bv, acc[1]);
-        acc[2] = kf_mfma(av.z, bv, acc[2]); acc[3] = kf_mfma(av.w, bv, acc[3]);
+        kf_mfma16(acc, av, bv);
       }
     }
   }
@@ -248,9 +247,8 @@ __device__ __forceinline__ void kf_frag_gmm_cb(double* __restrict__ C, int ldc, 
                                                const double* __restrict__ B, int ldb, int ncb) {
   // a wave owns a block ROW and up to CB column blocks of it: the A fragment of a k-step is loaded once and feeds CB independent
   // accumulator chains, and 1 + CB independent loads per k-step are in flight (a one-block loop is a chain of L2 round trips)
-  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, slot = (lane & 3) + 4 * g;
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const double4* __restrict__ F4 = reinterpret_cast<const double4*>(AF);
   const int ncg = (ncb + CB - 1) / CB;
   for (int unit = wave; unit < nbr * ncg; unit += nw) {
     const int rb = unit / ncg, cb0 = (unit - rb * ncg) * CB;
@@ -260,12 +258,12 @@ __device__ __forceinline__ void kf_frag_gmm_cb(double* __restrict__ C, int ldc, 
     // k-steps in batches of 4 (ksn is a multiple of 4): the 4 fragment loads and 4 CB operand loads of a batch are issued together,
     // then its 16 CB MFMAs -- one memory round trip per batch instead of one per k-step
     for (int k0 = 0; k0 < ksn; k0 += 4) {
-      double4 av[4];
+      double av[4];
       double bv[4][CB];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int ks = k0 + u;
-        av[u] = F4[(rb * ksn + ks) * 16 + slot];
+        av[u] = AF[(rb * ksn + ks) * 64 + lane];
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
           const int cb = min(cb0 + c, ncb - 1);      // clamped: the surplus chains of the last group are computed and dropped
@@ -275,10 +273,7 @@ __device__ __forceinline__ void kf_frag_gmm_cb(double* __restrict__ C, int ldc, 
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-          acc[c][0] = kf_mfma(av[u].x, bv[u][c], acc[c][0]); acc[c][1] = kf_mfma(av[u].y, bv[u][c], acc[c][1]);
-          acc[c][2] = kf_mfma(av[u].z, bv[u][c], acc[c][2]); acc[c][3] = kf_mfma(av[u].w, bv[u][c], acc[c][3]);
-        }
+        for (int c = 0; c < CB; ++c) kf_mfma16(acc[c], av[u], bv[u][c]);
     }
 #pragma unroll
     for (int c = 0; c < CB; ++c)
