@@ -85,10 +85,12 @@ class OnOffSVGP(Parameterized):
             self._engine.set_data(self.Xtrain.value, self.Ytrain.value)
             self._resident = True
         if self.minibatch_size >= self.num_data:
+            self._engine.select_rows(None)       # back to the full resident set (a minibatch_size raised after a minibatch step must not leave its last sample active)
             return 1.0
         # GPflow 0.4 MinibatchData picks its index manager by the batch fraction [GPflow-recall; not in the reference tree, unverified]:
-        # below one half sampling WITH replacement (rng.randint), from one half up a fresh permutation's head (without replacement)
-        if 2 * self.minibatch_size < self.num_data:
+        # up to one half sampling WITH replacement (rng.randint), ABOVE one half a fresh permutation's head (without replacement) -- the
+        # boundary case of exactly one half goes with randint, as the `fraction > 0.5` test of that recollection says
+        if 2 * self.minibatch_size <= self.num_data:
             idx = self._rng.randint(self.num_data, size=self.minibatch_size)
         else:
             idx = self._rng.permutation(self.num_data)[:self.minibatch_size]
