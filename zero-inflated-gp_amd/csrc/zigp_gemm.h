@@ -527,9 +527,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
     }
     if constexpr (M16) {
       const int (&a16_base)[4] = a16_base_;
-#pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        double bf[TNW], af[TMW];
+      // ZIGP_M16_PREFETCH (measured, off): two fragment sets, the LDS reads of k-step ks + 1 pinned IN FRONT of the MFMAs of k-step ks by a
+      // sched_barrier.  Left to itself the compiler reads a k-step's fragments, waits for all of them (s_waitcnt lgkmcnt(0)) and only then
+      // issues its 8 / 16 MFMAs; with the prefetch it still waits with lgkmcnt(0) -- now also for the reads it has just issued -- and the
+      // triangular products lose 1 % (61.8 vs 62.4 TFLOP/s, profiles/r04t_ab_prefetch.log): with 4 waves per SIMD the LDS latency of a
+      // k-step is already covered by the other waves.  Partial waits would need the reads in inline assembly.
+#ifndef ZIGP_M16_PREFETCH
+#define ZIGP_M16_PREFETCH 0
+#endif
+      double bfb[2][TNW], afb[2][TMW];
+      auto load = [&](int ks, double (&af)[TMW], double (&bf)[TNW]) {
 #pragma unroll
         for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * (B_PAD ? 258 : 256) : tn * 16)];
 #pragma unroll
@@ -539,10 +546,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 #pragma unroll
           for (int tn = 0; tn < TNW; ++tn) bf[tn] *= sc;
         }
+      };
+      if (ZIGP_M16_PREFETCH) load(0, afb[0], bfb[0]);
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        if (ZIGP_M16_PREFETCH) {
+          if (ks + 1 < BK / 4) load(ks + 1, afb[(ks + 1) & 1], bfb[(ks + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);      // the reads stay IN FRONT of this k-step's MFMAs (the scheduler otherwise sinks them to where their values are used)
+        } else load(ks, afb[ks & 1], bfb[ks & 1]);
 #pragma unroll
         for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TNW; ++tn) mfma16(acc[tm][tn], af[tm], bf[tn]);
+          for (int tn = 0; tn < TNW; ++tn) mfma16(acc[tm][tn], afb[ks & 1][tm], bfb[ks & 1][tn]);
       }
       return;
     }
