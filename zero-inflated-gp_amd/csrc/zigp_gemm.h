@@ -473,10 +473,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 
   // stage `it` must have landed (at most NSTAGE-2 younger stages may stay in flight), every wave is done with the stage about to be
   // overwritten, then the next stage is requested: one barrier per BK step
+  // ZIGP_KO_*: knock-out switches for TIMING experiments (results are wrong with any of them): what does the barrier, the epilogue, the
+  // LDS fragment traffic cost?  (profiles/r04u_knockout.log)
+#ifndef ZIGP_KO_BARRIER
+#define ZIGP_KO_BARRIER 0
+#endif
+#ifndef ZIGP_KO_EPI
+#define ZIGP_KO_EPI 0
+#endif
+#ifndef ZIGP_KO_LDS
+#define ZIGP_KO_LDS 0
+#endif
+#ifndef ZIGP_KO_GLDS
+#define ZIGP_KO_GLDS 0
+#endif
   auto stage_step = [&](int it) -> const double* {
-    if (it + NSTAGE - 2 < total) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (it + NSTAGE - 1 < total) issue(it + NSTAGE - 1);
+    if (!(ZIGP_KO_GLDS && TRI != TRI_NONE)) { if (it + NSTAGE - 2 < total) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>(); }
+    if (!(ZIGP_KO_BARRIER && TRI != TRI_NONE)) __builtin_amdgcn_s_barrier();      // (TRI != TRI_NONE: the chunk-loop kernels only -- the M x M stage must stay correct, or its Cholesky fails)
+    if (!(ZIGP_KO_GLDS && TRI != TRI_NONE) && it + NSTAGE - 1 < total) issue(it + NSTAGE - 1);
     return lds + (it % NSTAGE) * STAGE_DOUBLES;
   };
   // One BK step of this wave's RW x 64 sub-tile, fully unrolled.  The loop has ONE body (runtime predicates inside the unrolled nest,
@@ -537,6 +551,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 #endif
       double bfb[2][TNW], afb[2][TMW];
       auto load = [&](int ks, double (&af)[TMW], double (&bf)[TNW]) {
+        if (ZIGP_KO_LDS && TRI != TRI_NONE) {      // no LDS traffic: operands from registers (values that the compiler cannot fold)
+#pragma unroll
+          for (int tn = 0; tn < TNW; ++tn) { bf[tn] = __builtin_amdgcn_readfirstlane(ks + tn) * 1e-3 + acc[0][tn][0] * 1e-300; }
+#pragma unroll
+          for (int tm = 0; tm < TMW; ++tm) { af[tm] = (double)(ks + tm) * 1e-3 + acc[tm][0][1] * 1e-300; }
+          return;
+        }
 #pragma unroll
         for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * (B_PAD ? 258 : 256) : tn * 16)];
 #pragma unroll
@@ -621,6 +642,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
   EpiCtx e;
   e.C = g.C + (int64_t)tl.slice * g.slice_stride; e.ldc = g.ldc; e.alpha = g.alpha;
   e.row0 = row0 + wrow; e.col0 = col0 + wn * WTN; e.lane = lane; e.prow = (int64_t)tl.bi * WMW + wm;
+  if (ZIGP_KO_EPI && TRI != TRI_NONE) { if (acc[0][0][0] == 1.2345e300) epi(acc, e); return; }   // no stores (the test keeps the accumulators live)
   epi(acc, e);
 }
 
