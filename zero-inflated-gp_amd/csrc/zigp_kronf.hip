@@ -797,24 +797,19 @@ template <bool TA, bool TB, bool ACC>
 __device__ __forceinline__ void kf_lds_mm(double* C, const double* A, const double* B, int m, int n, int k, int w0 = 0) {
   // w0: first wave of this product (independent products of one phase start on different waves: a 32 x 32 product is four blocks)
   const int nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - w0) % nwaves, lane = threadIdx.x & 63;
-  const int ai = lane & 3, kq = lane >> 4, bj = lane & 15, ci = lane >> 4;
+  const int kq = lane >> 4, bj = lane & 15, ci = lane >> 4;
   const int nbn = n / 16, nblk = (m / 16) * nbn;
   for (int blk = wave; blk < nblk; blk += nwaves) {
     const int rb = blk / nbn, cb = blk - rb * nbn;
     double acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = ACC ? C[(16 * rb + 4 * r + ci) * KF_SLD + 16 * cb + bj] : 0.0;
-    for (int ks = 0; ks < k / 4; ++ks) {
+    for (int ks = 0; ks < k / 4; ++ks) {      // one 16 x 16 x 4 product per k-step: A (row l % 16, k l / 16), B (k l / 16, column l % 16)
       const int q = 4 * ks + kq;
       const double b = TB ? B[(16 * cb + bj) * KF_SLD + q] : B[q * KF_SLD + 16 * cb + bj];
-      double af[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * rb + 4 * r + ai;
-        af[r] = TA ? A[q * KF_SLD + i] : A[i * KF_SLD + q];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = kf_mfma(af[r], b, acc[r]);
+      const int i = 16 * rb + bj;
+      const double a = TA ? A[q * KF_SLD + i] : A[i * KF_SLD + q];
+      kf_mfma16(acc, a, b);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) C[(16 * rb + 4 * r + ci) * KF_SLD + 16 * cb + bj] = acc[r];
@@ -1020,11 +1015,14 @@ k_kf_finish(KfFinishArgs a) {
   }
   __syncthreads();
   if (p == 0) {
-    kf_lds_mm_seq<false, false, false>(sX, sdAl, sPo, Mq0, Mq1, Mq1);       // X = dAl P1
-    kf_lds_mm_seq<false, true, true>(sdP, sdAl, sT, Mq0, Mq0, Mq1);         // dP0 += dAl T0^T
-    if (kl) kf_lds_mm_seq<false, true, false>(sQ, sT, sU, Mq0, Mq0, Mq1);   // Q0 = T0 U^T
+    // (rounds 3: these ran one thread per element with k in ascending order, to keep the last digits of d var / d ell where a test's
+    // "op-order floor" margin had seen them; with the compensated sandwich below that margin is gone -- section 1 of DESIGN.md -- and
+    // the products are back on the MFMA pipe, the independent ones of the phase on different waves)
+    kf_lds_mm<false, false, false>(sX, sdAl, sPo, Mq0, Mq1, Mq1);           // X = dAl P1
+    kf_lds_mm<false, true, true>(sdP, sdAl, sT, Mq0, Mq0, Mq1, 4);          // dP0 += dAl T0^T
+    if (kl) kf_lds_mm<false, true, false>(sQ, sT, sU, Mq0, Mq0, Mq1, 8);    // Q0 = T0 U^T
     __syncthreads();
-    kf_lds_mm_seq<false, false, false>(sG, sP, sX, Mq0, Mq1, Mq0);          // dU = P0 X
+    kf_lds_mm<false, false, false>(sG, sP, sX, Mq0, Mq1, Mq0);              // dU = P0 X
     __syncthreads();
     for (int idx = t; idx < M0 * M1; idx += 1024) {
       const int i = idx / M1, j = idx - i * M1;
@@ -1034,8 +1032,8 @@ k_kf_finish(KfFinishArgs a) {
       jb.gu[idx] = gu; jb.gs[idx] = gs;
     }
   } else {
-    kf_lds_mm_seq<true, false, true>(sdP, sT, sdAl, Mq1, Mq1, Mq0);         // dP1 += T1^T dAl
-    if (kl) kf_lds_mm_seq<true, false, false>(sQ, sU, sT, Mq1, Mq1, Mq0);   // Q1 = U^T T1
+    kf_lds_mm<true, false, true>(sdP, sT, sdAl, Mq1, Mq1, Mq0);             // dP1 += T1^T dAl
+    if (kl) kf_lds_mm<true, false, false>(sQ, sU, sT, Mq1, Mq1, Mq0, 4);    // Q1 = U^T T1
   }
   __syncthreads();
   // sX = sym(dP) [- kl pieces]
