@@ -543,8 +543,9 @@ def main():
             res['side_kernels'] = hbm
             res['mfma_busy_pmc'] = mfma_util
             # device time per class in the profiled pass (exact sums, no extrapolation).  mxm_stage covers BOTH latents' chains, which
-            # run concurrently on two streams (forward: wall time of the two interleaved chains; reverse: the sum of the two chains):
-            # it is listed apart and not part of the single-stream sum.
+            # run concurrently on two streams: wall time of the forward stage + wall time of the reverse stage (events on the main
+            # stream around fork ... join; until round 3 the reverse part was the SUM of the two concurrent chains, which overstated
+            # the stage by ~0.8 ms).  It is listed apart and not part of the single-stream sum.
             kms = {k: v['ms'] / args.profile_steps for k, v in prof.items()}
             res['profiled_pass'] = {'ms_per_step_wall': prof_wall_ms,
                                     'kernel_ms_per_step': {k: v for k, v in kms.items() if k != 'mxm_stage'},

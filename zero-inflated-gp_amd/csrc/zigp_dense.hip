@@ -86,18 +86,16 @@ int latents_forward(zigp_ctx* c, const HostLatent (&hl)[2], int D, double jitter
     Latent& lt = c->lat[h];
     const int Mp = lt.Mp;
     c->stream = st[h];
-    hipLaunchKernelGGL(k_square, dim3(ceil_div(Mp, 256)), dim3(256), 0, c->stream, lt.s.p, lt.s2.p, Mp);
     KernHyp hyp = make_hyp(hl[h].ell, hl[h].var, D);
-    hipLaunchKernelGGL(k_rbf_matrix, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.Z.p, (int64_t)hl[h].M, lt.Z.p,
-                       (int64_t)hl[h].M, hyp, jitter, lt.Kuu.p, (int64_t)Mp, (int64_t)Mp, (int64_t)Mp);
+    hipLaunchKernelGGL(k_kuu_setup, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.Z.p, (int64_t)hl[h].M, hyp, jitter, lt.Kuu.p,
+                       lt.L.p, lt.W.p, lt.s.p, lt.s2.p, (int64_t)Mp);
     ZIGP_HIP(c, hipGetLastError());
-    ZIGP_HIP(c, hipMemcpyAsync(lt.L.p, lt.Kuu.p, sizeof(double) * Mp * Mp, hipMemcpyDeviceToDevice, c->stream));
   }
   {
     PotrfJob jobs[2];
     for (int h = 0; h < 2; ++h) {
       Latent& lt = c->lat[h];
-      jobs[h] = PotrfJob{lt.L.p, lt.W.p, lt.T1.p, lt.Mp, true, lt.M, pivot_tol(hl[h].var, jitter, c->pivot_rtol)};
+      jobs[h] = PotrfJob{lt.L.p, lt.W.p, lt.T1.p, lt.Mp, true, lt.M, pivot_tol(hl[h].var, jitter, c->pivot_rtol), true, &lt.sk};
     }
     ZIGP_TRY(potrf_trtri_jobs(c, 2, jobs, st));
   }
@@ -223,7 +221,6 @@ int latent_chunk_syrk(zigp_ctx* c, Latent& lt, int64_t Nc) {
 
 // MxM backward: G = dELBO/dKuu (symmetric) -> krow accumulators.
 int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with_data, bool with_kl) {
-  ProfScope ps(c, PC_MXM);
   const int Mp = lt.Mp, nb = Mp / BM, kb = BM / BK;
   const size_t mm = (size_t)Mp * Mp;
   ZIGP_ENSURE(c, lt.T1, mm); ZIGP_ENSURE(c, lt.T2, mm); ZIGP_ENSURE(c, lt.T3, mm); ZIGP_ENSURE(c, lt.G, mm);
@@ -530,6 +527,7 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   ZIGP_TRY(dense_chunk_loop(c, k));
   if (predict) { ZIGP_HIP(c, hipStreamSynchronize(c->stream)); prof_collect(c); return info_result(c, k.hinfo, "Kuu"); }
   if (k.need_grad) {
+    ProfScope ps(c, PC_MXM);     // wall time of the two concurrent chains, as in the forward: both events on the main stream, the second after the join
     TwoStream ts(c);
     ZIGP_TRY(ts.fork());
     for (int h = 0; h < 2; ++h) {

@@ -265,7 +265,48 @@ static inline double pivot_tol(double var, double jitter, double rtol = 8.0) { r
 // One or two factorisations at a time: the launches of job 0 go to streams[0], those of job 1 to streams[1], ALTERNATING step by
 // step.  A chain is ~25 dependent launches of 5-50 us; enqueued one chain after the other, the second stream started ~100-400 us
 // late (the host was still enqueueing the first), and the M x M forward of the two latents took that much longer than one chain.
-struct PotrfJob { double* L; double* W; double* T; int Mp; bool want_W; int Mreal; double piv_tol; };
+// split-K over an explicit tile set (the panel solve / trailing update of the blocked factorisation and the block products of the triangular
+// inverse below: 4-28 tiles of 8-32 staged steps, i.e. 4-28 workgroups that each run 15-70 us at one CU's rate).  Every tile's k range is cut into S slices, slice s writes its partial tile into
+// plane s, and k_sk_finish_tiles adds the planes IN ORDER (deterministic) and stores alpha * sum into C (accum: adds it to C) -- at these
+// tiles only.
+__global__ void __launch_bounds__(256)
+k_sk_finish_tiles(const double* __restrict__ planes, const GemmTile* __restrict__ tiles, int S, int64_t Mp, double alpha, int accum, double* __restrict__ out) {
+  const GemmTile tl = tiles[blockIdx.x >> 6];                          // the first `count` entries of the list are slice 0 of every tile
+  const int e = ((blockIdx.x & 63) << 8) + threadIdx.x;                // element of the 128 x 128 tile
+  const int64_t idx = ((int64_t)tl.bi * BM + (e >> 7)) * Mp + (int64_t)tl.bj * BN + (e & 127);
+  double v = 0.0;
+  for (int s = 0; s < S; ++s) v += planes[(int64_t)s * Mp * Mp + idx];
+  out[idx] = accum ? fma(alpha, v, out[idx]) : alpha * v;
+}
+template <int AL, int BL, class Gen>
+static int run_gemm_sk_tiles(zigp_ctx* c, DevBuf& planes, const std::string& key, Gen gen, const double* A, const double* B, double* C, int64_t Mp, double alpha,
+                             bool accum = false) {
+  std::vector<GemmTile> base;
+  gen(base);
+  if (base.empty()) return 0;
+  int minlen = 1 << 30;
+  for (const GemmTile& t : base) minlen = std::min(minlen, t.kend - t.kbeg);
+  const int count = (int)base.size(), S = std::max(1, std::min(std::min(8, minlen), 512 / count));
+  TileList tl;
+  ZIGP_TRY(get_tiles(c, "skt:" + key + ":" + std::to_string(S), [&](std::vector<GemmTile>& v) {
+    for (int s = 0; s < S; ++s)
+      for (const GemmTile& t : base) {
+        const int len = t.kend - t.kbeg;
+        v.push_back(mk_tile(t.bi, t.bj, t.kbeg + (int)((int64_t)len * s / S), t.kbeg + (int)((int64_t)len * (s + 1) / S), s));
+      }
+  }, tl));
+  ZIGP_ENSURE(c, planes, (size_t)S * Mp * Mp);
+  GemmArgs g = mk_args(A, Mp, B, Mp, planes.p, Mp);
+  g.slice_stride = Mp * Mp;
+  ZIGP_TRY((run_gemm<AL, BL, false>(c, tl, g, EpiStore())));
+  hipLaunchKernelGGL(k_sk_finish_tiles, dim3(64 * count), dim3(256), 0, c->stream, planes.p, tl.d, S, Mp, alpha, accum ? 1 : 0, C);
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+
+// prepared: the caller has zeroed W and the strictly-upper blocks of L already (k_kuu_setup writes both next to Kuu); planes: buffer for
+// the split-K block products of the inverse (nullptr: plain launches, one workgroup per tile)
+struct PotrfJob { double* L; double* W; double* T; int Mp; bool want_W; int Mreal; double piv_tol; bool prepared; DevBuf* planes; };
 static int potrf_trtri_jobs(zigp_ctx* c, int njobs, const PotrfJob* jobs, const hipStream_t* streams) {
   hipStream_t const saved = c->stream;
   struct Restore { zigp_ctx* c; hipStream_t s; ~Restore() { c->stream = s; } } restore{c, saved};
@@ -275,6 +316,7 @@ static int potrf_trtri_jobs(zigp_ctx* c, int njobs, const PotrfJob* jobs, const 
   for (int q = 0; q < njobs; ++q) nbmax = std::max(nbmax, jobs[q].Mp / BM);
   // c->d_info is cleared by the caller (several factorizations may share one check_info)
   for (int q = 0; q < njobs; ++q) {
+    if (jobs[q].prepared) continue;
     c->stream = streams[q];
     ZIGP_HIP(c, hipMemsetAsync(jobs[q].W, 0, sizeof(double) * jobs[q].Mp * jobs[q].Mp, c->stream));
   }
@@ -293,19 +335,25 @@ static int potrf_trtri_jobs(zigp_ctx* c, int njobs, const PotrfJob* jobs, const 
           hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(1024), shm, c->stream, Ajj, Ajj, Wjj, (int64_t)Mp, j * BM, c->d_info, (nreal_j + PNB - 1) / PNB, J.piv_tol);
           ZIGP_HIP(c, hipGetLastError());
         } else if (j + 1 < nb && step == 1) {
-          TileList tp;
-          ZIGP_TRY(get_tiles(c, "po_p:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
+          auto genp = [&](std::vector<GemmTile>& v) {
             for (int bi = j + 1; bi < nb; ++bi) v.push_back(mk_tile(bi, j, j * kb, (j + 1) * kb));
-          }, tp));
+          };
+          const std::string tag = "po_p:" + std::to_string(nb) + ":" + std::to_string(j);
           // L[bi][j] = A[bi][j] * W_jj^T   (in place: each tile reads only itself and W_jj)
+          if (J.planes) { ZIGP_TRY((run_gemm_sk_tiles<LAY_KCONTIG, LAY_KCONTIG>(c, *J.planes, tag, genp, Lb, Wb, Lb, Mp, 1.0))); continue; }
+          TileList tp;
+          ZIGP_TRY(get_tiles(c, tag, genp, tp));
           ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, tp, mk_args(Lb, Mp, Wb, Mp, Lb, Mp), EpiStore())));
         } else if (j + 1 < nb && step == 2) {
-          TileList ts;
-          ZIGP_TRY(get_tiles(c, "po_s:" + std::to_string(nb) + ":" + std::to_string(j), [&](std::vector<GemmTile>& v) {
+          auto gens = [&](std::vector<GemmTile>& v) {
             for (int bi = j + 1; bi < nb; ++bi)
               for (int bj = j + 1; bj <= bi; ++bj) v.push_back(mk_tile(bi, bj, j * kb, (j + 1) * kb));
-          }, ts));
+          };
+          const std::string tag = "po_s:" + std::to_string(nb) + ":" + std::to_string(j);
           // A[bi][bj] -= L[bi][j] L[bj][j]^T
+          if (J.planes) { ZIGP_TRY((run_gemm_sk_tiles<LAY_KCONTIG, LAY_KCONTIG>(c, *J.planes, tag, gens, Lb, Lb, Lb, Mp, -1.0, true))); continue; }
+          TileList ts;
+          ZIGP_TRY(get_tiles(c, tag, gens, ts));
           ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_KCONTIG, false>(c, ts, mk_args(Lb, Mp, Lb, Mp, Lb, Mp, -1.0), EpiAccum())));
         }
       }
@@ -314,7 +362,7 @@ static int potrf_trtri_jobs(zigp_ctx* c, int njobs, const PotrfJob* jobs, const 
   for (int bi = 0; bi + 1 < nbmax; ++bi)
     for (int q = 0; q < njobs; ++q) {
       const int Mp = jobs[q].Mp, nb = Mp / BM;
-      if (bi + 1 >= nb) continue;
+      if (bi + 1 >= nb || jobs[q].prepared) continue;
       c->stream = streams[q];
       ZIGP_HIP(c, hipMemset2DAsync(jobs[q].L + (int64_t)bi * BM * Mp + (int64_t)(bi + 1) * BM, sizeof(double) * Mp, 0,
                                    sizeof(double) * (size_t)(Mp - (bi + 1) * BM), BM, c->stream));
@@ -327,34 +375,39 @@ static int potrf_trtri_jobs(zigp_ctx* c, int njobs, const PotrfJob* jobs, const 
         const int Mp = J.Mp, nb = Mp / BM;
         if (!J.want_W || b >= nb) continue;
         c->stream = streams[q];
-        if (step == 0) {
+        auto gen1 = [&](std::vector<GemmTile>& v) {
+          for (int lo = 0; lo < nb; lo += 2 * b) {
+            const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
+            if (mid >= nb) continue;
+            for (int bi = mid; bi < hi; ++bi)
+              for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, mid * kb));
+          }
+        };
+        auto gen2 = [&](std::vector<GemmTile>& v) {
+          for (int lo = 0; lo < nb; lo += 2 * b) {
+            const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
+            if (mid >= nb) continue;
+            for (int bi = mid; bi < hi; ++bi)
+              for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, mid * kb, (bi + 1) * kb));
+          }
+        };
+        const std::string tag = std::to_string(nb) + ":" + std::to_string(b);
+        if (step == 0) {          // T = L21 W11
+          if (J.planes) { ZIGP_TRY((run_gemm_sk_tiles<LAY_KCONTIG, LAY_MNCONTIG>(c, *J.planes, "tri1:" + tag, gen1, J.L, J.W, J.T, Mp, 1.0))); continue; }
           TileList t1;
-          ZIGP_TRY(get_tiles(c, "tri1:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
-            for (int lo = 0; lo < nb; lo += 2 * b) {
-              const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
-              if (mid >= nb) continue;
-              for (int bi = mid; bi < hi; ++bi)
-                for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, bj * kb, mid * kb));
-            }
-          }, t1));
+          ZIGP_TRY(get_tiles(c, "tri1:" + tag, gen1, t1));
           ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t1, mk_args(J.L, Mp, J.W, Mp, J.T, Mp), EpiStore())));
-        } else {
+        } else {                  // W21 = -W22 T
+          if (J.planes) { ZIGP_TRY((run_gemm_sk_tiles<LAY_KCONTIG, LAY_MNCONTIG>(c, *J.planes, "tri2:" + tag, gen2, J.W, J.T, J.W, Mp, -1.0))); continue; }
           TileList t2;
-          ZIGP_TRY(get_tiles(c, "tri2:" + std::to_string(nb) + ":" + std::to_string(b), [&](std::vector<GemmTile>& v) {
-            for (int lo = 0; lo < nb; lo += 2 * b) {
-              const int mid = lo + b, hi = std::min(lo + 2 * b, nb);
-              if (mid >= nb) continue;
-              for (int bi = mid; bi < hi; ++bi)
-                for (int bj = lo; bj < mid; ++bj) v.push_back(mk_tile(bi, bj, mid * kb, (bi + 1) * kb));
-            }
-          }, t2));
+          ZIGP_TRY(get_tiles(c, "tri2:" + tag, gen2, t2));
           ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false>(c, t2, mk_args(J.W, Mp, J.T, Mp, J.W, Mp, -1.0), EpiStore())));
         }
       }
   return 0;
 }
 static int potrf_trtri(zigp_ctx* c, double* Lb, double* Wb, double* Tb, int Mp, bool want_W, int Mreal = -1, double piv_tol = 0.0) {
-  const PotrfJob job = {Lb, Wb, Tb, Mp, want_W, Mreal, piv_tol};
+  const PotrfJob job = {Lb, Wb, Tb, Mp, want_W, Mreal, piv_tol, false, nullptr};
   const hipStream_t st = c->stream;
   return potrf_trtri_jobs(c, 1, &job, &st);
 }

@@ -67,6 +67,31 @@ __global__ void k_rbf_matrix(const double* __restrict__ X1, int64_t n1, const do
   out[i * ld + j] = v;
 }
 
+// Kuu of the M x M forward (k_rbf_matrix with X1 = X2 = Z, same expression) together with everything the factorisation chain wants next to
+// it, in ONE launch: the working copy L = Kuu with its strictly-upper 128-blocks zero (the chain factors in place and never reads them;
+// potrf_trtri_jobs otherwise clears them block row by block row afterwards: 7 memsets at M = 1024), W = 0, and s2 = s^2.
+__global__ void k_kuu_setup(const double* __restrict__ Z, int64_t M, KernHyp h, double jitter, double* __restrict__ Kuu, double* __restrict__ L,
+                            double* __restrict__ W, const double* __restrict__ s, double* __restrict__ s2, int64_t Mp) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mp * Mp) return;
+  if (idx < Mp) s2[idx] = s[idx] * s[idx];
+  int64_t i = idx / Mp, j = idx - i * Mp;
+  double v;
+  if (i < M && j < M) {
+    double r2 = 0.0;
+    for (int d = 0; d < h.D; ++d) {
+      double t = (Z[i * h.D + d] - Z[j * h.D + d]) * h.inv_ell[d];
+      r2 = fma(t, t, r2);
+    }
+    v = h.var * exp(-0.5 * r2) + ((i == j) ? jitter : 0.0);
+  } else {
+    v = (i == j) ? 1.0 : 0.0;
+  }
+  Kuu[idx] = v;
+  L[idx] = (j / 128 > i / 128) ? 0.0 : v;
+  W[idx] = 0.0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Kuf panel for one chunk: K[m][n] = var*exp(-0.5*|(z_m - x_n)/ell|^2), m < M ; 0 for padded rows.
 // (kern.K(X, Xnew), onofftf/main.py:266.)  grid (Nc/512, Mp/16); thread = two adjacent columns, 16 rows.
