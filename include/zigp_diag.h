@@ -45,8 +45,9 @@ int zigp_set_kron_range_tiles(zigp_ctx* ctx, int32_t tiles);
 /* C (m,n) = op(A) * op(B) with the fp64 MFMA GEMM core; transA/transB as BLAS; all dims padded internally. */
 int zigp_test_gemm(zigp_ctx* ctx, int32_t transA, int32_t transB, int64_t m, int64_t n, int64_t k,
                    const double* A, const double* B, double* C);
-/* L = chol(A) (lower), W = L^-1, A is (n,n) SPD; either output may be NULL. */
-int zigp_test_potrf_trtri(zigp_ctx* ctx, int64_t n, const double* A, double* L, double* W);
+/* L = chol(A) (lower), W = L^-1, A is (n,n) SPD; either output may be NULL.  split_k != 0: the blocked chain's products run as k slices +
+ * an ordered reduction, as in the M x M forward of zigp_elbo (0: one workgroup per tile, as in the Kronecker panel path). */
+int zigp_test_potrf_trtri(zigp_ctx* ctx, int64_t n, const double* A, double* L, double* W, int32_t split_k);
 
 #ifdef __cplusplus
 }

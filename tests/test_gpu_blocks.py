@@ -25,13 +25,14 @@ def test_gemm_layouts(engine, ta, tb, m, n, k):
     assert np.array_equal(Ci, (Ai.T if ta else Ai) @ (Bi.T if tb else Bi))
 
 
-@pytest.mark.parametrize('n', [1, 9, 31, 32, 33, 50, 64, 65, 96, 97, 100, 127, 128, 129, 200, 512, 1024])   # every panel count and boundary of the blocked factorisation
-def test_potrf_trtri(engine, n):
+@pytest.mark.parametrize('split_k', [False, True])   # one workgroup per tile (Kronecker panel path) / k slices + ordered reduction (dense M x M forward)
+@pytest.mark.parametrize('n', [1, 9, 31, 32, 33, 50, 64, 65, 96, 97, 100, 127, 128, 129, 200, 512, 640, 1024])   # every panel count and boundary of the blocked factorisation
+def test_potrf_trtri(engine, n, split_k):
     rs = np.random.RandomState(n)
     Z = rs.rand(n, 3)
     d2 = ((Z[:, None, :] - Z[None, :, :]) ** 2).sum(-1)
     A = np.exp(-0.5 * d2 / 0.1 ** 2) + 1e-6 * np.eye(n)
-    L, W = engine.test_potrf_trtri(A)
+    L, W = engine.test_potrf_trtri(A, split_k)
     Lr = sl.cholesky(A, lower=True)
     assert np.all(np.triu(L, 1) == 0) and np.all(np.triu(W, 1) == 0)
     assert relerr(L @ L.T, A) < 1e-13

@@ -87,7 +87,10 @@ struct zigp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;    // stream every launch helper enqueues on (swapped to stream2 inside a TwoStream section)
   hipStream_t stream_main = nullptr, stream2 = nullptr;
+  hipStream_t stream3 = nullptr;   // dense path: buffers, zeroed accumulators and the first chunk's Kuf panels, under the M x M forward of both latents
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_prep_fork = nullptr, ev_prep = nullptr, ev_kuf = nullptr;
+  bool jp_wait = false;            // the next J' launch waits for ev_join first: the previous chunk's Kuf-cotangent kernels still read J' (dense_chunk_loop)
   std::string err;
   int info = 0;
   int64_t chunk = 32768;

@@ -173,6 +173,7 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
 #endif
     }
     {
+      if (c->jp_wait) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); c->jp_wait = false; }   // the previous chunk's kgrads read J' (dense_chunk_loop)
       ProfScope ps(c, PC_GEMM_J, fl);   // J' = W^T H - A2
       ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu_lpt, mk_args(lt.W.p, Mp, lt.H.p, Nc, lt.Jp.p, Nc), EpiSubLoad{lt.A2.p})));
     }
@@ -311,13 +312,30 @@ struct DenseCall {
   int64_t Nc = 0;         // rows per full chunk
   int pw_blocks = 0;
   int* hinfo = nullptr;   // Cholesky status, staged with the other results
+  bool prep_side = false; // buffers / zeroed accumulators / first Kuf panels were issued on the third stream (dense_mxm_forward)
 };
 
 // Parameters to the device, then the MxM forward of f on the main stream and of g on stream2 (dozens of small dependent launches each)
+int dense_prepare_buffers(zigp_ctx* c, DenseCall& k);
+int64_t dense_first_chunk_rows(const DenseCall& k) { return std::min<int64_t>(k.Nc, round_up(k.row_end - k.row_begin, 1024)); }
 int dense_mxm_forward(zigp_ctx* c, DenseCall& k) {
   ZIGP_TRY(begin_staged_call(c));
   ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
   ZIGP_TRY(latents_upload(c, k.hl, k.D));
+  // The call's buffers, its zeroed accumulators and the first chunk's Kuf panels need the uploaded parameters only: third stream, under
+  // the two factorisation chains (which are dependent launches of <= 36 workgroups).  Not while kernels are being timed (they run alone).
+  k.prep_side = c->overlap == 1 && !c->prof_on;
+  if (k.prep_side) {
+    struct Guard { zigp_ctx* c; ~Guard() { c->stream = c->stream_main; } } guard{c};
+    ZIGP_HIP(c, hipEventRecord(c->ev_prep_fork, c->stream_main));
+    ZIGP_HIP(c, hipStreamWaitEvent(c->stream3, c->ev_prep_fork, 0));
+    c->stream = c->stream3;
+    ZIGP_TRY(dense_prepare_buffers(c, k));
+    if (k.has_rows)
+      for (int h = 0; h < 2; ++h)
+        ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, k.row_begin, dense_first_chunk_rows(k), k.D, k.ell_h[h]));
+    ZIGP_HIP(c, hipEventRecord(c->ev_prep, c->stream3));
+  }
   {
     ProfScope ps(c, PC_MXM);     // wall time of the two concurrent chains: both events on the main stream, the second after the join
     TwoStream ts(c);
@@ -421,14 +439,22 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
   struct SideGuard { zigp_ctx* c; ~SideGuard() { c->stream = c->stream_main; c->prof_skip = false; } } side_guard{c};
   bool side_busy = false;
   c->prof_skip = c->prof_on && !sampled(row_begin);
-  for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, row_begin, chunk_rows(row_begin), D, k.ell_h[h]));
+  if (!k.prep_side)     // (otherwise built on the third stream under the M x M forward: dense_mxm_forward)
+    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, row_begin, chunk_rows(row_begin), D, k.ell_h[h]));
+  bool kuf_split = false;     // the side stream built the next chunk's Kuf panels BEFORE this chunk's kgrads (ev_kuf, then ev_join)
   for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc_full) {
     const int64_t Nc = chunk_rows(n0);   // the last (partial) chunk shrinks to the next multiple of 1024 rows
     const int64_t n1 = n0 + Nc_full;
     const bool has_next = n1 < row_end;
     const bool timed = sampled(n0), timed_next = has_next && sampled(n1);
     c->prof_skip = c->prof_on && !timed;
-    if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
+    if (side_busy) {
+      // A1 of this chunk needs the Kuf panels; the previous chunk's kgrads (they read J' and gm) only have to be done before this
+      // chunk's first J' launch (latent_chunk_forward consumes jp_wait)
+      if (kuf_split) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_kuf, 0)); c->jp_wait = true; }
+      else ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0));
+      side_busy = false; kuf_split = false;
+    }
     for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], Nc, k.need_grad));
     ZIGP_TRY(dense_pointwise(c, k, n0, Nc));
     // side work of this chunk: its kgrads and the next chunk's Kuf panels (gradient mode only: without the SYRKs there is
@@ -439,8 +465,20 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
       ZIGP_HIP(c, hipEventRecord(c->ev_fork, c->stream_main));
       ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
       c->stream = c->stream2;
+      // ZIGP_KUF_FIRST (measured, off): the panels first (K is read by A1 only; kgrad recomputes it), because at M = 512 the two kgrads outlast
+      // the two rank-N updates and the next chunk's first product waits 160 us for panels queued behind them.  But a side kernel gets few
+      // workgroup slots beside a rank-N update: the two panel builds then take 260 us each instead of 43, the kgrads slide under the next
+      // chunk's A1 and slow it by 170 us -- cfg2 6.43 -> 6.54 ms.
+#ifndef ZIGP_KUF_FIRST
+#define ZIGP_KUF_FIRST 0
+#endif
+      kuf_split = (ZIGP_KUF_FIRST != 0) && kuf_side && (ZIGP_KGRAD_RECOMPUTE != 0);
+      if (kuf_split) {
+        for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]));
+        ZIGP_HIP(c, hipEventRecord(c->ev_kuf, c->stream2));
+      }
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], k.dX, k.Nrows, n0, Nc, D, k.ell_h[h]));
-      if (kuf_side)
+      if (kuf_side && !kuf_split)
         for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]));
       ZIGP_HIP(c, hipEventRecord(c->ev_join, c->stream2));
       side_busy = true;
@@ -452,13 +490,13 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_syrk(c, c->lat[h], Nc));
     }
     if (has_next && !kuf_side) {   // a timed next chunk gets its panels from the main stream, with the side stream drained
-      if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
+      if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; kuf_split = false; }
       c->prof_skip = c->prof_on && !timed_next;
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]));
     }
   }
   if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
-  c->prof_skip = false;
+  c->prof_skip = false; c->jp_wait = false;
   return 0;
 }
 
@@ -523,7 +561,8 @@ int run_dense(zigp_ctx* c, const zigp_params* p, const double* dX, const double*
   k.hl[1] = HostLatent{p->Mg, p->Zg, p->u_gm, p->u_gs_sqrt, p->ell_g, p->var_g};
   k.ell_h[0] = p->ell_f; k.ell_h[1] = p->ell_g;
   ZIGP_TRY(dense_mxm_forward(c, k));
-  ZIGP_TRY(dense_prepare_buffers(c, k));
+  if (k.prep_side) ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_prep, 0));
+  else ZIGP_TRY(dense_prepare_buffers(c, k));
   ZIGP_TRY(dense_chunk_loop(c, k));
   if (predict) { ZIGP_HIP(c, hipStreamSynchronize(c->stream)); prof_collect(c); return info_result(c, k.hinfo, "Kuu"); }
   if (k.need_grad) {
@@ -559,8 +598,12 @@ int zigp_create(zigp_ctx** out, int device_id) {
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZIGP_EHIP; }
   c->stream_main = c->stream;
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return ZIGP_EHIP; }
+  if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return ZIGP_EHIP; }
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_prep_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_kuf, hipEventDisableTiming) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipMalloc((void**)&c->d_info, sizeof(int)) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(sizeof(double) * PB * PBLD)) != hipSuccess) { delete c; return ZIGP_EHIP; }
@@ -574,6 +617,7 @@ int zigp_destroy(zigp_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream_main);
   (void)hipStreamSynchronize(c->stream2);
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->comm) { RcclApi* api = rccl_api(nullptr); if (api) (void)api->CommDestroy(static_cast<ncclComm_t>(c->comm)); c->comm = nullptr; }
   for (int h = 0; h < 2; ++h) {
     Latent& l = c->lat[h];
@@ -591,6 +635,10 @@ int zigp_destroy(zigp_ctx* c) {
   c->pinned.release();
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_prep_fork) (void)hipEventDestroy(c->ev_prep_fork);
+  if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+  if (c->ev_kuf) (void)hipEventDestroy(c->ev_kuf);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream_main) (void)hipStreamDestroy(c->stream_main);
   delete c;
@@ -859,7 +907,7 @@ int zigp_test_gemm(zigp_ctx* c, int32_t transA, int32_t transB, int64_t m, int64
   return ZIGP_OK;
 }
 
-int zigp_test_potrf_trtri(zigp_ctx* c, int64_t n, const double* A, double* L, double* W) {
+int zigp_test_potrf_trtri(zigp_ctx* c, int64_t n, const double* A, double* L, double* W, int32_t split_k) {
   if (!c) return ZIGP_EARG;
   if (n <= 0 || !A) return fail_arg(c, "zigp_test_potrf_trtri: bad arguments");
   ZIGP_HIP(c, hipSetDevice(c->device));
@@ -869,12 +917,16 @@ int zigp_test_potrf_trtri(zigp_ctx* c, int64_t n, const double* A, double* L, do
     if (i < n) memcpy(&ha[i * Mp], &A[i * n], sizeof(double) * n);
     else ha[i * Mp + i] = 1.0;
   }
-  DevBuf dl, dw, dt;
+  DevBuf dl, dw, dt, dplanes;
   auto body = [&]() -> int {
     ZIGP_ENSURE(c, dl, ha.size()); ZIGP_ENSURE(c, dw, ha.size()); ZIGP_ENSURE(c, dt, ha.size());
     ZIGP_HIP(c, hipMemcpyAsync(dl.p, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice, c->stream));
     ZIGP_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
-    ZIGP_TRY(potrf_trtri(c, dl.p, dw.p, dt.p, Mp, true, (int)n));
+    if (split_k) {     // the chain as the dense M x M forward runs it: every block product cut into k slices (run_gemm_sk_tiles)
+      const PotrfJob job = {dl.p, dw.p, dt.p, Mp, true, (int)n, 0.0, false, &dplanes};
+      const hipStream_t st = c->stream;
+      ZIGP_TRY(potrf_trtri_jobs(c, 1, &job, &st));
+    } else ZIGP_TRY(potrf_trtri(c, dl.p, dw.p, dt.p, Mp, true, (int)n));
     ZIGP_TRY(check_info(c, "A"));
     std::vector<double> ho(ha.size());
     if (L) {
@@ -890,7 +942,7 @@ int zigp_test_potrf_trtri(zigp_ctx* c, int64_t n, const double* A, double* L, do
     return 0;
   };
   int rc = body();
-  dl.release(); dw.release(); dt.release();
+  dl.release(); dw.release(); dt.release(); dplanes.release();
   return rc;
 }
 

@@ -485,6 +485,8 @@ static inline KernHyp make_hyp(const double* ell, double var, int D) {
 static int begin_staged_call(zigp_ctx* c) {
   ZIGP_HIP(c, hipStreamSynchronize(c->stream_main));
   ZIGP_HIP(c, hipStreamSynchronize(c->stream2));
+  ZIGP_HIP(c, hipStreamSynchronize(c->stream3));
+  c->jp_wait = false;
   c->pinned.reset();
   return 0;
 }

@@ -281,7 +281,10 @@ k_pointwise(PwArgs p) {
 // (reverse of KernSE.K, onofftf/main.py:41-57)
 // ---------------------------------------------------------------------------------------------
 constexpr int KG_ROWS = 4;
-constexpr int KG_SPLIT = 4;   // column splits (blockIdx.y); each split accumulates into its own krow slab [KG_SPLIT][Mp][W]
+#ifndef ZIGP_KG_SPLIT
+#define ZIGP_KG_SPLIT 4
+#endif
+constexpr int KG_SPLIT = ZIGP_KG_SPLIT;   // column splits (blockIdx.y); each split accumulates into its own krow slab [KG_SPLIT][Mp][W]
 // ZIGP_KGRAD_RECOMPUTE (default): K[m,n] is recomputed from x_n and z_m (the expression of k_kuf_build, bit for bit) instead of read
 // back: half the HBM bytes (0.27 instead of 0.54 GB per chunk and latent) for 8.1 instead of 7.2 ms of kernel time per step when it runs
 // alone -- with the side-stream overlap (zigp_set_overlap, what bench.py times) the step is 0.3 % shorter (profiles/r03a_ab_kgrad.log).

@@ -578,9 +578,9 @@ class DenseEngine:
         _check(self.lib, self.ctx, self.lib.zigp_test_gemm(self.ctx, int(transA), int(transB), m, n, k, ptr(A), ptr(B), ptr(out)))
         return out
 
-    def test_potrf_trtri(self, A):
+    def test_potrf_trtri(self, A, split_k=False):
         A = as_f64(A)
         n = A.shape[0]
         L, W = np.zeros((n, n)), np.zeros((n, n))
-        _check(self.lib, self.ctx, self.lib.zigp_test_potrf_trtri(self.ctx, n, ptr(A), ptr(L), ptr(W)))
+        _check(self.lib, self.ctx, self.lib.zigp_test_potrf_trtri(self.ctx, n, ptr(A), ptr(L), ptr(W), int(bool(split_k))))
         return L, W
