@@ -288,6 +288,9 @@ constexpr int KG_SPLIT = ZIGP_KG_SPLIT;   // column splits (blockIdx.y); each sp
 // ZIGP_KGRAD_RECOMPUTE (default): K[m,n] is recomputed from x_n and z_m (the expression of k_kuf_build, bit for bit) instead of read
 // back: half the HBM bytes (0.27 instead of 0.54 GB per chunk and latent) for 8.1 instead of 7.2 ms of kernel time per step when it runs
 // alone -- with the side-stream overlap (zigp_set_overlap, what bench.py times) the step is 0.3 % shorter (profiles/r03a_ab_kgrad.log).
+// r4, re-measured on the 16x16x4 core (profiles/r04ai_ab_kgread.log, two boxes): reading K is now 0.0-0.6 % FASTER per step (173.1-174.6 vs
+// 174.5-174.7 ms) -- within what two boxes differ by, so the default stays; two columns per thread with 16-byte loads changes nothing
+// (7.13 vs 7.17 ms alone = 4.6 TB/s).
 // r3, measured and dropped: a 1-row x 2-column version of 69 VGPRs, meant to sit beside the two rank-N-update workgroups of a CU (which
 // leave 112 registers per lane; this kernel holds 150): 9.4 ms alone and no better overlapped (185.0 vs 184.5 ms/step, r03e_overlap.log).
 #ifndef ZIGP_KGRAD_RECOMPUTE
