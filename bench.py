@@ -479,7 +479,7 @@ def main():
         })
         if prof is not None:
             from zigp._lib import PROF_KERNELS
-            gemm_classes = ('gemm_A1', 'gemm_A2', 'gemm_H', 'gemm_J', 'syrk')
+            gemm_classes = tuple(k for k in ('gemm_A1', 'gemm_A2', 'gemm_H', 'gemm_J', 'syrk') if prof[k]['launches'] > 0)   # (H: folded into J' since round 4)
             dom = max(gemm_classes, key=lambda k: prof[k]['ms'])          # dominant kernel = largest share of the step
             gk = prof[dom]
             avg_launch_s = gk['ms'] * 1e-3 / max(gk['launches'], 1)

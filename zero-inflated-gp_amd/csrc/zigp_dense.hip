@@ -23,6 +23,10 @@
 
 using namespace zigp;
 
+// ZIGP_J_QFORM (round 4): the gradient step's H and J' panels as one full product with Q = Kuu^-1 diag(s^2) - I (latent_chunk_forward)
+#ifndef ZIGP_J_QFORM
+#define ZIGP_J_QFORM 1
+#endif
 namespace {
 
 struct HostLatent {
@@ -71,6 +75,7 @@ int latents_upload(zigp_ctx* c, const HostLatent (&hl)[2], int D) {
     ZIGP_ENSURE(c, lt.Wp, Mp * Mp);
     ZIGP_ENSURE(c, lt.Wt, Mp * Mp);
     ZIGP_ENSURE(c, lt.Wpt, Mp * Mp);
+    ZIGP_ENSURE(c, lt.P, Mp * Mp); ZIGP_ENSURE(c, lt.Qt, Mp * Mp);
   }
   return 0;
 }
@@ -99,11 +104,12 @@ int latents_forward(zigp_ctx* c, const HostLatent (&hl)[2], int D, double jitter
     }
     ZIGP_TRY(potrf_trtri_jobs(c, 2, jobs, st));
   }
-  for (int step = 0; step < 5; ++step)
+  for (int step = 0; step < 7; ++step)
     for (int h = 0; h < 2; ++h) {
       Latent& lt = c->lat[h];
       const int Mp = lt.Mp;
       c->stream = st[h];
+      if (step == 0) lt.P_ready = false;
       double* v = lt.vec.p; double* alpha = v + Mp; double* dkinv = v + 2 * Mp; double* klv = v + 3 * Mp;
       switch (step) {
 #if ZIGP_LOWER_VIA_WT
@@ -115,9 +121,22 @@ int latents_forward(zigp_ctx* c, const HostLatent (&hl)[2], int D, double jitter
         case 1: if (with_kl) hipLaunchKernelGGL(k_gemv_rows, dim3(Mp), dim3(256), 0, c->stream, lt.W.p, lt.u.p, (int64_t)Mp, v); break;
         case 2: if (with_kl) hipLaunchKernelGGL(k_kl_cols, dim3(Mp / 64), dim3(64, COL_LANES), 0, c->stream, lt.W.p, v, (int64_t)Mp, alpha, dkinv); break;
         case 3: if (with_kl) hipLaunchKernelGGL(k_kl_value, dim3(1), dim3(256), 0, c->stream, v, lt.L.p, lt.s.p, dkinv, lt.M, (int64_t)Mp, klv); break;
-        case 4:   // W' = W diag(s^2) (operand of H = W' A2)
+        case 4:   // W' = W diag(s^2) (operand of H = W' A2 and of the reverse M x M stage)
           if (need_grad) hipLaunchKernelGGL(k_colscale, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.W.p, lt.s2.p, (int64_t)Mp, lt.Wp.p);
           break;
+#if ZIGP_J_QFORM
+        case 5:   // P = W^T W = Kuu^-1 (the reverse M x M stage needs it anyway and takes it from here)
+          if (need_grad) {
+            const int nb = Mp / BM, kb = BM / BK;
+            ZIGP_TRY((run_gemm_sk<LAY_MNCONTIG, LAY_MNCONTIG>(c, lt.sk, "s", nb, [&](int bi, int bj, int& k0, int& k1) { k0 = std::max(bi, bj) * kb; k1 = nb * kb; },
+                                                              lt.W.p, lt.W.p, lt.P.p, Mp, SK_STORE, 1.0, false)));
+            lt.P_ready = true;
+          }
+          break;
+        case 6:   // Q^T = diag(s^2) P - I: J' = W^T (W diag(s^2) A2) - A2 = (P diag(s^2) - I) A2 = Q A2 is ONE full product per chunk
+          if (need_grad) hipLaunchKernelGGL(k_rowscale_minus_eye, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.P.p, lt.s2.p, (int64_t)Mp, lt.Qt.p);
+          break;
+#endif
         default: break;
       }
       ZIGP_HIP(c, hipGetLastError());
@@ -163,6 +182,19 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
     EpiStoreColsum ep{nullptr, lt.s2.p, nullptr, lt.part.p + (size_t)2 * np * Nc};
     ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), ep)));
   }
+#if ZIGP_J_QFORM
+  if (need_grad) {
+    // J' = Q A2, Q = Kuu^-1 diag(s^2) - I (M x M, dense): the two triangular products H = W diag(s^2) A2, J' = W^T H - A2 as ONE full
+    // product of the same flop count -- every tile the full k range (no triangular padding, half as many prologues and epilogues per
+    // flop), no H panel written and read back, no operand tile in the epilogue.
+    TileList tf;
+    ZIGP_TRY(tiles_full_xcd(c, nbm, nbn, nbm * (BM / BK), tf));
+    ProfScope ps(c, PC_GEMM_J, 2.0 * fl);
+    if (c->jp_wait) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); c->jp_wait = false; }
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, tf, mk_args(lt.Qt.p, Mp, lt.A2.p, Nc, lt.Jp.p, Nc), EpiStore())));
+    return 0;
+  }
+#endif
   if (need_grad) {
     {
       ProfScope ps(c, PC_GEMM_H, fl);   // H = (W diag(s^2)) A2
@@ -269,15 +301,16 @@ int latent_mxm_backward(zigp_ctx* c, Latent& lt, int D, double jitter, bool with
     ZIGP_TRY((run_gemm_sk<LAY_MNCONTIG, LAY_MNCONTIG>(c, lt.sk, "s", nb, [&](int bi, int bj, int& k0, int& k1) { k0 = std::max(bi, bj) * kb; k1 = nb * kb; },
                                                       lt.W.p, lt.T3.p, lt.T1.p, Mp, SK_STORE, 1.0, false)));
   }
-  double* P = lt.T2.p; double* PSP = lt.G.p;
+  double* P = lt.P_ready ? lt.P.p : lt.T2.p; double* PSP = lt.G.p;
   if (with_kl) {
-    // P = W^T W -> T2
-    ZIGP_TRY((run_gemm_sk<LAY_MNCONTIG, LAY_MNCONTIG>(c, lt.sk, "s", nb, [&](int bi, int bj, int& k0, int& k1) { k0 = std::max(bi, bj) * kb; k1 = nb * kb; },
-                                                      lt.W.p, lt.W.p, lt.T2.p, Mp, SK_STORE, 1.0, false)));
+    // P = W^T W -> T2   (a gradient step has it from the forward stage: latents_forward)
+    if (!lt.P_ready)
+      ZIGP_TRY((run_gemm_sk<LAY_MNCONTIG, LAY_MNCONTIG>(c, lt.sk, "s", nb, [&](int bi, int bj, int& k0, int& k1) { k0 = std::max(bi, bj) * kb; k1 = nb * kb; },
+                                                        lt.W.p, lt.W.p, lt.T2.p, Mp, SK_STORE, 1.0, false)));
     // Ps = diag(s2) P -> T3 ; PSP = P Ps -> G
-    hipLaunchKernelGGL(k_rowscale, dim3(gridmm), dim3(256), 0, c->stream, lt.T2.p, lt.s2.p, (int64_t)Mp, lt.T3.p);
+    hipLaunchKernelGGL(k_rowscale, dim3(gridmm), dim3(256), 0, c->stream, P, lt.s2.p, (int64_t)Mp, lt.T3.p);
     ZIGP_TRY((run_gemm_sk<LAY_KCONTIG, LAY_MNCONTIG>(c, lt.sk, "full", nb, [&](int, int, int& k0, int& k1) { k0 = 0; k1 = nb * kb; },
-                                                     lt.T2.p, lt.T3.p, lt.G.p, Mp, SK_STORE, 1.0, false)));
+                                                     P, lt.T3.p, lt.G.p, Mp, SK_STORE, 1.0, false)));
   }
   // G = sym(S) - dKL/dKuu -> T3 (T3 free again)
   hipLaunchKernelGGL(k_sym_combine, dim3(gridmm), dim3(256), 0, c->stream, S, P, PSP, lt.vec.p + Mp, with_data ? 1 : 0, with_kl ? 1 : 0,
@@ -379,7 +412,7 @@ int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
     if (k.has_rows) {
       ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A2, (size_t)Mp * Nc);
       ZIGP_ENSURE(c, lt.part, (size_t)3 * (Mp / 32) * Nc);
-      if (k.need_grad) { ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc); }
+      if (k.need_grad) { if (!ZIGP_J_QFORM) ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc); }
     }
     if (k.need_grad) {
       ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)KG_SPLIT * Mp * (2 + 2 * D));
@@ -621,7 +654,7 @@ int zigp_destroy(zigp_ctx* c) {
   if (c->comm) { RcclApi* api = rccl_api(nullptr); if (api) (void)api->CommDestroy(static_cast<ncclComm_t>(c->comm)); c->comm = nullptr; }
   for (int h = 0; h < 2; ++h) {
     Latent& l = c->lat[h];
-    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.H, &l.Jp, &l.Wp, &l.Wt, &l.Wpt, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
+    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.H, &l.Jp, &l.Wp, &l.Wt, &l.Wpt, &l.P, &l.Qt, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
                     &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec, &l.sk};
     for (DevBuf* b : bs) b->release();
   }

@@ -129,8 +129,25 @@ struct EpiAccum {   // C += alpha*acc
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] += v; });
   }
 };
+// ZIGP_J_PREFETCH: the S tile of EpiSubLoad is touched (one 8-byte load per 64-byte segment of this wave's sub-tile, TM * TN / 2 per lane)
+// three staged steps before the tile's k loop ends, and the values are consumed one step later, behind the wait the next stage needs
+// anyway: the epilogue's loads then hit L2.  With the paired tile order all workgroups reach their epilogues together, and a burst of
+// loads from HBM in front of the stores is what made that order lose 4.5 % for J' (DESIGN section 5).
+#ifndef ZIGP_J_PREFETCH
+#define ZIGP_J_PREFETCH 1
+#endif
 struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
   const double* __restrict__ S;
+  static constexpr bool PREFETCH = ZIGP_J_PREFETCH != 0;
+  template <int TM, int TN>
+  __device__ __forceinline__ void prefetch(const EpiCtx& e, double (&v)[TM * TN / 2]) const {
+    constexpr int SEGS = TN * 2;                     // 64-byte segments per row of the sub-tile
+#pragma unroll
+    for (int q = 0; q < TM * TN / 2; ++q) {
+      const int sidx = e.lane + 64 * q, row = sidx / SEGS, seg = sidx % SEGS;
+      v[q] = S[(e.row0 + row) * e.ldc + e.col0 + seg * 8];
+    }
+  }
   template <int TM, int TN>
   __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const {
     double* __restrict__ C = e.C; const int64_t ld = e.ldc; const double* __restrict__ Sp = S;
@@ -251,6 +268,9 @@ __device__ __forceinline__ int a_read_off(const int (&a_base)[4], int tm, int r,
   return a_base[0] + ks * 4 * LDMN + tm * 16 + 4 * r;
 }
 
+// does this epilogue want its extra operand tile touched ahead of time (EpiSubLoad::PREFETCH)?
+template <class E> constexpr auto epi_prefetches(int) -> decltype(E::PREFETCH) { return E::PREFETCH; }
+template <class E> constexpr bool epi_prefetches(long) { return false; }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // TRI: triangular structure exploited at wave granularity inside diagonal blocks (64 rows in the 4-wave, 32 rows in the 8-wave shape).
@@ -439,6 +459,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
     for (int b = 0; b < TNW; ++b)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.0;
+  constexpr bool EPI_PF = epi_prefetches<Epi>(0);
+  double pfv[TMW * TNW / 2];
+#pragma unroll
+  for (int q = 0; q < TMW * TNW / 2; ++q) pfv[q] = 0.0;
 
   const int total = tl.kend - tl.kbeg;       // BK steps of this tile
   const uint32_t offA = glds_lane_offset<ALAY, WAVES, A_NEWMAP>(sg.lda, wave, ln), offB = glds_lane_offset<BLAY, WAVES, false>(sg.ldb, wave, ln);
@@ -628,6 +652,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
   };
   for (int it = 0; it < total; ++it) {
     const double* As = stage_step(it);
+    if constexpr (EPI_PF) {
+      if (it == total - 2) {        // the touched values have landed with the stage just waited for: no extra stall
+#pragma unroll
+        for (int q = 0; q < TMW * TNW / 2; ++q) asm volatile("" ::"v"(pfv[q]));
+      }
+      if (it == total - 3) {
+        EpiCtx e;
+        e.C = nullptr; e.ldc = g.ldc; e.alpha = 0.0; e.row0 = row0 + wrow; e.col0 = col0 + wn * WTN; e.lane = ln; e.prow = 0;
+        epi.template prefetch<TMW, TNW>(e, pfv);
+      }
+    }
     // Triangular structure at wave granularity: a wave whose rows cannot touch this BK step of a triangular A, or whose whole 64x64
     // output lies above the diagonal of a lower-triangular C, issues no MFMAs (it still takes part in staging and barriers; the
     // co-resident workgroup gets the matrix pipe).

@@ -212,6 +212,20 @@ static int tiles_syr2k(zigp_ctx* c, int nbm, int nk, SyrPlan sp, TileList& tl) {
     }
   }, tl);
 }
+// Full product over column panels, for the chunk loop: panel bj goes to XCD bj % 8 (launch position p runs on XCD p % 8), its nbm row
+// blocks are consecutive entries of that XCD's queue -- they start together and walk the panel's k range in lockstep, so a panel's
+// slab is fetched into that L2 once.  All tiles have the same length: nbm * nbn tiles over the 512 resident workgroups.
+static int tiles_full_xcd(zigp_ctx* c, int nbm, int nbn, int nk, TileList& tl) {
+  return get_tiles(c, "fullx:" + std::to_string(nbm) + ":" + std::to_string(nbn) + ":" + std::to_string(nk), [&](std::vector<GemmTile>& v) {
+    std::vector<GemmTile> q[8];
+    for (int bj = 0; bj < nbn; ++bj)
+      for (int bi = 0; bi < nbm; ++bi) q[bj % 8].push_back(mk_tile(bi, bj, 0, nk));
+    size_t longest = 0;
+    for (int x = 0; x < 8; ++x) longest = std::max(longest, q[x].size());
+    for (size_t e = 0; e < longest; ++e)
+      for (int x = 0; x < 8; ++x) v.push_back(e < q[x].size() ? q[x][e] : mk_tile(0, 0, 0, 0));
+  }, tl);
+}
 static int tiles_full(zigp_ctx* c, int nbm, int nbn, int nk, TileList& tl) {
   return get_tiles(c, "full:" + std::to_string(nbm) + ":" + std::to_string(nbn) + ":" + std::to_string(nk), [&](std::vector<GemmTile>& v) {
     for (int bi = 0; bi < nbm; ++bi)

@@ -682,6 +682,13 @@ k_transpose_scale(const double* __restrict__ W, const double* __restrict__ s2, i
     if (Wpt) Wpt[o] = v * s2[bx + j];
   }
 }
+// Qt[k][i] = s2[k] * P[k][i] - (k == i):  Q^T for Q = P diag(s^2) - I (P symmetric)
+__global__ void k_rowscale_minus_eye(const double* __restrict__ P, const double* __restrict__ s2, int64_t Mp, double* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mp * Mp) return;
+  const int64_t k = idx / Mp;
+  out[idx] = fma(s2[k], P[idx], (idx - k * Mp == k) ? -1.0 : 0.0);
+}
 // Bs[k][j] = s2[k] * P[k][j]
 __global__ void k_rowscale(const double* __restrict__ P, const double* __restrict__ s2, int64_t Mp, double* __restrict__ out) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
