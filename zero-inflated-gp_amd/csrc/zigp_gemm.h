@@ -102,6 +102,7 @@ struct EpiCtx {
   int64_t row0, col0;   // first row / column of this wave's sub-tile (tm = 0, tn = 0)
   int64_t prow;         // index of this wave's partial row for the fused column sums (one per wave and row block)
   int lane;
+  int64_t tm_stride = 16;   // rows from sub-tile tm to tm + 1 (16: contiguous; the balanced triangular kernels own sub-tiles wm and 7 - wm)
 };
 template <int TM, int TN, class F>
 __device__ __forceinline__ void epi_foreach(const double (&acc)[TM][TN][4], const EpiCtx& e, F f) {
@@ -110,7 +111,7 @@ __device__ __forceinline__ void epi_foreach(const double (&acc)[TM][TN][4], cons
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t gi = e.row0 + tm * 16 + 4 * r + c_i;
+      const int64_t gi = e.row0 + tm * e.tm_stride + 4 * r + c_i;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) f(gi, e.col0 + tn * 16 + c_j, e.alpha * acc[tm][tn][r]);
     }
@@ -145,7 +146,7 @@ struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
 #pragma unroll
     for (int q = 0; q < TM * TN / 2; ++q) {
       const int sidx = e.lane + 64 * q, row = sidx / SEGS, seg = sidx % SEGS;
-      v[q] = S[(e.row0 + row) * e.ldc + e.col0 + seg * 8];
+      v[q] = S[(e.row0 + (row >> 4) * e.tm_stride + (row & 15)) * e.ldc + e.col0 + seg * 8];
     }
   }
   template <int TM, int TN>
@@ -174,7 +175,7 @@ struct EpiStoreColsum {
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t gi = e.row0 + tm * 16 + 4 * r + c_i;
+          const int64_t gi = e.row0 + tm * e.tm_stride + 4 * r + c_i;
           const double a1 = w1 ? w1[gi] : 0.0, a2 = w2 ? w2[gi] : 1.0;
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn) {
@@ -429,7 +430,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
   int ln = lane;
   asm volatile("" : "+v"(ln));
   const int a_i = ln & 3, kq = ln >> 4, b_j = ln & 15;
-  const int wrow = wm * RW;     // row (within the 128-row block) of this wave's sub-tile
+  // ZIGP_TRI_BALANCE: in the 8-wave triangular products wave (wm, wn) owns the 16-row sub-tiles wm and 7 - wm of the row block instead of
+  // the rows 32 wm .. 32 wm + 31.  Inside the DIAGONAL block of the triangular factor, sub-tile t needs the staged steps s <= t (lower) or
+  // s >= t (upper) only; with contiguous rows and skipping per wave, wave row 3 works through all 8 steps of that block while wave row 0
+  // idles after 2 -- a diagonal block costs the workgroup 8 step times for 62 % of the MFMAs.  With the pairs (t, 7 - t) every wave has
+  // 9 sub-tile steps there and the step times are 2,2,2,2,1,1,1,1 halves = 6 instead of 8 (tiles are 1-8 blocks long, one of them diagonal).
+#ifndef ZIGP_TRI_BALANCE
+#define ZIGP_TRI_BALANCE 1
+#endif
+  constexpr bool TRI_BAL = (ZIGP_TRI_BALANCE != 0) && M16 && WAVES == 8 && ALAY == LAY_MNCONTIG && (TRI == TRI_A_LOWER || TRI == TRI_A_UPPER);
+  const int wrow = TRI_BAL ? 16 * wm : wm * RW;     // row (within the 128-row block) of this wave's sub-tile tm = 0
+  const int tm_stride = TRI_BAL ? 16 * (7 - 2 * wm) : 16;   // rows from sub-tile tm = 0 to tm = 1
   // per-lane LDS read bases; the (tm, r, tn, ks) parts are compile-time offsets (see header comment)
   // k-contiguous A: granule = (2ks | kq>>1) ^ a_i ^ C(r), C(r) = 4(r&1) + (r>>1)  ->  [(2ks ^ C(r)) & ~3] is a compile-time
   // offset and the low two bits select one of four per-lane bases a_base[x] = ... + 2*((a_i ^ (kq>>1)) ^ x)
@@ -522,7 +533,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 #ifndef ZIGP_KK_PIPE
 #define ZIGP_KK_PIPE 0
 #endif
-  auto body = [&](const double* As) {
+  auto body = [&](const double* As, auto mask_c) {     // mask_c: which of the wave's sub-tile rows take part (bit tm; M16 form only)
+    constexpr int MASK = decltype(mask_c)::value;
     const double* Bs = As + TILE_DOUBLES;
     const int (&a_base)[4] = a_base_; const int (&b_base)[4] = b_base_;
     if constexpr (ZIGP_KK_PIPE != 0 && WAVES == 4 && ALAY == LAY_KCONTIG && BLAY == LAY_KCONTIG && KSCALE && TRI == TRI_C_LOWER) {
@@ -585,7 +597,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 #pragma unroll
         for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * (B_PAD ? 258 : 256) : tn * 16)];
 #pragma unroll
-        for (int tm = 0; tm < TMW; ++tm) af[tm] = As[a16_base[ks] + ((ALAY == LAY_KCONTIG) ? tm * (A_PAD ? 258 : 256) : tm * 16)];
+        for (int tm = 0; tm < TMW; ++tm)
+          if ((MASK >> tm) & 1) af[tm] = As[a16_base[ks] + ((ALAY == LAY_KCONTIG) ? tm * (A_PAD ? 258 : 256) : (TRI_BAL ? tm * tm_stride : tm * 16))];
         if (KSCALE) {
           const double sc = As[2 * TILE_DOUBLES + ks * 4 + kq];
 #pragma unroll
@@ -601,8 +614,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
         } else load(ks, afb[ks & 1], bfb[ks & 1]);
 #pragma unroll
         for (int tm = 0; tm < TMW; ++tm)
+          if ((MASK >> tm) & 1) {
 #pragma unroll
-          for (int tn = 0; tn < TNW; ++tn) mfma16(acc[tm][tn], afb[ks & 1][tm], bfb[ks & 1][tn]);
+            for (int tn = 0; tn < TNW; ++tn) mfma16(acc[tm][tn], afb[ks & 1][tm], bfb[ks & 1][tn]);
+          }
       }
       return;
     }
@@ -659,7 +674,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
       }
       if (it == total - 3) {
         EpiCtx e;
-        e.C = nullptr; e.ldc = g.ldc; e.alpha = 0.0; e.row0 = row0 + wrow; e.col0 = col0 + wn * WTN; e.lane = ln; e.prow = 0;
+        e.C = nullptr; e.ldc = g.ldc; e.alpha = 0.0; e.row0 = row0 + wrow; e.col0 = col0 + wn * WTN; e.lane = ln; e.prow = 0; e.tm_stride = tm_stride;
         epi.template prefetch<TMW, TNW>(e, pfv);
       }
     }
@@ -667,16 +682,33 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
     // output lies above the diagonal of a lower-triangular C, issues no MFMAs (it still takes part in staging and barriers; the
     // co-resident workgroup gets the matrix pipe).
     const int krel = (kb0 + (int)kd * it) * BK - tl.bi * BM;   // k offset of this step relative to the row block
-    bool skip = false;
-    if (TRI == TRI_A_LOWER) skip = krel > wm * RW + RW - 1;
-    if (TRI == TRI_A_UPPER) skip = krel + BK - 1 < wm * RW;
-    if (TRI == TRI_C_LOWER) skip = (tl.bi == tl.bj) && (wn * WTN > wm * RW + RW - 1);
-    if (!skip) body(As);
+    constexpr std::integral_constant<int, (1 << TMW) - 1> all_rows{};
+    if constexpr (TRI_BAL) {
+      static_assert(!TRI_BAL || (TMW == 2 && BK == 16), "balanced triangular kernels: two sub-tile rows per wave, one staged step per 16 k");
+      const int st = krel >> 4;       // staged step relative to the diagonal block (< 0: left of it, > 7: right of it)
+      // two independent `if`s, not if / else-if: with one conditional update of the accumulators per statement the compiler keeps them in
+      // place (as for the plain skip); an if / else-if of two different bodies made it copy all 64 accumulator registers per branch and spill
+      if (TRI == TRI_A_LOWER) {       // sub-tile t takes part while st <= t;  wm < 7 - wm
+        const bool both = st <= wm, one = !both && st <= 7 - wm;
+        if (both) body(As, all_rows);
+        if (one) body(As, std::integral_constant<int, 2>{});
+      } else {                        // upper: sub-tile t takes part once st >= t
+        const bool both = st >= 7 - wm, one = !both && st >= wm;
+        if (both) body(As, all_rows);
+        if (one) body(As, std::integral_constant<int, 1>{});
+      }
+    } else {
+      bool skip = false;
+      if (TRI == TRI_A_LOWER) skip = krel > wm * RW + RW - 1;
+      if (TRI == TRI_A_UPPER) skip = krel + BK - 1 < wm * RW;
+      if (TRI == TRI_C_LOWER) skip = (tl.bi == tl.bj) && (wn * WTN > wm * RW + RW - 1);
+      if (!skip) body(As, all_rows);
+    }
   }
 
   EpiCtx e;
   e.C = g.C + (int64_t)tl.slice * g.slice_stride; e.ldc = g.ldc; e.alpha = g.alpha;
-  e.row0 = row0 + wrow; e.col0 = col0 + wn * WTN; e.lane = lane; e.prow = (int64_t)tl.bi * WMW + wm;
+  e.row0 = row0 + wrow; e.col0 = col0 + wn * WTN; e.lane = lane; e.prow = (int64_t)tl.bi * WMW + wm; e.tm_stride = tm_stride;
   if (ZIGP_KO_EPI && TRI != TRI_NONE) { if (acc[0][0][0] == 1.2345e300) epi(acc, e); return; }   // no stores (the test keeps the accumulators live)
   epi(acc, e);
 }
