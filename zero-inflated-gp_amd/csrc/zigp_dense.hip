@@ -191,7 +191,7 @@ int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
     ZIGP_TRY(tiles_full_xcd(c, nbm, nbn, nbm * (BM / BK), tf));
     ProfScope ps(c, PC_GEMM_J, 2.0 * fl);
     if (c->jp_wait) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); c->jp_wait = false; }
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, tf, mk_args(lt.Qt.p, Mp, lt.A2.p, Nc, lt.Jp.p, Nc), EpiStore())));
+    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, tf, mk_args(lt.Qt.p, Mp, lt.A2.p, Nc, lt.Jp.p, Nc), EpiStorePanel())));
     return 0;
   }
 #endif

@@ -123,6 +123,7 @@ struct EpiStore {   // C = alpha*acc
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = v; });
   }
 };
+struct EpiStorePanel : EpiStore {};   // same code under its own kernel name: the chunk loop's J' = Q A2 (profilers aggregate by name, and the M x M stage launches the plain one)
 struct EpiAccum {   // C += alpha*acc
   template <int TM, int TN>
   __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const {
