@@ -537,7 +537,7 @@ def main():
                 'flops_per_launch': flops_per_launch, 'avg_launch_ms': avg_launch_s * 1e3, 'launches_timed': gk['launches'],
                 'all_gemm_tflops': gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
                 # whole step (timed region) against the same peak, counting the 10 M^2 N flops this engine's algorithm executes
-                # (four triangular products + one symmetric rank-N update per latent)
+                # (two triangular products + one full product of twice their flops + one symmetric rank-N update per latent)
                 'step_frac_10M2N': (10.0 * M * M * N / (dt / args.steps)) / PEAK_FP64_MFMA,
             }
             res['side_kernels'] = hbm
