@@ -330,8 +330,8 @@ def other_configs(eng, X3, Y3, p3, jitter):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--rows', type=int, default=1000000, help='rows per GPU (weak) or in total (strong)')
     ap.add_argument('--M', type=int, default=1024)
     ap.add_argument('--D', type=int, default=3)
