@@ -874,7 +874,14 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
 //   then W = L^-1 block diagonal by block diagonal, both products (T = sum L_ik W_kj, W_ij = -W_ii T) as MFMA tiles.
 // In-kernel stamps of the first version at M = 100: 296 k cycles, 4 x 30 k of them in the serial factor + inverse of wave 0 and most of
 // the rest in LDS-bandwidth-bound scalar dot products of the trailing updates and of W.
-__device__ __forceinline__ double potrf_mfma(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+// one 16 x 16 x 4 product: c[r] of lane l is C[4 r + l / 16][l % 16], a = A[l % 16][l / 16], b = B[l / 16][l % 16]  (r4: was four 4x4x4 MFMAs
+// with the A block read at the same address in all four 16-lane groups; one instruction and one LDS read instead of four each)
+typedef double potrf_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void potrf_mfma16(double (&c)[4], double a, double b) {
+  potrf_d4 v = {c[0], c[1], c[2], c[3]};
+  v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, v, 0, 0, 0);
+  c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
+}
 __device__ __forceinline__ double potrf_rsqrt(double d) {      // d > 0: hardware estimate + two Newton steps
   double y = __builtin_amdgcn_rsq(d);
   double e = fma(-d * y, y, 1.0);
@@ -885,14 +892,12 @@ __device__ __forceinline__ double potrf_rsqrt(double d) {      // d > 0: hardwar
 }
 // S[i0 + ., k0 + .] (16 x 16) -= sum_{c = c0 .. c0 + 31} S[i][c] S[k][c]     (one wave)
 __device__ __forceinline__ void potrf_tile_update(double* S, int i0, int k0, int c0) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, ai = lane & 3;
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int ks = 0; ks < PNB / 4; ++ks) {
     const int c = c0 + 4 * ks + g;
-    const double bv = S[(k0 + n) * PBLD + c];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = potrf_mfma(S[(i0 + 4 * r + ai) * PBLD + c], bv, acc[r]);
+    potrf_mfma16(acc, S[(i0 + n) * PBLD + c], S[(k0 + n) * PBLD + c]);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) S[(i0 + 4 * r + g) * PBLD + k0 + n] -= acc[r];
@@ -937,7 +942,7 @@ __device__ __forceinline__ void potrf_wave_sync() {
 }
 __device__ __forceinline__ int potrf_factor32(const double* S, PotrfShared& psh, int jb, double tol) {
   const int lane = threadIdx.x & 63, r = lane & 31;     // lanes 32..63 shadow lanes 0..31 (they never store)
-  const int g = lane >> 4, n = lane & 15, ai = lane & 3;
+  const int g = lane >> 4, n = lane & 15;
   double a[PNB];
 #pragma unroll
   for (int k = 0; k < PNB; ++k) a[k] = S[(jb + r) * PBLD + jb + k];
@@ -954,9 +959,8 @@ __device__ __forceinline__ int potrf_factor32(const double* S, PotrfShared& psh,
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < PHB / 4; ++ks) {
-      const double bv = psh.T[0][PHB + n][4 * ks + g];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = potrf_mfma(psh.T[0][PHB + 4 * q + ai][4 * ks + g], bv, acc[q]);
+      const double bv = psh.T[0][PHB + n][4 * ks + g];      // L21 L21^T: the A and the B operand of a lane are the same element
+      potrf_mfma16(acc, bv, bv);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) psh.T[1][PHB + 4 * q + g][n] = acc[q];
@@ -1017,7 +1021,7 @@ __device__ __forceinline__ void potrf_invert16(double* S, PotrfShared& psh, int 
 // one wave, after both halves: X = L21 W11 stays in the accumulators (the D layout of one product is the B layout of the next),
 // W21 = -W22 X goes to S[pb + col][pb + 16 + row]
 __device__ __forceinline__ void potrf_invert_couple(double* S, PotrfShared& psh, int pb) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15, ai = lane & 3;
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
   double x[4] = {0.0, 0.0, 0.0, 0.0}, w[4] = {0.0, 0.0, 0.0, 0.0};
   const double dn = psh.dinv[pb + n];
 #pragma unroll
@@ -1025,19 +1029,13 @@ __device__ __forceinline__ void potrf_invert_couple(double* S, PotrfShared& psh,
     const int k = 4 * ks + g;                                  // B = W11[k][n]: S[pb + n][pb + k] for k > n
     const double sv = S[(pb + n) * PBLD + pb + k];
     const double bv = k > n ? sv : (k == n ? dn : 0.0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = potrf_mfma(S[(pb + PHB + 4 * r + ai) * PBLD + pb + k], bv, x[r]);
+    potrf_mfma16(x, S[(pb + PHB + n) * PBLD + pb + k], bv);
   }
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int k = 4 * ks + g;                                  // A = W22[row][k]: S[pb + 16 + k][pb + 16 + row] for row > k
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * r + ai;
-      const double sv = S[(pb + PHB + k) * PBLD + pb + PHB + row], dv = psh.dinv[pb + PHB + row];
-      const double av = row > k ? sv : (row == k ? dv : 0.0);
-      w[r] = potrf_mfma(av, x[ks], w[r]);
-    }
+    const double sv = S[(pb + PHB + k) * PBLD + pb + PHB + n], dv = psh.dinv[pb + PHB + n];
+    potrf_mfma16(w, n > k ? sv : (n == k ? dv : 0.0), x[ks]);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) S[(pb + n) * PBLD + pb + PHB + 4 * r + g] = -w[r];
@@ -1129,7 +1127,7 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
   if (wave == 0) potrf_invert_couple(S, psh, nreal - PNB);
   __syncthreads();
   // W[x][y]: x > y at S[y][x], x == y in dinv, x < y zero
-  const int lane = t & 63, g = lane >> 4, n = lane & 15, ai = lane & 3;
+  const int lane = t & 63, g = lane >> 4, n = lane & 15;
   for (int dist = 1; dist < npan; ++dist) {
     const int nblk = npan - dist;                 // blocks (b + dist, b), b = 0 .. nblk-1, four 16 x 16 tiles each
     for (int tile = wave; tile < 4 * nblk; tile += 16) {   // T = sum_x L[ib + r][x] W[x][jb + c],  jb <= x < ib
@@ -1137,19 +1135,16 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
       const int y = jb + 16 * ct + n;
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
       for (int ks4 = 4 * ct; ks4 < 8 * dist; ks4 += 4) {     // four k-steps of loads at a time
-        double bv[4], av[4][4];
+        double bv[4], av[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int x = jb + 4 * (ks4 + u) + g;
           const double sv = S[y * PBLD + x], dv = dinv[y];
           bv[u] = x > y ? sv : (x == y ? dv : 0.0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) av[u][r] = S[(ib + 16 * rt + 4 * r + ai) * PBLD + x];
+          av[u] = S[(ib + 16 * rt + n) * PBLD + x];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = potrf_mfma(av[u][r], bv[u], acc[r]);
+        for (int u = 0; u < 4; ++u) potrf_mfma16(acc, av[u], bv[u]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[b][16 * rt + 4 * r + g][16 * ct + n] = acc[r];
@@ -1159,22 +1154,16 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
       const int b = tile >> 2, rt = (tile >> 1) & 1, ct = tile & 1, jb = b * PNB, ib = (b + dist) * PNB;
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
       for (int ks4 = 0; ks4 < 4 * (rt + 1); ks4 += 4) {
-        double bv[4], av[4][4];
+        double bv[4], av[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int m = 4 * (ks4 + u) + g;
+          const int m = 4 * (ks4 + u) + g, row = 16 * rt + n;
           bv[u] = T[b][m][16 * ct + n];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * rt + 4 * r + ai;
-            const double sv = S[(ib + m) * PBLD + ib + row], dv = dinv[ib + row];
-            av[u][r] = row > m ? sv : (row == m ? dv : 0.0);
-          }
+          const double sv = S[(ib + m) * PBLD + ib + row], dv = dinv[ib + row];
+          av[u] = row > m ? sv : (row == m ? dv : 0.0);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = potrf_mfma(av[u][r], bv[u], acc[r]);
+        for (int u = 0; u < 4; ++u) potrf_mfma16(acc, av[u], bv[u]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) S[(jb + 16 * ct + n) * PBLD + ib + 16 * rt + 4 * r + g] = -acc[r];
