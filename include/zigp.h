@@ -62,9 +62,11 @@ const char* zigp_last_error(zigp_ctx* ctx);
 int zigp_last_info(zigp_ctx* ctx);
 
 /* Tunables: chunk = number of data rows processed per pass through the fused pipeline (multiple of
- * 1024 and <= 1048576).  Default, until this is called: 32768 * 1024 / M rows, clamped to [32768, 131072]. */
+ * 1024 and <= 1048576).  Default, until this is called: 32768 * 1024 / M rows, clamped to [32768, 131072]; a row range of up to 131072
+ * rows goes through in one pass. */
 int zigp_set_chunk(zigp_ctx* ctx, int64_t chunk_rows);
-/* The chunk (rows per pass) the dense path uses for M inducing points per latent: the zigp_set_chunk value, else the default rule. */
+/* The chunk (rows per pass) the dense path uses for M inducing points per latent on a long row range: the zigp_set_chunk value, else
+ * the default rule. */
 int64_t zigp_get_chunk(zigp_ctx* ctx, int32_t M);
 /* Smallest Cholesky pivot accepted, as a multiple of eps * (kernel variance + jitter).  Default 8 (see ZIGP_ENOTPD above);
  * 0 reproduces tf.cholesky / LAPACK potrf, which fail on a non-positive pivot only (onofftf/main.py:200,268,355). */

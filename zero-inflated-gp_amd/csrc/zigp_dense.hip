@@ -389,8 +389,12 @@ int64_t auto_chunk(const zigp_ctx* c) {
   return std::min<int64_t>(131072, std::max<int64_t>(32768, round_up(32768 * 1024 / std::max<int64_t>(Mmax, 128), 1024)));
 }
 int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
-  const int64_t chunk = auto_chunk(c);
   const int64_t span = k.has_rows ? (k.row_end - k.row_begin) : 0;
+  // A row range of up to 131072 rows goes through in ONE pass unless the caller fixed the chunk: no chunk boundary (where the side stream's
+  // kgrads outlast the rank-N updates), one prologue / tail per product instead of two to four -- cfg2 (1e5 rows, M = 512) 5.98 -> 5.81 ms, the
+  // 125 000-row shard of cfg3 23.4 -> 23.0 ms; long ranges stay at the M-scaled chunk (cfg3: 32768 rows 167.8 ms, 65536: 170.2, 131072: 169.2;
+  // tools/chunk_sweep.py, profiles/r04ao_chunk_sweep.log)
+  const int64_t chunk = (c->chunk_auto && span > 0 && span <= 131072) ? 131072 : auto_chunk(c);
   k.Nc = 1024;
   if (span > 0) {
     const int64_t nchunks = (span + chunk - 1) / chunk;
