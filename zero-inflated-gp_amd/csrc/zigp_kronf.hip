@@ -681,14 +681,19 @@ k_kf_factor(KfFactorArgs a) {
     jb.Zs[idx] = z * inv_ell[d];
   }
   __syncthreads();
-  if (t < MAXD) {      // zc_d = mid-range of the inducing inputs (min / max are exact: any order gives the same bits)
-    double zc = 0.0;
-    if (t < D) {
-      double lo = zl[t], hi = lo;
-      for (int m = 1; m < M; ++m) { const double z = zl[m * D + t]; lo = fmin(lo, z); hi = fmax(hi, z); }
-      zc = 0.5 * (lo + hi);
+  if (t < 64) {        // zc_d = mid-range of the inducing inputs (min / max are exact: any order gives the same bits).  One wave, lanes over the
+                       // points: as a serial loop in MAXD lanes (100 dependent LDS reads) this held wave 0 back for ~10 k cycles before its share of K
+    for (int d = 0; d < MAXD; ++d) {
+      double zc = 0.0;
+      if (d < D) {
+        double lo = zl[d], hi = lo;                        // point 0: every lane starts from a real value
+        for (int m = t; m < M; m += 64) { const double z = zl[m * D + d]; lo = fmin(lo, z); hi = fmax(hi, z); }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) { lo = fmin(lo, __shfl_xor(lo, sft, 64)); hi = fmax(hi, __shfl_xor(hi, sft, 64)); }
+        zc = 0.5 * (lo + hi);
+      }
+      if (t == 0) jb.zc_out[d] = zc;
     }
-    jb.zc_out[t] = zc;
   }
   const int nreal = ((M + PNB - 1) / PNB) * PNB;   // the factorisation touches the 32-column panels that hold real rows only
   for (int idx = t; idx < (nreal / 2) * (nreal + 1); idx += 1024) {
@@ -724,50 +729,35 @@ k_kf_factor(KfFactorArgs a) {
   // every LDS round trip exposed).  Dearest blocks first over the 16 waves.  Each lane ends with P(16 rb + 4 r + g, 16 cb + n),
   // r = 0..3 -- one 32-byte granule of the fragment image PF -- and mirrors it into block (cb, rb).
   {
-    const int lane = t & 63, g = lane >> 4, n = lane & 15, ai = lane & 3, wave = t >> 6;
+    // (r4: one 16 x 16 x 4 MFMA per k-step; the A operand of a lane is row 16 rb + n of the block -- the same read pattern as the B operand)
+    const int lane = t & 63, g = lane >> 4, n = lane & 15, wave = t >> 6;
     const int nbq = Mq / 16, ksn = Mq / 4;
     for (int blk = wave; blk < nbq * (nbq + 1) / 2; blk += 16) {
       int rb = 0, cb = blk;
       while (cb > rb) { cb -= rb + 1; ++rb; }
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      const int j = 16 * cb + n;
+      const int j = 16 * cb + n, i_a = 16 * rb + n;
       const double* Sb = S + j * PBLD + g;
-      const double* Sa = S + (16 * rb + ai) * PBLD + g;
+      const double* Sa = S + i_a * PBLD + g;
       {
-        double bv[4], av[4][4];
-        const double dj = psh.dinv[j];
-        double di[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) di[r] = psh.dinv[16 * rb + 4 * r + ai];
+        double bv[4], av[4];
+        const double dj = psh.dinv[j], di = psh.dinv[i_a];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int k = 16 * rb + 4 * u + g;
-          const double sb = Sb[4 * (4 * rb + u)];
+          const double sb = Sb[4 * (4 * rb + u)], sa = Sa[4 * (4 * rb + u)];
           bv[u] = k > j ? sb : (k == j ? dj : 0.0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * rb + 4 * r + ai;
-            const double sa = Sa[4 * r * PBLD + 4 * (4 * rb + u)];
-            av[u][r] = k > i ? sa : (k == i ? di[r] : 0.0);
-          }
+          av[u] = k > i_a ? sa : (k == i_a ? di : 0.0);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = kf_mfma(av[u][r], bv[u], acc[r]);
+        for (int u = 0; u < 4; ++u) kf_mfma16(acc, av[u], bv[u]);
       }
       for (int ks = 4 * rb + 4; ks < ksn; ks += 4) {
-        double bv[4], av[4][4];
+        double bv[4], av[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          bv[u] = Sb[4 * (ks + u)];
+        for (int u = 0; u < 4; ++u) { bv[u] = Sb[4 * (ks + u)]; av[u] = Sa[4 * (ks + u)]; }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) av[u][r] = Sa[4 * r * PBLD + 4 * (ks + u)];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = kf_mfma(av[u][r], bv[u], acc[r]);
+        for (int u = 0; u < 4; ++u) kf_mfma16(acc, av[u], bv[u]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
