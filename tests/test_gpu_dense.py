@@ -351,3 +351,37 @@ def test_chunk_rule_is_reported_by_the_library():
             e.comm_init(0, 1, b'short')
     finally:
         e.close()
+
+
+def test_automatic_rule_takes_a_short_row_range_in_one_pass_with_the_same_result():
+    """Under the library's own chunk rule (a fresh engine: no zigp_set_chunk) a row range of <= 131072 rows is ONE pass; a long range is cut
+    at the M-scaled chunk.  Both must give what explicit small chunks give (value 1e-12; gradients 1e-6 relative, the tolerance of every gradient comparison here -- measured
+    9e-10 on Z and 3e-8 on the kernel variance, a sum with cancellation: the partial sums are split differently and the reverse M x M stage amplifies that by cond(Kuu)), and the rule must switch at the boundary without a seam: 131072 rows in one pass against 131073 in two."""
+    import zigp
+    e = zigp.DenseEngine(0)
+    try:
+        N, M, D = 40000, 130, 2
+        X, Y, p = make_problem(N, M, D, seed=31, ell=0.4)
+        e.set_data(X, Y)
+        ed_a, kl_a, g_a = e.elbo(p, jitter=1e-6)                      # automatic: one pass of 40960 columns
+        ed_r, _, _ = e.elbo(p, jitter=1e-6, rows=(100, 35000))        # a row range through the same rule
+        e.set_chunk(8192)
+        ed_c, kl_c, g_c = e.elbo(p, jitter=1e-6)                      # five chunks
+        ed_rc, _, _ = e.elbo(p, jitter=1e-6, rows=(100, 35000))
+        assert abs(ed_a - ed_c) <= 1e-12 * abs(ed_c) and kl_a == kl_c and abs(ed_r - ed_rc) <= 1e-12 * abs(ed_rc)
+        for k in ('Zf', 'Zg', 'u_fm', 'u_gs_sqrt', 'ell_f', 'var_g', 'noise'):
+            a, b = np.asarray(g_a[k], dtype=float).reshape(-1), np.asarray(g_c[k], dtype=float).reshape(-1)
+            assert np.max(np.abs(a - b)) <= 1e-6 * np.max(np.abs(b)), k
+    finally:
+        e.close()
+    e = zigp.DenseEngine(0)
+    try:
+        N, M, D = 131073, 64, 2
+        X, Y, p = make_problem(N, M, D, seed=32, ell=0.5)
+        e.set_data(X, Y)
+        one, _, _ = e.elbo(p, jitter=1e-6, rows=(0, 131072), need_grad=False)        # one pass
+        last, _, _ = e.elbo(p, jitter=1e-6, rows=(131072, 131073), include_kl=False, need_grad=False)
+        both, _, _ = e.elbo(p, jitter=1e-6, need_grad=False)                         # 131073 rows: the M-scaled chunk (131072 at M = 64) -> two passes
+        assert abs((one + last) - both) <= 1e-12 * abs(both)
+    finally:
+        e.close()
