@@ -521,9 +521,9 @@ def main():
                     pass
             Mp = (M + 127) // 128 * 128
             hbm = {}
-            # kgrad reads the J' panel only (8 Mp bytes per column) since it recomputes K from x, z (ZIGP_KGRAD_RECOMPUTE, round 3; PMC: 0.28 GB
-            # per launch): it is bound by the fp64 exp / VALU work of that recompute, not by HBM -- its GB/s is reported for the record
-            for k, bytes_per_col, bound in (('kgrad', 8.0 * Mp + 8.0 * (D + 2), 'fp64 VALU (K recomputed: ~45 fp64 instructions per element); HBM rate for the record'),
+            # kgrad reads the J' and the K panel (16 Mp bytes per column): since late round 4 it reads K again instead of recomputing it from
+            # x, z (ZIGP_KGRAD_RECOMPUTE = 0: beside the MFMA-bound products the saved fp64 VALU work is worth more than the bytes)
+            for k, bytes_per_col, bound in (('kgrad', 16.0 * Mp + 8.0 * (D + 2), 'HBM read (J\' and K panels; ~17 fp64 instructions per element)'),
                                             ('kuf_build', 8.0 * Mp + 8.0 * D, 'HBM write')):
                 if prof[k]['launches'] > 0 and prof[k]['ms'] > 0:
                     # bytes over ALL launches of the profiled pass: every column of the shard is swept once per latent and step

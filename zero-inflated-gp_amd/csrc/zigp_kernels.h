@@ -285,16 +285,19 @@ constexpr int KG_ROWS = 4;
 #define ZIGP_KG_SPLIT 4
 #endif
 constexpr int KG_SPLIT = ZIGP_KG_SPLIT;   // column splits (blockIdx.y); each split accumulates into its own krow slab [KG_SPLIT][Mp][W]
-// ZIGP_KGRAD_RECOMPUTE (default): K[m,n] is recomputed from x_n and z_m (the expression of k_kuf_build, bit for bit) instead of read
-// back: half the HBM bytes (0.27 instead of 0.54 GB per chunk and latent) for 8.1 instead of 7.2 ms of kernel time per step when it runs
-// alone -- with the side-stream overlap (zigp_set_overlap, what bench.py times) the step is 0.3 % shorter (profiles/r03a_ab_kgrad.log).
-// r4, re-measured on the 16x16x4 core (profiles/r04ai_ab_kgread.log, two boxes): reading K is now 0.0-0.6 % FASTER per step (173.1-174.6 vs
-// 174.5-174.7 ms) -- within what two boxes differ by, so the default stays; two columns per thread with 16-byte loads changes nothing
-// (7.13 vs 7.17 ms alone = 4.6 TB/s).
+// ZIGP_KGRAD_RECOMPUTE (round 3's default; OFF since late round 4): K[m,n] is recomputed from x_n and z_m (the expression of k_kuf_build, bit
+// for bit) instead of read back: half the HBM bytes (0.27 instead of 0.54 GB per chunk and latent) for 8.1 instead of 7.2 ms of kernel time
+// per step when it runs alone -- with the side-stream overlap (zigp_set_overlap, what bench.py times) the step was 0.3 % shorter on the
+// round-3 core (profiles/r03a_ab_kgrad.log).
+// r4, re-measured on the 16x16x4 core (profiles/r04ai_ab_kgread.log: three boxes, eleven rounds): READING K is faster in every round -- cfg3
+// -0.3 ... -1.1 ms per step (avg -0.6), the 125 000-row shard -0.7 %, cfg2 -1.3 %: beside MFMA-bound products that leave 7 of the 8 TB/s of
+// HBM idle, 28 fewer fp64 VALU instructions per element are worth more than 8 more bytes.  Two columns per thread with 16-byte loads change
+// nothing (7.13 vs 7.17 ms alone = 4.6 TB/s).  K stays valid until this kernel is done: the next chunk's panels are built behind it on the
+// same stream (dense_chunk_loop).
 // r3, measured and dropped: a 1-row x 2-column version of 69 VGPRs, meant to sit beside the two rank-N-update workgroups of a CU (which
 // leave 112 registers per lane; this kernel holds 150): 9.4 ms alone and no better overlapped (185.0 vs 184.5 ms/step, r03e_overlap.log).
 #ifndef ZIGP_KGRAD_RECOMPUTE
-#define ZIGP_KGRAD_RECOMPUTE 1
+#define ZIGP_KGRAD_RECOMPUTE 0
 #endif
 template <int D>
 __global__ void __launch_bounds__(256)
