@@ -43,6 +43,11 @@ constexpr int BM = 128, BN = 128, BK = 16;
 #ifndef ZIGP_MFMA16
 #define ZIGP_MFMA16 1
 #endif
+#ifndef ZIGP_PIPE_READS
+#define ZIGP_PIPE_READS 2      // hand-pipelined fragment reads (see ds_rd64 below): 2 = the full and the lower-triangular 8-wave m/n-contiguous products
+                               // (A2 = W^T A1 measures 1 % SLOWER with them: profiles/r05h_ab_pipe.log), 1 = all three, 0 = the compiler's order
+
+#endif
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void mfma16(double (&c)[4], double a, double b) {
   mfma_d4 v = {c[0], c[1], c[2], c[3]};
@@ -274,6 +279,25 @@ __device__ __forceinline__ int a_read_off(const int (&a_base)[4], int tm, int r,
 template <class E> constexpr auto epi_prefetches(int) -> decltype(E::PREFETCH) { return E::PREFETCH; }
 template <class E> constexpr bool epi_prefetches(long) { return false; }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ---- hand-pipelined fragment reads (round 5) ----------------------------------------------------------------------------------------
+// Left to the compiler, a k-step of the 16x16x4 form is [its LDS reads] [s_waitcnt lgkmcnt(0)] [its MFMAs]: every wave stalls for an LDS
+// round trip four times per staged step.  Here the reads of k-step ks + 1 are issued IN FRONT of the MFMAs of k-step ks into a second
+// fragment set and waited for with a counted lgkmcnt (LDS operations return in order): the reads are inline assembly -- the compiler's
+// own s_waitcnt insertion does not see them, so the waits are exactly the ones written here -- the MFMAs stay builtins (the compiler keeps
+// their hazards) and sched_barrier fences pin the order.  tools/ubench/gemm_lab.hip is where the form was developed and measured
+// (profiles/r05*_gemm_lab_*.log: +1.1 % on the full product; wider reads, fewer reads, an early barrier, cross-tile prefetch, staggered
+// tile boundaries and a column-strip wave shape were measured there too and do not pay).  The same treatment of the 4-wave k-contiguous
+// k-scaled kernel (the symmetric rank-N update) is 1.3 % SLOWER than the compiler's order (61.9 vs 62.7 TFLOP/s, profiles/r05i_ab_syrk_pipe.log;
+// the change is tools/syrk_pipe_experiment.patch).
+template <int N> struct IC { static constexpr int value = N; };
+template <int B, int E, class F> __device__ __forceinline__ void sfor(F f) { if constexpr (B < E) { f(IC<B>{}); sfor<B + 1, E>(f); } }
+template <int OFF> __device__ __forceinline__ double ds_rd64(uint32_t a) {    // a: LDS byte address of this lane, OFF: compile-time byte offset
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  double v; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF)); return v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ uint32_t lds_addr(const double* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)p; }
 
 // TRI: triangular structure exploited at wave granularity inside diagonal blocks (64 rows in the 4-wave, 32 rows in the 8-wave shape).
 // r3, measured and removed: peeling the diagonal 128 x 128 block of the triangular factor into a tail of 8 steps with 16-row granularity
@@ -574,6 +598,36 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
           }
         }
       }
+      return;
+    }
+    if constexpr (M16 && WAVES == 8 && ALAY == LAY_MNCONTIG && BLAY == LAY_MNCONTIG && !KSCALE && ZIGP_PIPE_READS != 0 && !(ZIGP_PIPE_READS == 2 && TRI == TRI_A_UPPER)) {
+      // the chunk loop's products (A1 = W K, A2 = W^T A1, J' = Q A2 and the predictive ones): fragment reads one k-step ahead, see above
+      constexpr int NA = (MASK & 1) + ((MASK >> 1) & 1);
+      static_assert(TMW == 2, "8-wave shape: two sub-tile rows per wave");
+      constexpr int NRD = NA + TNW;
+      const uint32_t aa0 = lds_addr(As) + 8u * (uint32_t)a16_base_[0];                       // sub-tile tm = 0 of k-step 0
+      const uint32_t aa1 = aa0 + 8u * (uint32_t)(TRI_BAL ? tm_stride : 16);                  // sub-tile tm = 1
+      const uint32_t ba = lds_addr(Bs) + 8u * (uint32_t)b_base_[0];
+      double af[2][TMW], bf[2][TNW];
+      auto load = [&](auto ks_, auto set_) {
+        constexpr int ks = decltype(ks_)::value, set = decltype(set_)::value;
+        if constexpr ((MASK & 1) != 0) af[set][0] = ds_rd64<ks * 4 * LDMN * 8>(aa0);
+        if constexpr ((MASK & 2) != 0) af[set][1] = ds_rd64<ks * 4 * LDMN * 8>(aa1);
+        sfor<0, TNW>([&](auto p_) { constexpr int p = decltype(p_)::value; bf[set][p] = ds_rd64<(ks * 4 * LDMN + p * 16) * 8>(ba); });
+      };
+      load(IC<0>{}, IC<0>{});
+      sfor<0, BK / 4>([&](auto ks_) {
+        constexpr int ks = decltype(ks_)::value;
+        if constexpr (ks + 1 < BK / 4) { load(IC<ks + 1>{}, IC<(ks + 1) & 1>{}); wait_lgkm<NRD>(); } else wait_lgkm<0>();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm)
+          if ((MASK >> tm) & 1) {
+#pragma unroll
+            for (int tn = 0; tn < TNW; ++tn) mfma16(acc[tm][tn], af[ks & 1][tm], bf[ks & 1][tn]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      });
       return;
     }
     if constexpr (M16) {
