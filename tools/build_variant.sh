@@ -4,6 +4,6 @@
 set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-/opt/rocm/bin/hipcc -O3 "$@" -DZIGP_NSTAGE=2 -DZIGP_WAVES_DEFAULT=4 --offload-arch=gfx950 -std=c++17 -shared -fPIC \
+/opt/rocm/bin/hipcc -O3 "$@" --offload-arch=gfx950 -std=c++17 -shared -fPIC \
   -o "$ROOT/zero-inflated-gp_amd/lib/libzigp_$NAME.so" "$ROOT/zero-inflated-gp_amd/csrc/zigp_lib.hip"
 echo "$ROOT/zero-inflated-gp_amd/lib/libzigp_$NAME.so"

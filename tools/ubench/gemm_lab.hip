@@ -88,7 +88,7 @@ k_v3(GemmArgs g, Stamp* stamps) {
   const uint32_t b_addr0 = lds0 + 8u * (uint32_t)(TILE_D + kq * LDM + wn * CW + cj);
   double* __restrict__ C = g.C;
   const int64_t ld = g.ldc;
-  const uint32_t offA = glds_lane_offset<LAY_MNCONTIG, WAVES, false>(sg.lda, wave, lane), offB = glds_lane_offset<LAY_MNCONTIG, WAVES, false>(sg.ldb, wave, lane);
+  const uint32_t offA = glds_lane_offset<LAY_MNCONTIG, WAVES>(sg.lda, wave, lane), offB = glds_lane_offset<LAY_MNCONTIG, WAVES>(sg.ldb, wave, lane);
   const int64_t csA = glds_chunk_stride<LAY_MNCONTIG, WAVES>(sg.lda), csB = glds_chunk_stride<LAY_MNCONTIG, WAVES>(sg.ldb);
 
   // scalar staging state of the tile whose stages are being requested (pinned where defined: see glds_pin)

@@ -45,7 +45,7 @@ struct Latent {
   DevBuf Z, ell, u, s, s2;              // Z (Mp,D) zero padded; u,s,s2 (Mp) zero padded
   double var = 1.0;
   DevBuf Kuu, L, W;                      // (Mp,Mp)
-  DevBuf K, A1, A2, H, Jp;               // chunk panels [Mp][Nc]: Kuf, A1 = W K, A2 = W^T A1, H = W diag(s^2) A2, J' = W^T H - A2
+  DevBuf K, A1, A2, Jp;                  // chunk panels [Mp][Nc]: Kuf, A1 = W K, A2 = W^T A1, J' = Q A2 (= W^T W diag(s^2) A2 - A2)
   DevBuf Wp, a1gm;                       // W diag(s^2) (Mp,Mp); running sum of A1 gm [Mp]
   DevBuf Wt, Wpt;                        // W^T, (W diag(s^2))^T (Mp,Mp): the m-contiguous images the lower-triangular products read
   DevBuf P, Qt;                          // gradient steps: P = W^T W = Kuu^-1 and Qt = diag(s^2) P - I = Q^T, J' = Q A2 (zigp_dense.hip, latent_chunk_forward)
@@ -91,8 +91,7 @@ struct zigp_ctx {
   hipStream_t stream_main = nullptr, stream2 = nullptr;
   hipStream_t stream3 = nullptr;   // dense path: buffers, zeroed accumulators and the first chunk's Kuf panels, under the M x M forward of both latents
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  hipEvent_t ev_prep_fork = nullptr, ev_prep = nullptr, ev_kuf = nullptr;
-  bool jp_wait = false;            // the next J' launch waits for ev_join first: the previous chunk's Kuf-cotangent kernels still read J' (dense_chunk_loop)
+  hipEvent_t ev_prep_fork = nullptr, ev_prep = nullptr;
   std::string err;
   int info = 0;
   int64_t chunk = 32768;

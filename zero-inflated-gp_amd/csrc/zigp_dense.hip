@@ -23,10 +23,6 @@
 
 using namespace zigp;
 
-// ZIGP_J_QFORM (round 4): the gradient step's H and J' panels as one full product with Q = Kuu^-1 diag(s^2) - I (latent_chunk_forward)
-#ifndef ZIGP_J_QFORM
-#define ZIGP_J_QFORM 1
-#endif
 namespace {
 
 struct HostLatent {
@@ -112,19 +108,16 @@ int latents_forward(zigp_ctx* c, const HostLatent (&hl)[2], int D, double jitter
       if (step == 0) lt.P_ready = false;
       double* v = lt.vec.p; double* alpha = v + Mp; double* dkinv = v + 2 * Mp; double* klv = v + 3 * Mp;
       switch (step) {
-#if ZIGP_LOWER_VIA_WT
-        case 0:   // W^T and (W diag(s^2))^T for the lower-triangular products (the latter is used by gradient steps only; it costs nothing extra)
+        case 0:   // W^T: the m-contiguous image of the factor that the lower-triangular product A1 = W K reads
           hipLaunchKernelGGL(k_transpose_scale, dim3(Mp / 32, Mp / 32), dim3(32, 8), 0, c->stream, lt.W.p, lt.s2.p, (int64_t)Mp, lt.Wt.p, lt.Wpt.p);
           break;
-#endif
         // v = W u and alpha = W^T v are needed by the KL value, by the fused mean (v^T A1) and by the rank-1 parts of the data-term gradient
         case 1: if (with_kl) hipLaunchKernelGGL(k_gemv_rows, dim3(Mp), dim3(256), 0, c->stream, lt.W.p, lt.u.p, (int64_t)Mp, v); break;
         case 2: if (with_kl) hipLaunchKernelGGL(k_kl_cols, dim3(Mp / 64), dim3(64, COL_LANES), 0, c->stream, lt.W.p, v, (int64_t)Mp, alpha, dkinv); break;
         case 3: if (with_kl) hipLaunchKernelGGL(k_kl_value, dim3(1), dim3(256), 0, c->stream, v, lt.L.p, lt.s.p, dkinv, lt.M, (int64_t)Mp, klv); break;
-        case 4:   // W' = W diag(s^2) (operand of H = W' A2 and of the reverse M x M stage)
+        case 4:   // W' = W diag(s^2) (operand of the reverse M x M stage)
           if (need_grad) hipLaunchKernelGGL(k_colscale, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.W.p, lt.s2.p, (int64_t)Mp, lt.Wp.p);
           break;
-#if ZIGP_J_QFORM
         case 5:   // P = W^T W = Kuu^-1 (the reverse M x M stage needs it anyway and takes it from here)
           if (need_grad) {
             const int nb = Mp / BM, kb = BM / BK;
@@ -136,7 +129,6 @@ int latents_forward(zigp_ctx* c, const HostLatent (&hl)[2], int D, double jitter
         case 6:   // Q^T = diag(s^2) P - I: J' = W^T (W diag(s^2) A2) - A2 = (P diag(s^2) - I) A2 = Q A2 is ONE full product per chunk
           if (need_grad) hipLaunchKernelGGL(k_rowscale_minus_eye, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.P.p, lt.s2.p, (int64_t)Mp, lt.Qt.p);
           break;
-#endif
         default: break;
       }
       ZIGP_HIP(c, hipGetLastError());
@@ -159,56 +151,30 @@ int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, i
 int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
   const int Mp = lt.Mp, nbm = Mp / BM, nbn = (int)(Nc / BN);
   const int np = Mp / 32;   // allocated partial rows per fused column sum (a kernel writes one per wave tile: 64 or 32 rows)
-  TileList tl, tu, tu_lpt;
+  TileList tl, tu;
   const bool paired = trmm_paired_pays(nbm, nbn);
   ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, tl, paired));
   ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu, paired));
-#ifndef ZIGP_J_PAIRED
-#define ZIGP_J_PAIRED 0
-#endif
-  ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu_lpt, ZIGP_J_PAIRED != 0 && paired));   // J': its epilogue loads an A2 tile, which the lockstep of the paired order makes coincide (LPT by default)
   const double fl = (double)lt.M * lt.M * (double)Nc;
   {
     ProfScope ps(c, PC_GEMM_A1, fl);   // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
     EpiStoreColsum ep{lt.vec.p, nullptr, lt.part.p, lt.part.p + (size_t)np * Nc};
-#if ZIGP_LOWER_VIA_WT
     ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wt.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), ep)));
-#else
-    ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.W.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), ep)));
-#endif
   }
   {
     ProfScope ps(c, PC_GEMM_A2, fl);   // A2 = W^T A1 ; partial column sums  sum s^2 A2^2
     EpiStoreColsum ep{nullptr, lt.s2.p, nullptr, lt.part.p + (size_t)2 * np * Nc};
     ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), ep)));
   }
-#if ZIGP_J_QFORM
   if (need_grad) {
-    // J' = Q A2, Q = Kuu^-1 diag(s^2) - I (M x M, dense): the two triangular products H = W diag(s^2) A2, J' = W^T H - A2 as ONE full
-    // product of the same flop count -- every tile the full k range (no triangular padding, half as many prologues and epilogues per
-    // flop), no H panel written and read back, no operand tile in the epilogue.
+    // J' = Q A2, Q = Kuu^-1 diag(s^2) - I (M x M, dense): the two triangular products H = W diag(s^2) A2, J' = W^T H - A2 of the reverse
+    // pass as ONE full product of the same flop count -- every tile the full k range (no triangular padding, half as many prologues and
+    // epilogues per flop), no H panel written and read back, no operand tile in the epilogue (r4: J' 61.9 -> 70.2 TFLOP/s, step -3.8 %,
+    // profiles/r04ak_ab_qform.log; the two-product form is in tools/r4_experiment_arms.patch).
     TileList tf;
     ZIGP_TRY(tiles_full_xcd(c, nbm, nbn, nbm * (BM / BK), tf));
     ProfScope ps(c, PC_GEMM_J, 2.0 * fl);
-    if (c->jp_wait) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); c->jp_wait = false; }
     ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, tf, mk_args(lt.Qt.p, Mp, lt.A2.p, Nc, lt.Jp.p, Nc), EpiStorePanel())));
-    return 0;
-  }
-#endif
-  if (need_grad) {
-    {
-      ProfScope ps(c, PC_GEMM_H, fl);   // H = (W diag(s^2)) A2
-#if ZIGP_LOWER_VIA_WT
-      ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wpt.p, Mp, lt.A2.p, Nc, lt.H.p, Nc), EpiStore())));
-#else
-      ZIGP_TRY((run_gemm<LAY_KCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wp.p, Mp, lt.A2.p, Nc, lt.H.p, Nc), EpiStore())));
-#endif
-    }
-    {
-      if (c->jp_wait) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); c->jp_wait = false; }   // the previous chunk's kgrads read J' (dense_chunk_loop)
-      ProfScope ps(c, PC_GEMM_J, fl);   // J' = W^T H - A2
-      ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu_lpt, mk_args(lt.W.p, Mp, lt.H.p, Nc, lt.Jp.p, Nc), EpiSubLoad{lt.A2.p})));
-    }
   }
   return 0;
 }
@@ -416,7 +382,7 @@ int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
     if (k.has_rows) {
       ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A2, (size_t)Mp * Nc);
       ZIGP_ENSURE(c, lt.part, (size_t)3 * (Mp / 32) * Nc);
-      if (k.need_grad) { if (!ZIGP_J_QFORM) ZIGP_ENSURE(c, lt.H, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc); }
+      if (k.need_grad) ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc);
     }
     if (k.need_grad) {
       ZIGP_ENSURE(c, lt.du, Mp); ZIGP_ENSURE(c, lt.dsq, Mp); ZIGP_ENSURE(c, lt.krow, (size_t)KG_SPLIT * Mp * (2 + 2 * D));
@@ -438,8 +404,7 @@ int dense_pointwise(zigp_ctx* c, const DenseCall& k, int64_t n0, int64_t Nc) {
   PwArgs a;
   a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32;
   {
-    constexpr int RW2 = Shape<WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false>::value>::RW;
-    constexpr int RW1 = ZIGP_LOWER_VIA_WT ? RW2 : Shape<WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false>::value>::RW;
+    constexpr int RW2 = Shape<WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false>::value>::RW, RW1 = RW2;
     static_assert(RW1 >= 32 && RW2 >= 32, "partial-row planes are allocated for 32-row wave tiles");
     a.np1_f = c->lat[0].Mp / RW1; a.np2_f = c->lat[0].Mp / RW2; a.np1_g = c->lat[1].Mp / RW1; a.np2_g = c->lat[1].Mp / RW2;
   }
@@ -478,7 +443,6 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
   c->prof_skip = c->prof_on && !sampled(row_begin);
   if (!k.prep_side)     // (otherwise built on the third stream under the M x M forward: dense_mxm_forward)
     for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, row_begin, chunk_rows(row_begin), D, k.ell_h[h]));
-  bool kuf_split = false;     // the side stream built the next chunk's Kuf panels BEFORE this chunk's kgrads (ev_kuf, then ev_join)
   for (int64_t n0 = row_begin; n0 < row_end; n0 += Nc_full) {
     const int64_t Nc = chunk_rows(n0);   // the last (partial) chunk shrinks to the next multiple of 1024 rows
     const int64_t n1 = n0 + Nc_full;
@@ -486,11 +450,9 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
     const bool timed = sampled(n0), timed_next = has_next && sampled(n1);
     c->prof_skip = c->prof_on && !timed;
     if (side_busy) {
-      // A1 of this chunk needs the Kuf panels; the previous chunk's kgrads (they read J' and gm) only have to be done before this
-      // chunk's first J' launch (latent_chunk_forward consumes jp_wait)
-      if (kuf_split) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_kuf, 0)); c->jp_wait = true; }
-      else ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0));
-      side_busy = false; kuf_split = false;
+      // A1 of this chunk needs the Kuf panels the side stream built behind the previous chunk's kgrads (which read J' and gm)
+      ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0));
+      side_busy = false;
     }
     for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], Nc, k.need_grad));
     ZIGP_TRY(dense_pointwise(c, k, n0, Nc));
@@ -502,20 +464,9 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
       ZIGP_HIP(c, hipEventRecord(c->ev_fork, c->stream_main));
       ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
       c->stream = c->stream2;
-      // ZIGP_KUF_FIRST (measured, off): the panels first (K is read by A1 only; kgrad recomputes it), because at M = 512 the two kgrads outlast
-      // the two rank-N updates and the next chunk's first product waits 160 us for panels queued behind them.  But a side kernel gets few
-      // workgroup slots beside a rank-N update: the two panel builds then take 260 us each instead of 43, the kgrads slide under the next
-      // chunk's A1 and slow it by 170 us -- cfg2 6.43 -> 6.54 ms.
-#ifndef ZIGP_KUF_FIRST
-#define ZIGP_KUF_FIRST 0
-#endif
-      kuf_split = (ZIGP_KUF_FIRST != 0) && kuf_side && (ZIGP_KGRAD_RECOMPUTE != 0);
-      if (kuf_split) {
-        for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]));
-        ZIGP_HIP(c, hipEventRecord(c->ev_kuf, c->stream2));
-      }
+      // (the next chunk's panels BEFORE this chunk's kgrads was measured and dropped: cfg2 +0.1 ms)
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], k.dX, k.Nrows, n0, Nc, D, k.ell_h[h]));
-      if (kuf_side && !kuf_split)
+      if (kuf_side)
         for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]));
       ZIGP_HIP(c, hipEventRecord(c->ev_join, c->stream2));
       side_busy = true;
@@ -527,13 +478,13 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_syrk(c, c->lat[h], Nc));
     }
     if (has_next && !kuf_side) {   // a timed next chunk gets its panels from the main stream, with the side stream drained
-      if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; kuf_split = false; }
+      if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
       c->prof_skip = c->prof_on && !timed_next;
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]));
     }
   }
   if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
-  c->prof_skip = false; c->jp_wait = false;
+  c->prof_skip = false;
   return 0;
 }
 
@@ -639,8 +590,7 @@ int zigp_create(zigp_ctx** out, int device_id) {
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_prep_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_kuf, hipEventDisableTiming) != hipSuccess) { delete c; return ZIGP_EHIP; }
+      hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipMalloc((void**)&c->d_info, sizeof(int)) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(sizeof(double) * PB * PBLD)) != hipSuccess) { delete c; return ZIGP_EHIP; }
@@ -658,7 +608,7 @@ int zigp_destroy(zigp_ctx* c) {
   if (c->comm) { RcclApi* api = rccl_api(nullptr); if (api) (void)api->CommDestroy(static_cast<ncclComm_t>(c->comm)); c->comm = nullptr; }
   for (int h = 0; h < 2; ++h) {
     Latent& l = c->lat[h];
-    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.H, &l.Jp, &l.Wp, &l.Wt, &l.Wpt, &l.P, &l.Qt, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
+    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.Jp, &l.Wp, &l.Wt, &l.Wpt, &l.P, &l.Qt, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
                     &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec, &l.sk};
     for (DevBuf* b : bs) b->release();
   }
@@ -674,7 +624,6 @@ int zigp_destroy(zigp_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_prep_fork) (void)hipEventDestroy(c->ev_prep_fork);
   if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
-  if (c->ev_kuf) (void)hipEventDestroy(c->ev_kuf);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream_main) (void)hipStreamDestroy(c->stream_main);

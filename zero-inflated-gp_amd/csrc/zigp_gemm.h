@@ -2,29 +2,24 @@
 // product on the zero-inflated-GP ELBO path (replaces TF's MatMul / MatrixTriangularSolve call sites,
 // onofftf/main.py:271,284,287 and their tf.gradients twins, scripts/onoff.py:334).
 //
-// Design (measured on MI355X):
-//   * round 4: a 16 x 16 x 4 product is ONE v_mfma_f64_16x16x4_f64 (ZIGP_MFMA16, below): 77.5 TFLOP/s chip-wide in the VGPR form these
-//     kernels compile to (tools/ubench/mfma_f64_tile.hip, profiles/r04k_ubench_mfma_tile.log); the A operand of a 16-row sub-tile is one
-//     ds_read_b64 per lane (row l % 16, k l / 16), the B operand one (k l / 16, column l % 16), the accumulator element r of lane l is
-//     C[4 r + l / 16][l % 16].
-//   * rounds 1-3 (ZIGP_MFMA16 = 0, kept): the same product as FOUR v_mfma_f64_4x4x4_4b_f64 (~75 TFLOP/s, ~16.9 cycles/instr/SIMD) whose
-//     A operand is a 4-row block read from LDS with the same address in all four 16-lane groups (LDS broadcast is free; cbsz / abid
-//     broadcast is ignored for f64) -- chosen because round 1's rate test showed 16x16x4 at ~50 TFLOP/s, which turned out to measure the
-//     VGPR <-> AGPR copies the compiler had put around every MFMA of that test, not the instruction.
+// Design (measured on MI355X; the measured-and-dropped alternatives live as patches under tools/, see tools/README.md):
+//   * a 16 x 16 x 4 product is ONE v_mfma_f64_16x16x4_f64: 77.5 TFLOP/s chip-wide in the VGPR form these kernels compile to
+//     (tools/ubench/mfma_f64_tile.hip, profiles/r04k_ubench_mfma_tile.log); the A operand of a 16-row sub-tile is one ds_read_b64 per
+//     lane (row l % 16, k l / 16), the B operand one (k l / 16, column l % 16), the accumulator element r of lane l is
+//     C[4 r + l / 16][l % 16].  (Rounds 1-3 issued four v_mfma_f64_4x4x4_4b_f64 instead: tools/r4_experiment_arms.patch.)
 //   * workgroup tile 128x128, BK = 16, as 4 waves (2x2, 64x64 wave tiles, 64 accumulators/lane) or 8 waves
 //     (4x2, 32x64 wave tiles, 32 accumulators/lane); two workgroups share a CU.  MFMA issue is never
 //     dependency-bound (>= 8 independent 16x16 accumulator blocks).
-//   * operand tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into an
-//     NSTAGE-deep ring.  One wave-instruction writes 1 KB linearly, so bank conflicts are removed
+//   * operand tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a
+//     2-deep ring.  One wave-instruction writes 1 KB linearly, so bank conflicts are removed
 //     (a) for k-contiguous tiles ([128 rows][16 k], 8 rows per instruction) by an XOR swizzle of the 16-byte
 //         granule index with (row>>1)&7, applied on the SOURCE address and again on every ds_read
-//         (cdna_hip_programming.md rule 21); the swizzle separates into a per-lane base plus compile-time
-//         offsets, so reads need one (A) / four (B) address registers;
+//         (cdna_hip_programming.md rule 21), plus 16 B of padding in front of every 16-row block (see glds_tile);
 //     (b) for m/n-contiguous tiles ([16 k][128], one k-row per instruction) by giving each row its own
 //         M0 base with a 144-double stride (odd k rows land 128 B further round the banks).
 //     One s_barrier per BK step; counted vmcnt keeps NSTAGE-2 stages in flight across it.
 //   * a workgroup runs a host-built UNIT of list entries (GemmArgs::per consecutive tiles, each with its own k range and k
-//     direction); the default lists are one tile per workgroup in LPT order, see tiles_trmm / tiles_syr2k in zigp_host.h.
+//     direction); the lists are built in zigp_host.h (tiles_trmm / tiles_syr2k / tiles_full_xcd).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,21 +28,6 @@
 namespace zigp {
 
 constexpr int BM = 128, BN = 128, BK = 16;
-// ZIGP_MFMA16 (round 4): the 16 x 16 x 4 products are issued as ONE v_mfma_f64_16x16x4_f64 instead of four v_mfma_f64_4x4x4_4b_f64.
-// Round 1 had measured the 16x16x4 instruction at ~48 TFLOP/s chip-wide and built the core on the 4x4x4 form -- but that microbenchmark's
-// loop copied every accumulator between VGPRs and AGPRs around each MFMA (compiler artefact of its launch bounds); in the VGPR form the
-// kernels here compile to, 16x16x4 sustains 77.5 TFLOP/s (tools/ubench/mfma_f64_tile.hip, profiles/r04k_ubench_mfma_tile.log), and
-// rocBLAS' gfx950 DGEMM kernels (MI16x16x4x1) reach 74-77 TFLOP/s (tools/dgemm_probe.py).  With it the A operand of a 16-row sub-tile is
-// ONE ds_read_b64 per lane (lane -> row l % 16, k l / 16) instead of four broadcast reads, and a BK step issues 64 instead of 256 MFMAs.
-// The accumulator layout is the same (element r of lane l = C[4 r + l / 16][l % 16]), so epilogues are unchanged.
-#ifndef ZIGP_MFMA16
-#define ZIGP_MFMA16 1
-#endif
-#ifndef ZIGP_PIPE_READS
-#define ZIGP_PIPE_READS 2      // hand-pipelined fragment reads (see ds_rd64 below): 2 = the full and the lower-triangular 8-wave m/n-contiguous products
-                               // (A2 = W^T A1 measures 1 % SLOWER with them: profiles/r05h_ab_pipe.log), 1 = all three, 0 = the compiler's order
-
-#endif
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void mfma16(double (&c)[4], double a, double b) {
   mfma_d4 v = {c[0], c[1], c[2], c[3]};
@@ -57,7 +37,7 @@ __device__ __forceinline__ void mfma16(double (&c)[4], double a, double b) {
 // Workgroup shapes (template parameter WAVES of the kernel): WAVES/2 (M) x 2 (N) waves, wave tiles 64 columns wide.
 //   WAVES = 4: wave tile 64x64, 64 accumulators/lane, <= 256 VGPRs, 2 waves/SIMD with 2 workgroups/CU
 //   WAVES = 8: wave tile 32x64, 32 accumulators/lane, <= 128 VGPRs, 4 waves/SIMD with 2 workgroups/CU; triangular
-//              structure is skipped at 32-row granularity
+//              structure is skipped at 16-row granularity (balanced sub-tile pairs, see gemm_tile)
 // Measured on MI355X (cfg3): the 8-wave shape is ~7 % faster where it fits 128 VGPRs without spilling.
 template <int WAVES> struct Shape {
   static constexpr int THREADS = 64 * WAVES;
@@ -70,7 +50,8 @@ template <int WAVES> struct Shape {
   static constexpr int CHUNKS = 16 / WAVES;    // 1 KB staging chunks per wave and operand tile
 };
 constexpr int LDMN = 128 + 16;                    // row stride (doubles) of an m/n-contiguous tile image: odd k rows shift 128 B
-constexpr int TILE_DOUBLES = BK * LDMN;           // 2304 doubles (18 KB) holds either image: [128][16] swizzled or [16][144]
+constexpr int KSUB = 256 + 2;                     // doubles from one 16-row block of a k-contiguous image to the next (16 B of padding, see glds_tile)
+constexpr int TILE_DOUBLES = BK * LDMN;           // 2304 doubles (18 KB) holds either image: [128][16] swizzled + padded, or [16][144]
 constexpr int STAGE_DOUBLES = 2 * TILE_DOUBLES + BK;   // A tile + B tile + one BK-slice of the k-scale vector
 
 // Operand layouts: element (i,k) of A / (k,j) of B
@@ -136,31 +117,6 @@ struct EpiAccum {   // C += alpha*acc
     epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] += v; });
   }
 };
-// ZIGP_J_PREFETCH: the S tile of EpiSubLoad is touched (one 8-byte load per 64-byte segment of this wave's sub-tile, TM * TN / 2 per lane)
-// three staged steps before the tile's k loop ends, and the values are consumed one step later, behind the wait the next stage needs
-// anyway: the epilogue's loads then hit L2.  With the paired tile order all workgroups reach their epilogues together, and a burst of
-// loads from HBM in front of the stores is what made that order lose 4.5 % for J' (DESIGN section 5).
-#ifndef ZIGP_J_PREFETCH
-#define ZIGP_J_PREFETCH 1
-#endif
-struct EpiSubLoad {  // C = alpha*acc - S   (S has C's leading dimension)
-  const double* __restrict__ S;
-  static constexpr bool PREFETCH = ZIGP_J_PREFETCH != 0;
-  template <int TM, int TN>
-  __device__ __forceinline__ void prefetch(const EpiCtx& e, double (&v)[TM * TN / 2]) const {
-    constexpr int SEGS = TN * 2;                     // 64-byte segments per row of the sub-tile
-#pragma unroll
-    for (int q = 0; q < TM * TN / 2; ++q) {
-      const int sidx = e.lane + 64 * q, row = sidx / SEGS, seg = sidx % SEGS;
-      v[q] = S[(e.row0 + (row >> 4) * e.tm_stride + (row & 15)) * e.ldc + e.col0 + seg * 8];
-    }
-  }
-  template <int TM, int TN>
-  __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const {
-    double* __restrict__ C = e.C; const int64_t ld = e.ldc; const double* __restrict__ Sp = S;
-    epi_foreach(acc, e, [&](int64_t i, int64_t j, double v) { C[i * ld + j] = v - Sp[i * ld + j]; });
-  }
-};
 
 // Store + fused column reductions over this wave's 16 * TM rows (GPConditional's reduce_sum over the inducing index,
 // onofftf/main.py:278,287,291,302):   out1[n] = sum_m w1[m] C[m,n]   (skipped if w1 == nullptr)
@@ -207,15 +163,9 @@ struct EpiStoreColsum {
   }
 };
 
-// k-contiguous image swizzle: granule position = (k>>1) ^ kswz(row).  kswz takes 4 distinct values on any 4 consecutive
-// rows 4r..4r+3 (the A-operand broadcast read of one 16-lane group) and 8 distinct values on the even and on the odd
-// rows of any aligned group of 16 (the B-operand read of a 32-lane group): both reads are bank-conflict free.
-// (measured: this map for A tiles, the plain (row>>1)&7 map for B tiles -- the B read of 16 rows per 16-lane group
-// prefers the latter once the compiler pairs reads into ds_read2_b64)
-template <bool NEWMAP> __device__ __forceinline__ int kswz(int row) {
-  return NEWMAP ? ((row & 3) ^ (((row >> 2) & 1) << 2) ^ ((row >> 3) & 1)) : ((row >> 1) & 7);
-}
-
+// k-contiguous image swizzle: granule position = (k>>1) ^ kswz(row).  kswz takes 8 distinct values on the even and on the odd rows of
+// any aligned group of 16 (the read of 16 rows x 4 k by one wave, both operand roles): bank-conflict free.
+__device__ __forceinline__ int kswz(int row) { return (row >> 1) & 7; }
 
 // Staging addresses.  A global_load_lds takes (scalar base) + (32-bit per-lane byte offset).  The per-lane offset of this wave's FIRST
 // 1 KB chunk is computed once per tile; its other 16 / WAVES - 1 chunks lie a uniform distance further on (chunk c = WAVES p + wave holds
@@ -223,24 +173,17 @@ template <bool NEWMAP> __device__ __forceinline__ int kswz(int row) {
 // m/n-contiguous one), which goes into the SCALAR base: one offset register per operand instead of 16 / WAVES.  The scalar base
 // advances by a constant each BK step, and the LDS destination (M0) is scalar arithmetic on the wave id -- no per-step vector address
 // math (glds_pin below is what makes the compiler keep it that way).
-template <int LAY, int WAVES, bool NEWMAP>
+template <int LAY, int WAVES>
 __device__ __forceinline__ uint32_t glds_lane_offset(int64_t ld, int wave, int lane) {
   if (LAY == LAY_KCONTIG) {                           // chunk = rows 8c..8c+7, lane -> (row, granule position)
     const int row = 8 * wave + (lane >> 3), gp = lane & 7;
-    const int g = gp ^ kswz<NEWMAP>(row);
+    const int g = gp ^ kswz(row);
     return (uint32_t)((row * ld + 2 * g) * 8);
   }
   return (uint32_t)((wave * ld + 2 * lane) * 8);      // chunk = k-row c, lane -> granule
 }
 template <int LAY, int WAVES>
 __device__ __forceinline__ int64_t glds_chunk_stride(int64_t ld) { return (LAY == LAY_KCONTIG ? 8 * WAVES : WAVES) * ld * 8; }
-// BPAD: a k-contiguous B image gets 2 doubles (16 B) of padding in front of every 16-row block.  The four B fragments of a k-step
-// (tn = 0..3) then sit 2064 B apart -- beyond the 2040-B reach of ds_read2_b64 and not a multiple of 512 B (ds_read2st64_b64) --
-// so the compiler must issue them as single ds_read_b64, which take the conflict-free 64-bank path (the paired form reads two
-// 16-lane groups per cycle on a 32-bank mapping: 49 % of the LDS cycles of the rank-N update were bank conflicts).
-#ifndef ZIGP_BPAD
-#define ZIGP_BPAD 1
-#endif
 // The uniform part of a staging address, pinned in a scalar register pair.  Without this the loop optimiser turns (uniform base that
 // advances per BK step) + (per-lane offset) into one 64-bit per-lane pointer PER LOAD as its induction variables: 2 VGPRs and two
 // v_lshl_add_u64 per load and step (18 VGPRs and 18 64-bit VALU adds per BK step in the 4-wave kernels; fp64 MFMAs do not overlap with
@@ -252,32 +195,23 @@ __device__ __forceinline__ const char* glds_pin(const char* p) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
   return (const char*)(((uint64_t)hi << 32) | lo);
 }
-template <int LAY, int WAVES, bool PAD = false>
+// A k-contiguous image gets 2 doubles (16 B) of padding in front of every 16-row block.  The four fragments of a k-step then sit
+// 2064 B apart -- beyond the 2040-B reach of ds_read2_b64 and not a multiple of 512 B (ds_read2st64_b64) -- so the compiler must
+// issue them as single ds_read_b64, which take the conflict-free 64-bank path (the paired form reads two 16-lane groups per cycle on a
+// 32-bank mapping: 49 % of the LDS cycles of the rank-N update were bank conflicts).
+template <int LAY, int WAVES>
 __device__ __forceinline__ void glds_tile(double* tile, const char* __restrict__ base, uint32_t off, int64_t chunk_stride, int wave) {
   asm volatile("" : "+v"(off));   // keeps the 32 -> 64 bit extension of the offset next to the load (instruction selection works per
                                   // block: hoisted out of the loop, the extension hides that the offset is 32 bits wide)
 #pragma unroll
   for (int p = 0; p < 16 / WAVES; ++p) {
     const int c = WAVES * p + wave;
-    double* dst = tile + ((LAY == LAY_KCONTIG) ? c * 128 + (PAD ? (c >> 1) * 2 : 0) : c * LDMN);
+    double* dst = tile + ((LAY == LAY_KCONTIG) ? c * 128 + (c >> 1) * 2 : c * LDMN);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(glds_pin(base + p * chunk_stride) + (uint64_t)off),
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
 }
 
-template <int ALAY, bool NEWMAP>
-__device__ __forceinline__ int a_read_off(const int (&a_base)[4], int tm, int r, int ks) {
-  if (ALAY == LAY_KCONTIG) {
-    if (!NEWMAP) return a_base[0] + (tm * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r));   // (row>>1)&7 map: fully separable
-    const int X = (2 * ks) ^ (4 * (r & 1) + (r >> 1));
-    return a_base[X & 3] + (tm * 16 + 4 * r) * 16 + 2 * (X & ~3);
-  }
-  return a_base[0] + ks * 4 * LDMN + tm * 16 + 4 * r;
-}
-
-// does this epilogue want its extra operand tile touched ahead of time (EpiSubLoad::PREFETCH)?
-template <class E> constexpr auto epi_prefetches(int) -> decltype(E::PREFETCH) { return E::PREFETCH; }
-template <class E> constexpr bool epi_prefetches(long) { return false; }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ---- hand-pipelined fragment reads (round 5) ----------------------------------------------------------------------------------------
@@ -287,9 +221,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // own s_waitcnt insertion does not see them, so the waits are exactly the ones written here -- the MFMAs stay builtins (the compiler keeps
 // their hazards) and sched_barrier fences pin the order.  tools/ubench/gemm_lab.hip is where the form was developed and measured
 // (profiles/r05*_gemm_lab_*.log: +1.1 % on the full product; wider reads, fewer reads, an early barrier, cross-tile prefetch, staggered
-// tile boundaries and a column-strip wave shape were measured there too and do not pay).  The same treatment of the 4-wave k-contiguous
-// k-scaled kernel (the symmetric rank-N update) is 1.3 % SLOWER than the compiler's order (61.9 vs 62.7 TFLOP/s, profiles/r05i_ab_syrk_pipe.log;
-// the change is tools/syrk_pipe_experiment.patch).
+// tile boundaries and a column-strip wave shape were measured there too and do not pay).  Used for the full (J' = Q A2) and the
+// lower-triangular (A1 = W K) 8-wave m/n-contiguous products: J' 70.2 -> 71.2, A1 64.5 -> 65.1 TFLOP/s, step -0.55 % same-box; the
+// upper-triangular product (A2 = W^T A1) measures 1 % SLOWER with it and keeps the compiler's order (profiles/r05h_ab_pipe.log), and so
+// does the 4-wave k-contiguous k-scaled kernel (the symmetric rank-N update: 61.9 vs 62.7 TFLOP/s, profiles/r05i_ab_syrk_pipe.log; the
+// change is tools/syrk_pipe_experiment.patch).
 template <int N> struct IC { static constexpr int value = N; };
 template <int B, int E, class F> __device__ __forceinline__ void sfor(F f) { if constexpr (B < E) { f(IC<B>{}); sfor<B + 1, E>(f); } }
 template <int OFF> __device__ __forceinline__ double ds_rd64(uint32_t a) {    // a: LDS byte address of this lane, OFF: compile-time byte offset
@@ -299,7 +235,7 @@ template <int OFF> __device__ __forceinline__ double ds_rd64(uint32_t a) {    //
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ uint32_t lds_addr(const double* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)p; }
 
-// TRI: triangular structure exploited at wave granularity inside diagonal blocks (64 rows in the 4-wave, 32 rows in the 8-wave shape).
+// TRI: triangular structure exploited at wave granularity inside diagonal blocks.
 // r3, measured and removed: peeling the diagonal 128 x 128 block of the triangular factor into a tail of 8 steps with 16-row granularity
 // (sub-tile rows dealt out round-robin over the waves along M so that they stay balanced; the wave row a template parameter, the tail
 // straight-line code) executes 1.016 instead of 1.03-1.06 x the algorithmic MFMAs and was 3 % SLOWER per step (193.4 vs 187.8 ms, same
@@ -316,34 +252,26 @@ enum { TRI_NONE = 0,
 // useful work, in the time of a full tile.  Here only ONE operand tile is needed per BK step, and the 36 lower 16 x 16 sub-tiles (8 x 8
 // grid, diagonal included) are dealt out 9 per wave: wave w owns the sub-tile rows w and 7 - w, i.e. w + 1 and 8 - w column sub-tiles.
 // The wave index is a template parameter (the four instantiations sit behind one scalar switch): every loop bound is a compile-time
-// constant.  36 accumulators, 8 A and <= 8 B fragments per k-step: ~120 VGPRs inside a kernel that holds ~200 anyway.
+// constant.  36 accumulators, 2 A and <= 8 B fragments per k-step inside a kernel that holds ~170 VGPRs anyway.
 // A ring stage has room for two operand tiles, so a step of this path covers TWO BK slices (the second one in the B slot; the k-scale
 // slices ride in the spare 2 KB behind each image): half the barriers and staging waits per MFMA of the generic path, which is what
 // brings a diagonal tile down to ~0.6 of a full tile's time.  The host gives diagonal tiles k ranges twice as long as the others'
 // (tiles_syr2k): both kinds of workgroup then finish together, and every XCD's tiles stay inside one window of k.
-#ifndef ZIGP_SYRK_DIAG
-#define ZIGP_SYRK_DIAG 1
-#endif
 template <int W, int NSTAGE, bool KSCALE, class Epi>
 __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile& tl, double* lds, int wave, int lane, const Epi& epi) {
   constexpr int WAVES = 4, CHUNKS = Shape<WAVES>::CHUNKS;
   constexpr int R1 = W, R2 = 7 - W, NC1 = W + 1, NC2 = 8 - W;   // this wave's two sub-tile rows and the column sub-tiles 0..NC-1 each needs
-#ifndef ZIGP_DIAG_PAD
-#define ZIGP_DIAG_PAD 1
-#endif
-  constexpr bool DPAD = (ZIGP_DIAG_PAD != 0) && (ZIGP_MFMA16 != 0) && (ZIGP_BPAD != 0);   // 16 B in front of every 16-row block, as for the B images of the generic path
-  constexpr int SUB = DPAD ? 258 : 256;                          // doubles from one 16-row block of the image to the next
   constexpr int SCALE_OFF = 128 * 16 + 16;                       // k-scale slice of an image: behind its 2048 (+ 16 of padding) doubles (TILE_DOUBLES = 2304)
   static_assert(TILE_DOUBLES >= SCALE_OFF + BK, "no room for the k-scale slice behind the operand image");
   const GemmSeg& sg = g.seg[0];
   int ln = lane;
   asm volatile("" : "+v"(ln));
-  const int a_i = ln & 3, kq = ln >> 4, b_j = ln & 15;
-  // element (row, k) of the swizzled [128][16] image: row * 16 + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)   (kswz<false>, both roles)
-  const int a_base = a_i * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1);
+  const int kq = ln >> 4, b_j = ln & 15;
+  // element (row, k) of the swizzled, padded [128][16] image: (row / 16) * 2 + row * 16 + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1); one read
+  // serves both operand roles (lane -> row b_j of a 16-row block, k = 4 ks + kq)
   int b_base[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) b_base[ks] = b_j * 16 + 2 * (((2 * ks) | (kq >> 1)) ^ kswz<false>(b_j)) + (kq & 1);
+  for (int ks = 0; ks < 4; ++ks) b_base[ks] = b_j * 16 + 2 * (((2 * ks) | (kq >> 1)) ^ kswz(b_j)) + (kq & 1);
   double acc1[1][NC1][4], acc2[1][NC2][4];
 #pragma unroll
   for (int c = 0; c < NC1; ++c)
@@ -355,7 +283,7 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
     for (int r = 0; r < 4; ++r) acc2[0][c][r] = 0.0;
   const int total = tl.kend - tl.kbeg;          // BK slices of this tile
   const int nsteps = (total + 1) / 2;           // two slices per step; a last odd slice stands alone
-  const uint32_t offA = glds_lane_offset<LAY_KCONTIG, WAVES, false>(sg.lda, wave, ln);
+  const uint32_t offA = glds_lane_offset<LAY_KCONTIG, WAVES>(sg.lda, wave, ln);
   const int64_t csA = glds_chunk_stride<LAY_KCONTIG, WAVES>(sg.lda);
   const int64_t row0 = (int64_t)tl.bi * BM;
   const int kb0 = (tl.kdir >= 0) ? tl.kbeg : tl.kend - 1;
@@ -364,7 +292,7 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
   const char* baseS = (const char*)(g.kscale + kfirst);
   const int64_t strideA = kd * BK * 8;
   auto issue_slice = [&](double* img, int sl) {   // BK slice `sl` of the tile's k range into the image at img
-    glds_tile<LAY_KCONTIG, WAVES, DPAD>(img, baseA + sl * strideA, offA, csA, wave);
+    glds_tile<LAY_KCONTIG, WAVES>(img, baseA + sl * strideA, offA, csA, wave);
     if (KSCALE) {
       uint32_t so = 16 * ln;
       asm volatile("" : "+v"(so));
@@ -383,37 +311,20 @@ __device__ __forceinline__ void syrk_diag_tile(const GemmArgs& g, const GemmTile
   auto slice_mfma = [&](const double* As) {
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-      double bf[NC2], af1[4], af2[4];
+      double bf[NC2];
 #pragma unroll
-      for (int c = 0; c < NC2; ++c) bf[c] = As[b_base[ks] + c * SUB];
+      for (int c = 0; c < NC2; ++c) bf[c] = As[b_base[ks] + c * KSUB];
       if (KSCALE) {
         const double sc = As[SCALE_OFF + ks * 4 + kq];
 #pragma unroll
         for (int c = 0; c < NC2; ++c) bf[c] *= sc;
       }
-      if constexpr (ZIGP_MFMA16 != 0) {
-        // the A operand of sub-tile row R is the SAME read as the B operand of column sub-tile R (one image, both roles): lane -> (row, k)
-        (void)af1; (void)af2;
-        const double a2 = As[b_base[ks] + R2 * SUB], a1 = As[b_base[ks] + R1 * SUB];
+      // the A operand of sub-tile row R is the SAME read as the B operand of column sub-tile R (one image, both roles): lane -> (row, k)
+      const double a2 = As[b_base[ks] + R2 * KSUB], a1 = As[b_base[ks] + R1 * KSUB];
 #pragma unroll
-        for (int c = 0; c < NC2; ++c) mfma16(acc2[0][c], a2, bf[c]);
+      for (int c = 0; c < NC2; ++c) mfma16(acc2[0][c], a2, bf[c]);
 #pragma unroll
-        for (int c = 0; c < NC1; ++c) mfma16(acc1[0][c], a1, bf[c]);
-      } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        af1[r] = As[a_base + (R1 * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r))];
-        af2[r] = As[a_base + (R2 * 16 + 4 * r) * 16 + 2 * ((2 * ks) ^ (2 * r))];
-      }
-#pragma unroll
-      for (int c = 0; c < NC2; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc2[0][c][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af2[r], bf[c], acc2[0][c][r], 0, 0, 0);
-#pragma unroll
-      for (int c = 0; c < NC1; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc1[0][c][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af1[r], bf[c], acc1[0][c][r], 0, 0, 0);
-      }
+      for (int c = 0; c < NC1; ++c) mfma16(acc1[0][c], a1, bf[c]);
     }
   };
 #pragma unroll
@@ -439,53 +350,33 @@ template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, int WAVES, class
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl, double* lds, int wave, int wm, int wn, int lane, const Epi& epi) {
   constexpr int WTN = Shape<WAVES>::WTN, TNW = Shape<WAVES>::TNW, CHUNKS = Shape<WAVES>::CHUNKS;
   constexpr int RW = Shape<WAVES>::RW, TMW = Shape<WAVES>::TMW, WMW = Shape<WAVES>::WMW;
-  // the 4-base A map costs 3 VGPRs more: used where the B tile is m/n-contiguous (1 base register), not in the K/K kernels
-#ifndef ZIGP_KK_NEWMAP
-#define ZIGP_KK_NEWMAP 0
-#endif
-  constexpr bool M16 = ZIGP_MFMA16 != 0;
-  // 16x16x4 form: a k-contiguous A image is read exactly as a k-contiguous B image (16 rows x 4 k per wave read): the plain map, padded
-  constexpr bool A_NEWMAP = !M16 && ((BLAY == LAY_MNCONTIG) || (ZIGP_KK_NEWMAP != 0 && KSCALE && TRI == TRI_C_LOWER));   // (the rank-N update only: the O(M^3) K/K products spill with it)
-  constexpr bool A_PAD = M16 && (ZIGP_BPAD != 0) && (ALAY == LAY_KCONTIG);
-  constexpr bool B_PAD = (ZIGP_BPAD != 0) && (BLAY == LAY_KCONTIG);
   const GemmSeg& sg = g.seg[0];
   const int64_t row0 = (int64_t)tl.bi * BM, col0 = (int64_t)tl.bj * BN;
   // Everything derived from the lane id is recomputed per tile from an opaque copy: otherwise the compiler keeps the ~16
   // address registers alive across the epilogue of the previous tile and spills there.
   int ln = lane;
   asm volatile("" : "+v"(ln));
-  const int a_i = ln & 3, kq = ln >> 4, b_j = ln & 15;
-  // ZIGP_TRI_BALANCE: in the 8-wave triangular products wave (wm, wn) owns the 16-row sub-tiles wm and 7 - wm of the row block instead of
-  // the rows 32 wm .. 32 wm + 31.  Inside the DIAGONAL block of the triangular factor, sub-tile t needs the staged steps s <= t (lower) or
+  const int kq = ln >> 4, b_j = ln & 15;
+  // Balanced diagonal blocks: in the 8-wave triangular products wave (wm, wn) owns the 16-row sub-tiles wm and 7 - wm of the row block instead
+  // of the rows 32 wm .. 32 wm + 31.  Inside the DIAGONAL block of the triangular factor, sub-tile t needs the staged steps s <= t (lower) or
   // s >= t (upper) only; with contiguous rows and skipping per wave, wave row 3 works through all 8 steps of that block while wave row 0
   // idles after 2 -- a diagonal block costs the workgroup 8 step times for 62 % of the MFMAs.  With the pairs (t, 7 - t) every wave has
   // 9 sub-tile steps there and the step times are 2,2,2,2,1,1,1,1 halves = 6 instead of 8 (tiles are 1-8 blocks long, one of them diagonal).
-#ifndef ZIGP_TRI_BALANCE
-#define ZIGP_TRI_BALANCE 1
-#endif
-  constexpr bool TRI_BAL = (ZIGP_TRI_BALANCE != 0) && M16 && WAVES == 8 && ALAY == LAY_MNCONTIG && (TRI == TRI_A_LOWER || TRI == TRI_A_UPPER);
+  constexpr bool TRI_BAL = WAVES == 8 && ALAY == LAY_MNCONTIG && (TRI == TRI_A_LOWER || TRI == TRI_A_UPPER);
   const int wrow = TRI_BAL ? 16 * wm : wm * RW;     // row (within the 128-row block) of this wave's sub-tile tm = 0
   const int tm_stride = TRI_BAL ? 16 * (7 - 2 * wm) : 16;   // rows from sub-tile tm = 0 to tm = 1
-  // per-lane LDS read bases; the (tm, r, tn, ks) parts are compile-time offsets (see header comment)
-  // k-contiguous A: granule = (2ks | kq>>1) ^ a_i ^ C(r), C(r) = 4(r&1) + (r>>1)  ->  [(2ks ^ C(r)) & ~3] is a compile-time
-  // offset and the low two bits select one of four per-lane bases a_base[x] = ... + 2*((a_i ^ (kq>>1)) ^ x)
+  // per-lane LDS read bases; the (tm, tn, ks) parts are compile-time offsets (see header comment).  lane -> (row wrow + b_j, k = 4 ks + kq)
+  // of the A image and (k = 4 ks + kq, column wn * 64 + b_j) of the B image; one base per k-step for a k-contiguous image, one in all for an
+  // m/n-contiguous one; the 16-row / 16-column sub-tile is a compile-time offset
   int a_base_[4];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
-    a_base_[x] = (ALAY == LAY_KCONTIG) ? (A_NEWMAP ? ((wrow + a_i) * 16 + 2 * ((a_i ^ (kq >> 1)) ^ x) + (kq & 1))
-                                                    : ((wrow + a_i) * 16 + 2 * ((kq >> 1) ^ (a_i >> 1)) + (kq & 1)))
-                                      : (kq * LDMN + wrow + a_i);
-  // 16x16x4 form: lane -> (row wrow + b_j, k = 4 ks + kq) of the A image; one base per k-step for a k-contiguous image (as for B), one in all
-  // for an m-contiguous one; the 16-row sub-tile tm is a compile-time offset
-  int a16_base_[4];
-#pragma unroll
   for (int ks = 0; ks < 4; ++ks)
-    a16_base_[ks] = (ALAY == LAY_KCONTIG) ? ((wrow + b_j) * 16 + (A_PAD ? (wrow / 16) * 2 : 0) + 2 * (((2 * ks) | (kq >> 1)) ^ kswz<false>(b_j)) + (kq & 1))
-                                         : (kq * LDMN + wrow + b_j + ks * 4 * LDMN);
+    a_base_[ks] = (ALAY == LAY_KCONTIG) ? ((wrow + b_j) * 16 + (wrow / 16) * 2 + 2 * (((2 * ks) | (kq >> 1)) ^ kswz(b_j)) + (kq & 1))
+                                       : (kq * LDMN + wrow + b_j + ks * 4 * LDMN);
   int b_base_[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
-    b_base_[ks] = (BLAY == LAY_KCONTIG) ? ((wn * WTN + b_j) * 16 + (B_PAD ? wn * (WTN / 16) * 2 : 0) + 2 * (((2 * ks) | (kq >> 1)) ^ kswz<false>(b_j)) + (kq & 1))
+    b_base_[ks] = (BLAY == LAY_KCONTIG) ? ((wn * WTN + b_j) * 16 + wn * (WTN / 16) * 2 + 2 * (((2 * ks) | (kq >> 1)) ^ kswz(b_j)) + (kq & 1))
                                        : (kq * LDMN + wn * WTN + b_j + ks * 4 * LDMN);
 
   double acc[TMW][TNW][4];
@@ -495,13 +386,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
     for (int b = 0; b < TNW; ++b)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.0;
-  constexpr bool EPI_PF = epi_prefetches<Epi>(0);
-  double pfv[TMW * TNW / 2];
-#pragma unroll
-  for (int q = 0; q < TMW * TNW / 2; ++q) pfv[q] = 0.0;
 
   const int total = tl.kend - tl.kbeg;       // BK steps of this tile
-  const uint32_t offA = glds_lane_offset<ALAY, WAVES, A_NEWMAP>(sg.lda, wave, ln), offB = glds_lane_offset<BLAY, WAVES, false>(sg.ldb, wave, ln);
+  const uint32_t offA = glds_lane_offset<ALAY, WAVES>(sg.lda, wave, ln), offB = glds_lane_offset<BLAY, WAVES>(sg.ldb, wave, ln);
   const int64_t csA = glds_chunk_stride<ALAY, WAVES>(sg.lda), csB = glds_chunk_stride<BLAY, WAVES>(sg.ldb);
   // scalar bases of BK step 0 and their per-step strides (bytes)
   const int kb0 = (tl.kdir >= 0) ? tl.kbeg : tl.kend - 1;   // k block (units of BK) of BK step 0; step `it` is kb0 + kdir * it
@@ -515,8 +402,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 
   auto issue = [&](int it) {
     double* st = lds + (it % NSTAGE) * STAGE_DOUBLES;
-    glds_tile<ALAY, WAVES, A_PAD>(st, baseA + it * strideA, offA, csA, wave);
-    glds_tile<BLAY, WAVES, B_PAD>(st + TILE_DOUBLES, baseB + it * strideB, offB, csB, wave);
+    glds_tile<ALAY, WAVES>(st, baseA + it * strideA, offA, csA, wave);
+    glds_tile<BLAY, WAVES>(st + TILE_DOUBLES, baseB + it * strideB, offB, csB, wave);
     if (KSCALE) {   // 16 doubles of the scale vector; every wave issues the same 128 B (uniform vmcnt accounting)
       uint32_t so = 16 * ln;
       asm volatile("" : "+v"(so));
@@ -533,81 +420,27 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 
   // stage `it` must have landed (at most NSTAGE-2 younger stages may stay in flight), every wave is done with the stage about to be
   // overwritten, then the next stage is requested: one barrier per BK step
-  // ZIGP_KO_*: knock-out switches for TIMING experiments (results are wrong with any of them): what does the barrier, the epilogue, the
-  // LDS fragment traffic cost?  (profiles/r04u_knockout.log)
-#ifndef ZIGP_KO_BARRIER
-#define ZIGP_KO_BARRIER 0
-#endif
-#ifndef ZIGP_KO_EPI
-#define ZIGP_KO_EPI 0
-#endif
-#ifndef ZIGP_KO_LDS
-#define ZIGP_KO_LDS 0
-#endif
-#ifndef ZIGP_KO_GLDS
-#define ZIGP_KO_GLDS 0
-#endif
   auto stage_step = [&](int it) -> const double* {
-    if (!(ZIGP_KO_GLDS && TRI != TRI_NONE)) { if (it + NSTAGE - 2 < total) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>(); }
-    if (!(ZIGP_KO_BARRIER && TRI != TRI_NONE)) __builtin_amdgcn_s_barrier();      // (TRI != TRI_NONE: the chunk-loop kernels only -- the M x M stage must stay correct, or its Cholesky fails)
-    if (!(ZIGP_KO_GLDS && TRI != TRI_NONE) && it + NSTAGE - 1 < total) issue(it + NSTAGE - 1);
+    if (it + NSTAGE - 2 < total) wait_vmcnt<GLDS_PER_STAGE * (NSTAGE - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (it + NSTAGE - 1 < total) issue(it + NSTAGE - 1);
     return lds + (it % NSTAGE) * STAGE_DOUBLES;
   };
-  // One BK step of this wave's RW x 64 sub-tile, fully unrolled.  The loop has ONE body (runtime predicates inside the unrolled nest,
-  // and a choice of bodies, spill and pessimise its schedule: the 4-wave kernels sit close to 256 VGPRs).
-#ifndef ZIGP_KK_PIPE
-#define ZIGP_KK_PIPE 0
-#endif
-  auto body = [&](const double* As, auto mask_c) {     // mask_c: which of the wave's sub-tile rows take part (bit tm; M16 form only)
+  // One BK step of this wave's RW x 64 sub-tile, fully unrolled.  The loop has ONE body per statement (runtime predicates inside the
+  // unrolled nest, and a choice of bodies, spill and pessimise its schedule).
+  auto body = [&](const double* As, auto mask_c) {     // mask_c: which of the wave's sub-tile rows take part (bit tm)
     constexpr int MASK = decltype(mask_c)::value;
     const double* Bs = As + TILE_DOUBLES;
     const int (&a_base)[4] = a_base_; const int (&b_base)[4] = b_base_;
-    if constexpr (ZIGP_KK_PIPE != 0 && WAVES == 4 && ALAY == LAY_KCONTIG && BLAY == LAY_KCONTIG && KSCALE && TRI == TRI_C_LOWER) {
-      // explicit two-deep fragment pipeline of the k-contiguous / k-contiguous kernels (the symmetric rank-N update): the 20 LDS reads of
-      // k-step ks + 1 are issued one per three MFMAs of k-step ks (sched_group_barrier), into the other fragment set
-      double afb[2][TMW][4], bfb[2][TNW];
-      auto load = [&](int ks, double (&af)[TMW][4], double (&bf)[TNW]) {
-#pragma unroll
-        for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + tn * (B_PAD ? 258 : 256)];
-#pragma unroll
-        for (int tm = 0; tm < TMW; ++tm)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) af[tm][r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
-        if (KSCALE) {
-          const double sc = As[2 * TILE_DOUBLES + ks * 4 + kq];
-#pragma unroll
-          for (int tn = 0; tn < TNW; ++tn) bf[tn] *= sc;
-        }
-      };
-      load(0, afb[0], bfb[0]);
-#pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        if (ks + 1 < BK / 4) load(ks + 1, afb[(ks + 1) & 1], bfb[(ks + 1) & 1]);
-#pragma unroll
-        for (int tm = 0; tm < TMW; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TNW; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(afb[ks & 1][tm][r], bfb[ks & 1][tn], acc[tm][tn][r], 0, 0, 0);
-        if (ks + 1 < BK / 4) {
-#pragma unroll
-          for (int i = 0; i < TMW * 4 + TNW + (KSCALE ? 1 : 0); ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);    // three MFMAs
-          }
-        }
-      }
-      return;
-    }
-    if constexpr (M16 && WAVES == 8 && ALAY == LAY_MNCONTIG && BLAY == LAY_MNCONTIG && !KSCALE && ZIGP_PIPE_READS != 0 && !(ZIGP_PIPE_READS == 2 && TRI == TRI_A_UPPER)) {
-      // the chunk loop's products (A1 = W K, A2 = W^T A1, J' = Q A2 and the predictive ones): fragment reads one k-step ahead, see above
+    if constexpr (WAVES == 8 && ALAY == LAY_MNCONTIG && BLAY == LAY_MNCONTIG && !KSCALE && TRI != TRI_A_UPPER) {
+      // the chunk loop's full and lower-triangular products (J' = Q A2, A1 = W K, and the predictive ones): fragment reads one k-step
+      // ahead of the MFMAs, see ds_rd64 above
       constexpr int NA = (MASK & 1) + ((MASK >> 1) & 1);
       static_assert(TMW == 2, "8-wave shape: two sub-tile rows per wave");
       constexpr int NRD = NA + TNW;
-      const uint32_t aa0 = lds_addr(As) + 8u * (uint32_t)a16_base_[0];                       // sub-tile tm = 0 of k-step 0
+      const uint32_t aa0 = lds_addr(As) + 8u * (uint32_t)a_base[0];                          // sub-tile tm = 0 of k-step 0
       const uint32_t aa1 = aa0 + 8u * (uint32_t)(TRI_BAL ? tm_stride : 16);                  // sub-tile tm = 1
-      const uint32_t ba = lds_addr(Bs) + 8u * (uint32_t)b_base_[0];
+      const uint32_t ba = lds_addr(Bs) + 8u * (uint32_t)b_base[0];
       double af[2][TMW], bf[2][TNW];
       auto load = [&](auto ks_, auto set_) {
         constexpr int ks = decltype(ks_)::value, set = decltype(set_)::value;
@@ -630,109 +463,31 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
       });
       return;
     }
-    if constexpr (M16) {
-      const int (&a16_base)[4] = a16_base_;
-      // ZIGP_M16_PREFETCH (measured, off): two fragment sets, the LDS reads of k-step ks + 1 pinned IN FRONT of the MFMAs of k-step ks by a
-      // sched_barrier.  Left to itself the compiler reads a k-step's fragments, waits for all of them (s_waitcnt lgkmcnt(0)) and only then
-      // issues its 8 / 16 MFMAs; with the prefetch it still waits with lgkmcnt(0) -- now also for the reads it has just issued -- and the
-      // triangular products lose 1 % (61.8 vs 62.4 TFLOP/s, profiles/r04t_ab_prefetch.log): with 4 waves per SIMD the LDS latency of a
-      // k-step is already covered by the other waves.  Partial waits would need the reads in inline assembly.
-#ifndef ZIGP_M16_PREFETCH
-#define ZIGP_M16_PREFETCH 0
-#endif
-      double bfb[2][TNW], afb[2][TMW];
-      auto load = [&](int ks, double (&af)[TMW], double (&bf)[TNW]) {
-        if (ZIGP_KO_LDS && TRI != TRI_NONE) {      // no LDS traffic: operands from registers (values that the compiler cannot fold)
-#pragma unroll
-          for (int tn = 0; tn < TNW; ++tn) { bf[tn] = __builtin_amdgcn_readfirstlane(ks + tn) * 1e-3 + acc[0][tn][0] * 1e-300; }
-#pragma unroll
-          for (int tm = 0; tm < TMW; ++tm) { af[tm] = (double)(ks + tm) * 1e-3 + acc[tm][0][1] * 1e-300; }
-          return;
-        }
-#pragma unroll
-        for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * (B_PAD ? 258 : 256) : tn * 16)];
-#pragma unroll
-        for (int tm = 0; tm < TMW; ++tm)
-          if ((MASK >> tm) & 1) af[tm] = As[a16_base[ks] + ((ALAY == LAY_KCONTIG) ? tm * (A_PAD ? 258 : 256) : (TRI_BAL ? tm * tm_stride : tm * 16))];
-        if (KSCALE) {
-          const double sc = As[2 * TILE_DOUBLES + ks * 4 + kq];
-#pragma unroll
-          for (int tn = 0; tn < TNW; ++tn) bf[tn] *= sc;
-        }
-      };
-      if (ZIGP_M16_PREFETCH) load(0, afb[0], bfb[0]);
-#pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        if (ZIGP_M16_PREFETCH) {
-          if (ks + 1 < BK / 4) load(ks + 1, afb[(ks + 1) & 1], bfb[(ks + 1) & 1]);
-          __builtin_amdgcn_sched_barrier(0);      // the reads stay IN FRONT of this k-step's MFMAs (the scheduler otherwise sinks them to where their values are used)
-        } else load(ks, afb[ks & 1], bfb[ks & 1]);
-#pragma unroll
-        for (int tm = 0; tm < TMW; ++tm)
-          if ((MASK >> tm) & 1) {
-#pragma unroll
-            for (int tn = 0; tn < TNW; ++tn) mfma16(acc[tm][tn], afb[ks & 1][tm], bfb[ks & 1][tn]);
-          }
-      }
-      return;
-    }
+    // every other kernel: the compiler's order (a k-step's reads, s_waitcnt lgkmcnt(0), its MFMAs; with 4 waves per SIMD the other waves
+    // cover the wait)
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-      const int k = ks * 4 + kq;
-      double bf[TNW];
+      double bf[TNW], af[TMW];
 #pragma unroll
-      for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * (B_PAD ? 258 : 256) : tn * 16)];
+      for (int tn = 0; tn < TNW; ++tn) bf[tn] = Bs[b_base[ks] + ((BLAY == LAY_KCONTIG) ? tn * KSUB : tn * 16)];
+#pragma unroll
+      for (int tm = 0; tm < TMW; ++tm)
+        if ((MASK >> tm) & 1) af[tm] = As[a_base[ks] + ((ALAY == LAY_KCONTIG) ? tm * KSUB : (TRI_BAL ? tm * tm_stride : tm * 16))];
       if (KSCALE) {
-        const double sc = As[2 * TILE_DOUBLES + k];
+        const double sc = As[2 * TILE_DOUBLES + ks * 4 + kq];
 #pragma unroll
         for (int tn = 0; tn < TNW; ++tn) bf[tn] *= sc;
       }
-      if (WAVES == 4) {
-        // all A fragments of this k-step are requested before the first MFMA (the MFMAs that follow cover the LDS latency of
-        // the next k-step's reads, which the compiler hoists above them)
-        double af[TMW][4];
 #pragma unroll
-        for (int tm = 0; tm < TMW; ++tm)
+      for (int tm = 0; tm < TMW; ++tm)
+        if ((MASK >> tm) & 1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            af[tm][r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
-#pragma unroll
-        for (int tm = 0; tm < TMW; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TNW; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[tm][r], bf[tn], acc[tm][tn][r], 0, 0, 0);
-      } else {
-        // 4 waves/SIMD hide LDS latency across waves: fragments are read 4 at a time to stay within 128 VGPRs
-#pragma unroll
-        for (int tm = 0; tm < TMW; ++tm) {
-          double af[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            af[r] = As[a_read_off<ALAY, A_NEWMAP>(a_base, tm, r, ks)];
-#pragma unroll
-          for (int tn = 0; tn < TNW; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              acc[tm][tn][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[r], bf[tn], acc[tm][tn][r], 0, 0, 0);
+          for (int tn = 0; tn < TNW; ++tn) mfma16(acc[tm][tn], af[tm], bf[tn]);
         }
-      }
     }
   };
   for (int it = 0; it < total; ++it) {
     const double* As = stage_step(it);
-    if constexpr (EPI_PF) {
-      if (it == total - 2) {        // the touched values have landed with the stage just waited for: no extra stall
-#pragma unroll
-        for (int q = 0; q < TMW * TNW / 2; ++q) asm volatile("" ::"v"(pfv[q]));
-      }
-      if (it == total - 3) {
-        EpiCtx e;
-        e.C = nullptr; e.ldc = g.ldc; e.alpha = 0.0; e.row0 = row0 + wrow; e.col0 = col0 + wn * WTN; e.lane = ln; e.prow = 0; e.tm_stride = tm_stride;
-        epi.template prefetch<TMW, TNW>(e, pfv);
-      }
-    }
     // Triangular structure at wave granularity: a wave whose rows cannot touch this BK step of a triangular A, or whose whole 64x64
     // output lies above the diagonal of a lower-triangular C, issues no MFMAs (it still takes part in staging and barriers; the
     // co-resident workgroup gets the matrix pipe).
@@ -764,7 +519,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
   EpiCtx e;
   e.C = g.C + (int64_t)tl.slice * g.slice_stride; e.ldc = g.ldc; e.alpha = g.alpha;
   e.row0 = row0 + wrow; e.col0 = col0 + wn * WTN; e.lane = lane; e.prow = (int64_t)tl.bi * WMW + wm; e.tm_stride = tm_stride;
-  if (ZIGP_KO_EPI && TRI != TRI_NONE) { if (acc[0][0][0] == 1.2345e300) epi(acc, e); return; }   // no stores (the test keeps the accumulators live)
   epi(acc, e);
 }
 
@@ -772,19 +526,18 @@ template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, int WAVES, class
 __global__ void __launch_bounds__(64 * WAVES, ((NSTAGE <= 2) ? 2 : 1) * WAVES / 4)
 gemm_f64_kernel(GemmArgs g, Epi epi) {
   constexpr int WNW = Shape<WAVES>::WNW;
-  static_assert(TILE_DOUBLES >= 128 * 16 + 16, "padded B image must fit the stage");
+  static_assert(TILE_DOUBLES >= 128 * 16 + 16, "padded k-contiguous image must fit the stage");
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS destinations and wave-level skips stay on the SALU
   const int wm = wave / WNW, wn = wave % WNW;
-  const GemmSeg& sg = g.seg[0];
   bool ring_used = false;
   for (int u = 0; u < g.per; ++u) {
   const GemmTile tl = g.tiles[(int64_t)blockIdx.x * g.per + u];
   if (tl.kend <= tl.kbeg) continue;                 // padding entry (uniform over the workgroup)
   if (ring_used) __builtin_amdgcn_s_barrier();      // slower waves may still read the previous tile's last stage
   ring_used = true;
-  if constexpr (ZIGP_SYRK_DIAG != 0 && TRI == TRI_C_LOWER && ALAY == LAY_KCONTIG && BLAY == LAY_KCONTIG && WAVES == 4) {
+  if constexpr (TRI == TRI_C_LOWER && ALAY == LAY_KCONTIG && BLAY == LAY_KCONTIG && WAVES == 4) {
     if (tl.bi == tl.bj) {   // diagonal tile of the symmetric update: balanced lower-triangle path (uniform over the workgroup)
       switch (wave) {
         case 0: syrk_diag_tile<0, NSTAGE, KSCALE>(g, tl, lds, wave, lane, epi); break;

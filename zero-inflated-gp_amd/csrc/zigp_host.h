@@ -40,29 +40,15 @@ static inline GemmTile mk_tile(int bi, int bj, int kbeg, int kend, int slice = 0
   GemmTile t; t.bi = bi; t.bj = bj; t.kbeg = kbeg; t.kend = kend; t.slice = slice; t.kdir = 1; t.pad1 = t.pad2 = 0; return t;
 }
 
-#ifndef ZIGP_WAVES_DEFAULT
-#define ZIGP_WAVES_DEFAULT 4
-#endif
-constexpr int NST = ZIGP_NSTAGE;   // LDS ring depth of the GEMM core (2 -> 64 KB, 2 workgroups/CU; 3-4 -> 1 workgroup/CU)
+constexpr int NST = 2;   // LDS ring depth of the GEMM core (2 stages = 74 KB per workgroup: two workgroups share a CU)
 
-// The lower-triangular products (A1 = W K, H = W diag(s^2) A2) read their factor TRANSPOSED (m-contiguous image W^T, written once per
-// step by k_transpose_scale), so that all four triangular products run the 8-wave <m/n-contiguous, m/n-contiguous> kernel (4 waves per
-// SIMD, 32-row triangular skipping): A1 / H 56-57 -> 60-61 TF; the chip gives part of it back as clock (A2 / J' / SYRK -2 %), net
-// -1.4 % per step (same-box A/B, profiles/r03c_ab_tail.log).  0: the round-1/2 arrangement (k-contiguous W, 4-wave kernel).
-#ifndef ZIGP_LOWER_VIA_WT
-#define ZIGP_LOWER_VIA_WT 1
-#endif
-// Workgroup shape per operand-layout pair (see Shape<> in zigp_gemm.h): 8 waves where the kernel fits 128 VGPRs
-template <int AL, int BL, bool KS> struct WavesFor { static constexpr int value = ZIGP_WAVES_DEFAULT; };
-#ifndef ZIGP_NO_8WAVE
+// Workgroup shape per operand-layout pair (see Shape<> in zigp_gemm.h): 8 waves where the kernel fits 128 VGPRs -- the m/n-contiguous
+// products, i.e. all of the chunk loop's but the rank-N update.  The lower-triangular products (A1 = W K) read their factor TRANSPOSED
+// (m-contiguous image W^T, written once per step by k_transpose_scale) so that they run that kernel too (r3: A1 56-57 -> 60-61 TFLOP/s,
+// profiles/r03c_ab_tail.log).  The 8-wave shape for the rank-N update and the 4-wave shape for the triangular products were measured
+// again on the 16x16x4 core and lose (profiles/r04m_ab_shapes.log).
+template <int AL, int BL, bool KS> struct WavesFor { static constexpr int value = 4; };
 template <> struct WavesFor<LAY_MNCONTIG, LAY_MNCONTIG, false> { static constexpr int value = 8; };
-#ifdef ZIGP_SYRK_8W
-template <> struct WavesFor<LAY_KCONTIG, LAY_KCONTIG, true> { static constexpr int value = 8; };
-#endif
-#ifdef ZIGP_8WAVE_LOWER
-template <> struct WavesFor<LAY_KCONTIG, LAY_MNCONTIG, false> { static constexpr int value = 8; };
-#endif
-#endif
 
 template <int AL, int BL, bool KS, int TRI = TRI_NONE, class EP>
 static int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
@@ -134,14 +120,10 @@ static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, bool paired, Ti
         for (int e = 0; e < 2; ++e) v.push_back(e0 + e < q[x].size() ? q[x][e0 + e] : mk_tile(0, 0, 0, 0));
   }, tl, 2);
 }
-#ifndef ZIGP_TRMM_PAIRED
-#define ZIGP_TRMM_PAIRED 1
-#endif
 // The paired order has nbn * ceil(nbm / 2) units of EQUAL length: it only pays where they fill whole waves of the 512 resident
 // workgroups (cfg3: 256 panels x 4 units = 2 waves exactly; cfg2: 392 x 2 = 784 units would leave the second wave 47 % empty, and so
 // would the short last chunk of cfg3) -- otherwise LPT, whose tiles of mixed length pack the tail.
 static inline bool trmm_paired_pays(int nbm, int nbn) {
-  if (!ZIGP_TRMM_PAIRED) return false;
   const int units = nbn * ((nbm + 1) / 2), slots = 512;
   const int waves = (units + slots - 1) / slots;
   return units >= slots && (double)units / ((double)waves * slots) >= 0.95;
@@ -162,21 +144,10 @@ static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool pa
 struct SyrPlan { int So, Sd; int planes() const { return std::max(So, Sd); } };
 static inline SyrPlan syr_plan(int nbm) {
   const int n_off = nbm * (nbm - 1) / 2, n_d = nbm, slots = 512;
-#if ZIGP_SYRK_DIAG
   int So = (int)(slots / (n_off + 0.5 * n_d)) / 16 * 16;
   So = std::max(16, std::min(64, So));
   while (So > 16 && n_off * So + n_d * (So / 2) > slots) So -= 16;
   return SyrPlan{So, So / 2};
-#else
-  int best = 4; double best_eff = 0.0;   // without the diagonal path: smallest S >= 4 whose tile count fills whole waves of the slots to >= 95 %
-  for (int S = 4; S <= 64; ++S) {
-    const int t = (n_off + n_d) * S;
-    const double eff = (double)t / (double)(((t + slots - 1) / slots) * slots);
-    if (eff > best_eff + 1e-12) { best_eff = eff; best = S; }
-    if (eff >= 0.95) { best = S; break; }
-  }
-  return SyrPlan{best, best};
-#endif
 }
 // Lower-triangular output tiles x split-K slices over nk k-steps.  Launch position p runs on XCD p % 8 (observed round-robin dispatch;
 // speed only): XCD x is handed the tiles whose k range lies in the x-th eighth of the k range (both slice counts multiples of 8), else
@@ -500,7 +471,6 @@ static int begin_staged_call(zigp_ctx* c) {
   ZIGP_HIP(c, hipStreamSynchronize(c->stream_main));
   ZIGP_HIP(c, hipStreamSynchronize(c->stream2));
   ZIGP_HIP(c, hipStreamSynchronize(c->stream3));
-  c->jp_wait = false;
   c->pinned.reset();
   return 0;
 }

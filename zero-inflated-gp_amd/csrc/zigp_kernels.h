@@ -281,24 +281,13 @@ k_pointwise(PwArgs p) {
 // (reverse of KernSE.K, onofftf/main.py:41-57)
 // ---------------------------------------------------------------------------------------------
 constexpr int KG_ROWS = 4;
-#ifndef ZIGP_KG_SPLIT
-#define ZIGP_KG_SPLIT 4
-#endif
-constexpr int KG_SPLIT = ZIGP_KG_SPLIT;   // column splits (blockIdx.y); each split accumulates into its own krow slab [KG_SPLIT][Mp][W]
-// ZIGP_KGRAD_RECOMPUTE (round 3's default; OFF since late round 4): K[m,n] is recomputed from x_n and z_m (the expression of k_kuf_build, bit
-// for bit) instead of read back: half the HBM bytes (0.27 instead of 0.54 GB per chunk and latent) for 8.1 instead of 7.2 ms of kernel time
-// per step when it runs alone -- with the side-stream overlap (zigp_set_overlap, what bench.py times) the step was 0.3 % shorter on the
-// round-3 core (profiles/r03a_ab_kgrad.log).
-// r4, re-measured on the 16x16x4 core (profiles/r04ai_ab_kgread.log: three boxes, eleven rounds): READING K is faster in every round -- cfg3
-// -0.3 ... -1.1 ms per step (avg -0.6), the 125 000-row shard -0.7 %, cfg2 -1.3 %: beside MFMA-bound products that leave 7 of the 8 TB/s of
-// HBM idle, 28 fewer fp64 VALU instructions per element are worth more than 8 more bytes.  Two columns per thread with 16-byte loads change
-// nothing (7.13 vs 7.17 ms alone = 4.6 TB/s).  K stays valid until this kernel is done: the next chunk's panels are built behind it on the
-// same stream (dense_chunk_loop).
-// r3, measured and dropped: a 1-row x 2-column version of 69 VGPRs, meant to sit beside the two rank-N-update workgroups of a CU (which
-// leave 112 registers per lane; this kernel holds 150): 9.4 ms alone and no better overlapped (185.0 vs 184.5 ms/step, r03e_overlap.log).
-#ifndef ZIGP_KGRAD_RECOMPUTE
-#define ZIGP_KGRAD_RECOMPUTE 0
-#endif
+constexpr int KG_SPLIT = 4;   // column splits (blockIdx.y); each split accumulates into its own krow slab [KG_SPLIT][Mp][W]
+// K[m,n] is READ from the chunk's Kuf panel.  Round 3 recomputed it from x_n and z_m (half the HBM bytes, 28 more fp64 VALU instructions per
+// element: 0.3 % faster per step on that round's core); on the 16x16x4 core reading is faster in every round (profiles/r04ai_ab_kgread.log:
+// cfg3 -0.3 ... -1.1 ms per step, cfg2 -1.3 %): beside MFMA-bound products that leave 7 of the 8 TB/s of HBM idle, fp64 VALU work costs
+// more than bytes.  K stays valid until this kernel is done: the next chunk's panels are built behind it on the same stream
+// (dense_chunk_loop).  (The recomputing form, the eight-way column split and a slim 1-row x 2-column version are in
+// tools/r4_experiment_arms.patch and DESIGN.md section 5.)
 template <int D>
 __global__ void __launch_bounds__(256)
 k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const double* __restrict__ alpha,
@@ -309,13 +298,13 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
   krow += (int64_t)blockIdx.y * slab;
   const int m0 = blockIdx.x * KG_ROWS;
   if (m0 >= M) return;
-  double zz[KG_ROWS][D], zs[KG_ROWS][D], am[KG_ROWS], acc[KG_ROWS][W];
+  double zz[KG_ROWS][D], am[KG_ROWS], acc[KG_ROWS][W];
 #pragma unroll
   for (int r = 0; r < KG_ROWS; ++r) {
     const int m = min(m0 + r, M - 1);
     am[r] = alpha[m];
 #pragma unroll
-    for (int d = 0; d < D; ++d) { zz[r][d] = Z[m * D + d]; zs[r][d] = zz[r][d] * hyp.inv_ell[d]; }
+    for (int d = 0; d < D; ++d) zz[r][d] = Z[m * D + d];
 #pragma unroll
     for (int q = 0; q < W; ++q) acc[r][q] = 0.0;
   }
@@ -329,14 +318,7 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
 #pragma unroll
     for (int r = 0; r < KG_ROWS; ++r) {
       const int64_t o = (int64_t)(m0 + r) * Nc + n;     // rows beyond M are zero-padded panels (inside the allocation)
-#if ZIGP_KGRAD_RECOMPUTE
-      double r2 = 0.0;
-#pragma unroll
-      for (int d = 0; d < D; ++d) { const double t_ = zs[r][d] - x[d] * hyp.inv_ell[d]; r2 = fma(t_, t_, r2); }
-      const double kk = (m0 + r < M) ? hyp.var * exp(-0.5 * r2) : 0.0;
-#else
       const double kk = K[o];
-#endif
       const double t = fma(gv2, Jp[o], am[r] * gmn) * kk;
       acc[r][0] += t;
       acc[r][1 + 2 * D] = fma(kk, gmn, acc[r][1 + 2 * D]);
@@ -730,143 +712,6 @@ struct PotrfShared { double dinv[PB]; double T[3][PNB][PNB + 1]; int fail; };
 __device__ __forceinline__ double potrf_wget(const double* S, const double* dinv, int x, int y) {
   return x > y ? S[y * PBLD + x] : (x == y ? dinv[x] : 0.0);
 }
-#if defined(ZIGP_POTRF_V1)
-__device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int j0, int* info, int npan, bool want_W, double tol) {
-  double* dinv = psh.dinv;
-  double (*T)[PNB][PNB + 1] = psh.T;
-  int& fail = psh.fail;
-  const int t = threadIdx.x;
-  if (t == 0) fail = 0;
-  if (t < PB) dinv[t] = 1.0;
-  __syncthreads();
-  const int nreal = npan * PNB;
-  for (int jb = 0; jb < nreal; jb += PNB) {
-    if (t < 64) {   // (1)
-      const int r = t & 31;                      // lanes 32..63 shadow lanes 0..31 (they never store)
-      double a[PNB];
-#pragma unroll
-      for (int k = 0; k < PNB; ++k) a[k] = S[(jb + r) * PBLD + jb + k];
-      int bad = 0;
-#pragma unroll
-      for (int j = 0; j < PNB; ++j) {
-        int rr = r;
-        asm volatile("" : "+v"(rr));   // lane masks of (rr == j) are recomputed per column instead of living in 2 SGPRs each
-        const double d = readlane_f64(a[j], j);
-        if (!(d > tol)) { if (!bad) bad = j + 1; }   // non-positive or NaN pivot (uniform); keep going on garbage, report below
-        const double rd = 1.0 / sqrt(d);
-        const double l = (rr == j) ? sqrt(d) : a[j] * rd;
-        a[j] = l;
-#pragma unroll
-        for (int k = j + 1; k < PNB; ++k) {   // row r, column k (k > r: unused)
-          a[k] = fma(-l, readlane_f64(l, k), a[k]);
-          asm volatile("" : "+v"(a[k]));     // materialise now: otherwise the update is sunk to column k and every broadcast stays live
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the broadcasts (SGPR pairs) of one column from piling up across columns
-      }
-      if (bad) {
-        if (t == 0) { atomicCAS(info, 0, j0 + jb + bad); fail = 1; }
-      } else {
-        // rows go through the staging tiles T[0] (L11) / T[1] (its inverse) with unconditional stores: predicated stores
-        // would keep one 64-bit lane mask per column alive in SGPRs
-        if (t < 32) {
-#pragma unroll
-          for (int k = 0; k < PNB; ++k) T[0][r][k] = a[k];
-        }
-        {
-          int rr = r;
-          asm volatile("" : "+v"(rr));
-#pragma unroll
-          for (int k = 1; k < PNB; ++k) a[k] = (k <= rr) ? a[k] : 0.0;   // columns right of the diagonal hold Schur-complement leftovers
-        }
-        // in-place inverse of the lower-triangular block, columns right to left:
-        //   w_jj = 1 / l_jj ;  w_rj = -w_jj * sum_{k=j+1..r} w_rk l_kj   (w_rk: already inverted, lane-local; l_kj: lane k, old)
-#pragma unroll
-        for (int j = PNB - 1; j >= 0; --j) {
-          int rr = r;
-          asm volatile("" : "+v"(rr));
-          const double wjj = 1.0 / readlane_f64(a[j], j);
-          double sum = 0.0;
-#pragma unroll
-          for (int k = j + 1; k < PNB; ++k) sum = fma(a[k], readlane_f64(a[j], k), sum);   // a[k] = 0 for k > r
-          a[j] = (rr == j) ? wjj : ((rr > j) ? -wjj * sum : 0.0);
-          asm volatile("" : "+v"(a[j]));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (t < 32) {
-#pragma unroll
-          for (int k = 0; k < PNB; ++k) T[1][r][k] = a[k];
-        }
-      }
-    }
-    __syncthreads();
-    if (fail) return false;
-    {   // scatter the diagonal block: L11 -> lower triangle, inv(L11)^T -> upper triangle, its diagonal -> dinv
-      const int r = t >> 5, k = t & 31;
-      if (k <= r) S[(jb + r) * PBLD + jb + k] = T[0][r][k];
-      if (k < r) S[(jb + k) * PBLD + jb + r] = T[1][r][k];
-      if (k == r) dinv[jb + r] = T[1][r][r];
-    }
-    __syncthreads();
-    const int nbelow = nreal - jb - PNB;   // real rows under the diagonal block
-    // (2) L21[i][c] = sum_{k<=c} A21[i][k] W11[c][k]   (in place: all sums first, then the stores)
-    double v[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int idx = t + 1024 * q;
-      v[q] = 0.0;
-      if (idx < nbelow * PNB) {
-        const int i = jb + PNB + idx / PNB, c = idx % PNB;
-        double s = S[i * PBLD + jb + c] * dinv[jb + c];
-        for (int k = 0; k < c; ++k) s = fma(S[i * PBLD + jb + k], S[(jb + k) * PBLD + jb + c], s);
-        v[q] = s;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int idx = t + 1024 * q;
-      if (idx < nbelow * PNB) S[(jb + PNB + idx / PNB) * PBLD + jb + idx % PNB] = v[q];
-    }
-    __syncthreads();
-    // (3) trailing update S[i][k] -= sum_c L[i][jb+c] L[k][jb+c] for jb+32 <= k <= i
-    for (int idx = t; idx < nbelow * nbelow; idx += 1024) {
-      const int i = jb + PNB + idx / nbelow, k = jb + PNB + idx % nbelow;
-      if (k > i) continue;
-      double acc = S[i * PBLD + k];
-#pragma unroll 8
-      for (int c = 0; c < PNB; ++c) acc = fma(-S[i * PBLD + jb + c], S[k * PBLD + jb + c], acc);
-      S[i * PBLD + k] = acc;
-    }
-    __syncthreads();
-  }
-  if (want_W) {
-    // W[x][y]: x > y at S[y][x], x == y in dinv, x < y zero
-    auto Wget = [&](int x, int y) -> double { return potrf_wget(S, dinv, x, y); };
-    const int NBLK = npan;
-    for (int dist = 1; dist < NBLK; ++dist) {
-      const int nblk = NBLK - dist;                 // blocks (bj + dist, bj), bj = 0 .. nblk-1
-      for (int idx = t; idx < nblk * PNB * PNB; idx += 1024) {   // T = sum_k L_ik W_kj
-        const int b = idx / (PNB * PNB), r = (idx / PNB) % PNB, c = idx % PNB;
-        const int jb = b * PNB, ib = (b + dist) * PNB;
-        double s = 0.0;
-        for (int x = jb + c; x < ib; ++x) s = fma(S[(ib + r) * PBLD + x], Wget(x, jb + c), s);
-        T[b][r][c] = s;
-      }
-      __syncthreads();
-      for (int idx = t; idx < nblk * PNB * PNB; idx += 1024) {   // W_ij = -W_ii T
-        const int b = idx / (PNB * PNB), r = (idx / PNB) % PNB, c = idx % PNB;
-        const int jb = b * PNB, ib = (b + dist) * PNB;
-        double s = 0.0;
-        for (int m = 0; m <= r; ++m) s = fma(Wget(ib + r, ib + m), T[b][m][c], s);
-        S[(jb + c) * PBLD + ib + r] = -s;
-      }
-      __syncthreads();
-    }
-  }
-  return true;
-}
-
-#else
 // ---- second version: the serial work is the 32 x 32 factorisation only; everything else runs beside it or on the MFMA pipe.
 //   per panel j:  [A] wave 0 factors the diagonal block (registers, v_readlane broadcasts, v_rsq_f64 + two Newton steps per pivot)
 //                     wave 1 inverts the PREVIOUS diagonal block (needed for W only, so it is off the critical path): two 16 x 16
@@ -1175,7 +1020,6 @@ __device__ __forceinline__ bool potrf_diag_lds(double* S, PotrfShared& psh, int 
   }
   return true;
 }
-#endif
 
 __global__ void __launch_bounds__(1024)
 k_potrf_diag(const double* __restrict__ A, double* __restrict__ L, double* __restrict__ W, int64_t ld, int j0, int* info, int npan, double tol) {

@@ -27,7 +27,7 @@ def source_hash(files=None):
         if os.path.exists(p):
             h.update(f.encode())
             h.update(open(p, 'rb').read())
-    for k in ('ZIGP_EXTRA_FLAGS', 'ZIGP_NSTAGE', 'ZIGP_WAVES_DEFAULT'):
+    for k in ('ZIGP_EXTRA_FLAGS',):
         h.update(('%s=%s' % (k, os.environ.get(k, ''))).encode())
     return h.hexdigest()
 
@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
         raise RuntimeError('hipcc not found: cannot build libzigp.so')
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc, '-O3'] + os.environ.get('ZIGP_EXTRA_FLAGS', '').split() + [ '-DZIGP_NSTAGE=%d' % int(os.environ.get('ZIGP_NSTAGE', '2')), '-DZIGP_WAVES_DEFAULT=%d' % int(os.environ.get('ZIGP_WAVES_DEFAULT', '4')), '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC', '-o', LIB] + srcs
+    cmd = [hipcc, '-O3'] + os.environ.get('ZIGP_EXTRA_FLAGS', '').split() + ['--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC', '-o', LIB] + srcs
     if verbose:
         print(' '.join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
