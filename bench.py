@@ -39,19 +39,35 @@ PEAK_FP64_MFMA = 78.6e12   # vendor fp64 matrix peak, MI355X (256 CU x 2.4 GHz x
 PEAK_HBM = 8.0e12          # HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a streaming copy reaches
 
 
-def synth(N, M, D, rank=0):
-    """SURVEY.md section 8d generator; rank r of a weak-scaling run draws its own shard (seed r)."""
-    rs = np.random.RandomState(rank)
-    X = rs.rand(N, D)
-    f = np.sin(2 * np.pi * X[:, 0]) * np.cos(2 * np.pi * X[:, 1]) + X[:, 2]
-    g = 2 * np.sin(2 * np.pi * (X[:, 0] + X[:, 2]))
-    Y = np.where(g + rs.randn(N) > 0, f + 0.1 * rs.randn(N), 0.0)
-    Z = np.random.RandomState(1001).rand(M, D)
-    ru = np.random.RandomState(1002)
+CFG4_SHARDS = 8            # cfg4 = the generator stream over 8e6 rows, rank r takes rows [r 1e6, (r + 1) 1e6)
+
+
+def synth(N, M, D, rank=0, shards=1):
+    """SURVEY.md section 8d generator: RandomState(0) over shards * N rows (X, then the gate noise, then the observation noise), of which
+    rows [rank N, (rank + 1) N) are returned; Z from RandomState(1), u from RandomState(2).  shards = 1: cfg2 / cfg3 as they stand;
+    a weak-scaling run draws every rank's shard from the cfg4 stream (weak_shard), so the one-GPU line IS the first shard of cfg4."""
+    Nt = N * shards
+    rs = np.random.RandomState(0)
+    X = rs.rand(Nt, D)
+    lo, hi = rank * N, (rank + 1) * N
+    Xs = np.ascontiguousarray(X[lo:hi])
+    del X
+    f = np.sin(2 * np.pi * Xs[:, 0]) * np.cos(2 * np.pi * Xs[:, 1]) + Xs[:, 2]
+    g = 2 * np.sin(2 * np.pi * (Xs[:, 0] + Xs[:, 2]))
+    e1 = rs.randn(Nt)[lo:hi].copy()
+    e2 = rs.randn(Nt)[lo:hi].copy()
+    Y = np.where(g + e1 > 0, f + 0.1 * e2, 0.0)
+    Z = np.random.RandomState(1).rand(M, D)
+    ru = np.random.RandomState(2)
     p = dict(Zf=Z.copy(), Zg=Z.copy(), u_fm=0.01 * ru.randn(M, 1), u_gm=0.01 * ru.randn(M, 1),
              u_fs_sqrt=np.ones((M, 1)), u_gs_sqrt=np.ones((M, 1)), ell_f=np.full(D, 0.1), ell_g=np.full(D, 0.1),
              var_f=1.0, var_g=5.0, noise=0.01)
-    return X, Y, p
+    return Xs, Y, p
+
+
+def weak_shard(rows, M, D, rank, world):
+    """rank r's rows of a weak-scaling run: rows [r rows, (r + 1) rows) of the cfg4 stream (8 shards; more when there are more ranks)"""
+    return synth(rows, M, D, rank=rank, shards=max(CFG4_SHARDS, world))
 
 
 def csrc_hash():
@@ -148,7 +164,7 @@ def headline(args, world, total_rows, dt):
 def library_exchange_check(eng, dist, red_dev, p, jitter, scale, ref_out, rank, dt, args, world, total_rows, limit_s=150.0):
     """One step through ncclAllReduce inside libzigp.so (zigp_comm_init) compared with the sums torch.distributed produced for the same
     step, plus a short timing of that path.  Returns a dict for the JSON line.  A hang anywhere inside ends the process after limit_s:
-    rank 0 first prints the headline it already has (with the check marked as timed out), every rank exits 0."""
+    rank 0 first prints the headline it already has (with the check marked as timed out), then every rank exits with code 3."""
     import threading
     import torch
     from zigp.parallel import ShardedELBO, pack
@@ -164,7 +180,7 @@ def library_exchange_check(eng, dist, red_dev, p, jitter, scale, ref_out, rank, 
                                                        'the headline above is the torch.distributed exchange' % limit_s}
             print(json.dumps(res))
             sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)      # the launcher sees that a collective hung (rc 3) -- after the headline is out
 
     timer = threading.Timer(limit_s, overrun)
     timer.daemon = True
@@ -263,7 +279,7 @@ def other_configs(eng, X3, Y3, p3, jitter):
         eng.set_data(X3[:n8], Y3[:n8])
         t8 = timeit(lambda: eng.elbo(p3, jitter=jitter), 5, 2)
         out['strong_1of8'] = dict(workload='rows [0, %d) of the headline workload (its 1/8 shard), M=%d, value+gradient: what each rank runs under '
-                                           '8-GPU strong scaling' % (n8, M3), ms_per_step=t8 * 1e3,
+                                           '8-GPU strong scaling' % (n8, M3), ms_per_step=t8 * 1e3, rows_per_pass=eng.get_chunk_rows(M3, n8),
                                   allreduce_us_assumed=50.0,
                                   note='projected_8gpu_speedup (top level) = ms_per_step / (this + the assumed all-reduce): arithmetic on two '
                                        'one-GPU measurements, NOT a measured 8-GPU run; the all-reduce of the 82 KB vector is assumed, never measured here')
@@ -273,7 +289,7 @@ def other_configs(eng, X3, Y3, p3, jitter):
     t = timeit(lambda: eng.elbo(p2, jitter=jitter), 8, 2)
     ed, kl, _ = eng.elbo(p2, jitter=jitter)
     out['cfg2'] = dict(workload='N=1e5, D=3, M=512, value+gradient', ms_per_step=t * 1e3, steps_per_s=1 / t,
-                       frac_10M2N=10.0 * 512 * 512 * 1e5 / t / PEAK_FP64_MFMA, elbo=ed - kl)
+                       frac_10M2N=10.0 * 512 * 512 * 1e5 / t / PEAK_FP64_MFMA, elbo=ed - kl, rows_per_pass=eng.get_chunk_rows(512, 100000))
     # cfg5: Kronecker pptr, 32 x 32 (tests/golden/pptr.npz is the reference's data file)
     try:
         from onofftf.model import init_params, engine_params
@@ -387,7 +403,7 @@ def main():
     M, D, jitter = args.M, args.D, 1e-6
     if args.scaling == 'weak':
         N = args.rows
-        X, Y, p = synth(N, M, D, rank)
+        X, Y, p = weak_shard(N, M, D, rank, world)
         total_rows = N * world
     else:
         Xa, Ya, p = synth(args.rows, M, D, 0)
@@ -459,6 +475,7 @@ def main():
         eng.profile_sampling(8)
         eng.set_overlap(0 if args.no_overlap else 1)
 
+    extras_failed = []
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         res = headline(args, world, total_rows, dt)
@@ -576,11 +593,15 @@ def main():
                                    'elbo_data_rel_diff_on_sample': abs(gdata - cdata) / abs(cdata)}
         print(json.dumps(res))
         sys.stdout.flush()
+        extras_failed = [k for k in res.get('other_configs', {}) if k.endswith('_error')]
     if dist is not None:
         dist.barrier()
         sh.close()
         dist.destroy_process_group()
     eng.close()
+    if rank == 0 and extras_failed:      # the headline is out; a configuration that silently stopped being measured must not pass unnoticed
+        sys.stderr.write('bench.py: other_configs raised: %s\n' % ', '.join(extras_failed))
+        sys.exit(4)
 
 
 if __name__ == '__main__':

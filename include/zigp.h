@@ -68,6 +68,9 @@ int zigp_set_chunk(zigp_ctx* ctx, int64_t chunk_rows);
 /* The chunk (rows per pass) the dense path uses for M inducing points per latent on a long row range: the zigp_set_chunk value, else
  * the default rule. */
 int64_t zigp_get_chunk(zigp_ctx* ctx, int32_t M);
+/* Rows per pass the dense path actually uses for a row range of `span` rows: the range is cut into equal passes of at most the chunk above
+ * (a multiple of 1024 rows each), and a range of up to 131072 rows goes through in ONE pass while its panels stay within 9 GB (M <= 1024). */
+int64_t zigp_get_chunk_rows(zigp_ctx* ctx, int32_t M, int64_t span);
 /* Smallest Cholesky pivot accepted, as a multiple of eps * (kernel variance + jitter).  Default 8 (see ZIGP_ENOTPD above);
  * 0 reproduces tf.cholesky / LAPACK potrf, which fail on a non-positive pivot only (onofftf/main.py:200,268,355). */
 int zigp_set_pivot_rtol(zigp_ctx* ctx, double rtol);
@@ -103,6 +106,10 @@ int zigp_elbo(zigp_ctx* ctx, const zigp_params* p, double jitter, double scale, 
  * out9 is (9,N): gfmean, gfvar, gfmeanu, fmean, fvar, gmean, gvar, ephi_g, evar_phi_g (order of :152). */
 int zigp_predict(zigp_ctx* ctx, const zigp_params* p, const double* Xnew, int64_t N, double jitter,
                  double g_offset, double* out9);
+/* The same with Xnew (N,D) and out9 (9,N) in DEVICE memory of the context's GPU (the companion of zigp_set_data_device): nothing crosses
+ * PCIe but the parameters; complete on return.  The caller orders its own streams around the call (it is synchronous on the host). */
+int zigp_predict_device(zigp_ctx* ctx, const zigp_params* p, const double* dXnew, int64_t N, double jitter,
+                        double g_offset, double* d_out9);
 
 /* Prior KL only (OnOffSVGP.compute_prior_KL, onoffgpf/OnOffSVGP.py:164-166): kl2 = {KL_f, KL_g}. */
 int zigp_prior_kl(zigp_ctx* ctx, const zigp_params* p, double jitter, double* kl2);
@@ -167,8 +174,9 @@ int zigp_kron_predict(zigp_ctx* ctx, const zigp_kron_params* p, const double* Xn
  *                instead (the one wrap-around batch per epoch, which is a concatenation of the old and the new permutation, :125-129)
  *   elbo_data, kl    out [n_steps] (nullable): scale * sum var_exp and KL of every step, evaluated at the parameters BEFORE its update
  * Grids beyond the fused kernels (a factor of more than 32 points next to one of more than 16, or more than 112) return ZIGP_EARG: step
- * them with zigp_kron_elbo_rows and a host optimiser.  A Cholesky failure returns ZIGP_ENOTPD; free_state / adam_* then hold the state
- * before the failing step and the history entries from that step on are NaN.  With a communicator (zigp_comm_init) every step's result
+ * them with zigp_kron_elbo_rows and a host optimiser.  A Cholesky failure in step k returns ZIGP_ENOTPD; free_state / adam_* then hold the state
+ * before the failing step -- the k updates before it HAVE been applied: the caller's iteration count advances by k -- and the history
+ * entries from step k on are NaN (the finite prefix is the history of the applied steps).  With a communicator (zigp_comm_init) every step's result
  * block is summed over the ranks before its update, so all ranks hold the same parameters (each passes its own rows, include_kl as usual
  * is rank 0's). */
 #define ZIGP_FIT_BLOCKS 17
@@ -231,7 +239,9 @@ int zigp_comm_init(zigp_ctx* ctx, int32_t rank, int32_t nranks, const void* id);
  * them enters the collective zigp_comm_init: a rank that cannot load RCCL would otherwise leave its peers waiting. */
 int zigp_comm_available(int32_t* version);
 /* zigp_comm_init gives up with ZIGP_ECOMM when its peers have not joined after `seconds` (default 120, or env ZIGP_COMM_TIMEOUT_S at
- * zigp_create); the communicator is then unusable on every rank: fall back to a host-side exchange or exit, do not retry on the same id. */
+ * zigp_create); the communicator is then unusable on every rank: fall back to a host-side exchange or exit, do not retry on the same id.
+ * The helper thread that is still inside ncclCommInitRank stays behind (it destroys the communicator itself should the call return late):
+ * a process that goes on after a timeout should end through os._exit / a fresh child process rather than a normal interpreter shutdown. */
 int zigp_comm_set_timeout(zigp_ctx* ctx, double seconds);
 int zigp_comm_destroy(zigp_ctx* ctx);
 /* Sum n host doubles over the ranks of the context's communicator, in place (staged through the device): for the few scalars a host loop

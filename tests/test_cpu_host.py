@@ -298,6 +298,137 @@ def test_data_parallel_kronecker_gloo_world2_equals_single_process():
             assert np.max(np.abs(x - y)) <= 1e-9 * max(np.max(np.abs(y)), 1e-300), k
 
 
+def _kron_pset(p, lr=1e-2):
+    """a ParamSet in the layout of onofftf.model.init_params from a make_kron_problem parameter dict"""
+    from collections import OrderedDict
+    from onofftf.main import Param
+    from zigp.optim import ParamSet
+    from zigp.transforms import Log1pe, positive
+    q = OrderedDict()
+    for tag in ('f', 'g'):
+        for i in range(2):
+            q['%s_kern/lengthscale_%d' % (tag, i)] = Param(p['ell_' + tag][i], Log1pe(), name='lengthscale', learning_rate=lr)
+            q['%s_kern/variance_%d' % (tag, i)] = Param(p['var_' + tag][i], Log1pe(), name='variance', learning_rate=lr)
+            q['%s_ind/z_%d' % (tag, i)] = Param(p['Z' + tag][i].copy(), name='z', learning_rate=2 * lr)
+        q['%s_ind/value' % tag] = Param(p['u_%sm' % tag].copy(), name='value', learning_rate=2 * lr)
+        q['%s_ind/variance' % tag] = Param(p['u_%ss_sqrt' % tag].copy(), positive, name='variance', learning_rate=2 * lr)
+    q['likelihood/variance'] = Param(p['noise'], Log1pe(), name='variance', learning_rate=lr)
+    return ParamSet(q)
+
+
+_FIT_ROWS = [0, 30, 60, 15]      # first row of each rank's minibatch inside its OWN shard, per iteration
+_FIT_BATCH = 20
+
+
+def _gloo_kron_fit_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from zigp.parallel import ShardedKronFit, shard_bounds
+    from test_gpu_kron import make_kron_problem
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    X, Y, p = make_kron_problem(203, 5, 4, seed=8, M0g=4, M1g=6)
+    lo, hi = shard_bounds(X.shape[0], world, rank)
+    pset = _kron_pset(p)
+    fit = ShardedKronFit(_OracleKronShardEngine(X[lo:hi], Y[lo:hi]), pset, dist)
+    assert not fit.on_device and not fit.library_comm       # gloo: host loop on the all-reduced gradient
+    ed, kl = fit.steps(_FIT_ROWS, _FIT_BATCH, 1e-5, 203.0 / (world * _FIT_BATCH))
+    q.put((rank, fit.t, ed, kl, {k: v.value.copy() for k, v in pset.params.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_kron_fit_gloo_world2_equals_single_process():
+    """ShardedKronFit (the data-parallel form of scripts/onoff.py:375-381) without a library communicator: 2 gloo ranks, each stepping on a
+    minibatch of its own shard, the gradient all-reduced, Adam on every rank -- both ranks must end with the parameters a single process
+    gets from the union of the two minibatches, and with each other's bit for bit."""
+    import torch.multiprocessing as mp
+    import zigp_oracle_torch as ot
+    from zigp.optim import AdamGroups
+    from zigp.parallel import shard_bounds
+    from onofftf.model import engine_params, named_grads
+    from test_gpu_kron import make_kron_problem
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_kron_fit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    X, Y, p = make_kron_problem(203, 5, 4, seed=8, M0g=4, M1g=6)
+    pset = _kron_pset(p)
+    adam = AdamGroups(pset)
+    scale = 203.0 / (2 * _FIT_BATCH)
+    hist = []
+    for rb in _FIT_ROWS:
+        idx = np.concatenate([np.arange(shard_bounds(203, 2, r)[0] + rb, shard_bounds(203, 2, r)[0] + rb + _FIT_BATCH) for r in range(2)])
+        e, d, kl, g = ot.kron_elbo_and_grad(X[idx], Y[idx], engine_params(pset), 1e-5, scale=scale)
+        hist.append((d * scale, kl))
+        adam.step(named_grads(g))
+    for rank, t, ed, kl, vals in got:
+        assert t == len(_FIT_ROWS)
+        assert np.max(np.abs(ed - np.array([h[0] for h in hist])) / np.abs(ed)) < 1e-9 and np.max(np.abs(kl - np.array([h[1] for h in hist])) / np.abs(kl)) < 1e-9
+        for k, v in pset.params.items():
+            assert np.max(np.abs(vals[k] - v.value)) <= 1e-8 * max(np.max(np.abs(v.value)), 1e-300), (rank, k)
+    for k in got[0][4]:
+        assert np.array_equal(got[0][4][k], got[1][4][k]), k          # the ranks agree bit for bit: they applied the same all-reduced gradient
+
+
+def test_kron_device_fit_counts_the_steps_applied_before_a_failure_and_notices_outside_changes():
+    """(1) a Cholesky failure in step k > 0 of a zigp_kron_fit_steps call has applied k updates: KronDeviceFit.t advances by k and
+    the exception carries the history of those steps; (2) a change made to the ParamSet behind the optimiser's back (load_checkpoint, an
+    assignment) is taken up by the next call instead of being overwritten by the cached free state -- KronDeviceFit and AdamGroups."""
+    import zigp
+    from zigp.optim import AdamGroups
+    from onofftf.model import KronDeviceFit, FIT_BLOCK_NAMES
+    from test_gpu_kron import make_kron_problem
+    X, Y, p = make_kron_problem(50, 3, 4, seed=2)
+
+    class FakeEngine:
+        fail_at = None
+        seen_x = None
+
+        def kron_fit_steps(self, shape, x, m, v, lr, positive, t0, row_begin, batch, **kw):
+            self.seen_x = x.copy()
+            n = len(row_begin)
+            k = n if self.fail_at is None else self.fail_at
+            x += 0.125 * k                       # k updates applied in place
+            if self.fail_at is not None:
+                e = zigp.NotPositiveDefiniteError('Cholesky failed in step %d' % k)
+                e.steps_applied, e.elbo_data, e.kl = k, np.arange(k, dtype=float), np.zeros(k)
+                raise e
+            return np.zeros(n), np.zeros(n)
+
+    eng = FakeEngine()
+    pset = _kron_pset(p)
+    fit = KronDeviceFit(eng, pset)
+    fit.steps([0, 1, 2], 10, 1e-5, 1.0)
+    assert fit.t == 3
+    eng.fail_at = 2
+    x_before = fit.x.copy()
+    with pytest.raises(zigp.NotPositiveDefiniteError) as ei:
+        fit.steps([0, 1, 2, 3, 4], 10, 1e-5, 1.0)
+    assert fit.t == 5 and ei.value.steps_applied == 2 and ei.value.elbo_data.tolist() == [0.0, 1.0]
+    assert np.allclose(fit.x, x_before + 0.25)
+    assert np.allclose(pset.params['f_ind/value'].value.reshape(-1), fit.x[sum(fit.sizes[:2]):sum(fit.sizes[:3])])   # the ParamSet has the state after those 2 updates
+    # (2) outside change
+    eng.fail_at = None
+    pset.params['f_ind/value'].value = np.full_like(pset.params['f_ind/value'].value, 7.0)
+    fit.steps([0], 10, 1e-5, 1.0)
+    o = sum(fit.sizes[:2])
+    assert np.all(eng.seen_x[o:o + fit.sizes[2]] == 7.0)            # the call started from the new values
+    adam = AdamGroups(pset)
+    g0 = {k: np.zeros_like(q.value) for k, q in pset.params.items()}
+    adam.step(g0)
+    pset.params['likelihood/variance'].value = np.array([0.5])
+    adam.step(g0)                                                    # zero gradient: the value must stay where it was PUT, not snap back
+    assert abs(float(pset.params['likelihood/variance'].value[0]) - 0.5) < 1e-12
+    adam.resync()
+    assert adam.t == 2
+
+
 def test_data_parallel_allreduce_gloo_world2_equals_single_process():
     """N>1 path on CPU: 2 ranks (gloo), row shards, one all-reduce; KL counted once (rank 0)."""
     import torch.multiprocessing as mp

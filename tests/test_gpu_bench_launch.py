@@ -35,7 +35,7 @@ def test_bench_self_launches_two_ranks_weak(engine):
     tot, kl = 0.0, None
     engine.set_chunk(32768)          # as bench.py's library rule at M = 256 would not: pin it for both sides
     for r in range(2):
-        X, Y, p = bench.synth(65536, 256, 3, rank=r)
+        X, Y, p = bench.weak_shard(65536, 256, 3, r, 2)
         engine.set_data(X, Y)
         ed, k, _ = engine.elbo(p, jitter=1e-6, include_kl=(r == 0))
         tot += ed
@@ -87,7 +87,7 @@ def test_cfg4_per_rank_workload_two_ranks_through_the_launcher(engine):
     tot, kl = 0.0, None
     engine.set_chunk(32768)          # the library's own rule at M = 1024 (other tests leave the shared engine on small chunks)
     for rk in range(2):
-        X, Y, p = bench.synth(1000000, 1024, 3, rank=rk)
+        X, Y, p = bench.weak_shard(1000000, 1024, 3, rk, 2)
         engine.set_data(X, Y)
         ed, k, _ = engine.elbo(p, jitter=1e-6, include_kl=(rk == 0), need_grad=False)
         tot += ed
@@ -171,7 +171,7 @@ def test_two_rank_rccl_exchange_matches_the_sum_of_the_shards(engine):
     tot, kl = 0.0, None
     engine.set_chunk(32768)
     for rk in range(2):
-        X, Y, p = bench.synth(65536, 256, 3, rank=rk)
+        X, Y, p = bench.weak_shard(65536, 256, 3, rk, 2)
         engine.set_data(X, Y)
         ed, k, _ = engine.elbo(p, jitter=1e-6, include_kl=(rk == 0))
         tot += ed

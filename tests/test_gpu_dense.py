@@ -47,6 +47,40 @@ def test_predict_matches_oracle(engine, N, M, Mg, D, ell, chunk, us):
             assert e < min(tol, 1e-6), (name, e, c)
 
 
+def test_predict_device_matches_oracle_and_the_host_entry_point(engine):
+    """zigp_predict_device (device X in, device (9,N) out: the companion of zigp_set_data_device) against the oracle's build_predict
+    (onoffgpf/OnOffSVGP.py:124-152) and bit for bit against zigp_predict; a host pointer is rejected, not dereferenced on the device."""
+    import ctypes as C
+    import torch
+    import zigp_oracle as o
+    from zigp import _lib
+    from zigp.engine import _Packed
+    X, Y, p = make_problem(3001, 70, 3, seed=12, Mg=45, ell=0.4)
+    engine.set_chunk(1024)                                  # three passes, the last one partial
+    Xd = torch.from_numpy(X).to('cuda:0')
+    for g_off in (0.0, -1.0):
+        out_d = engine.predict_device(p, Xd, jitter=1e-6, g_offset=g_off)
+        assert out_d.is_cuda and tuple(out_d.shape) == (9, 3001)
+        out_h = engine.predict(p, X, jitter=1e-6, g_offset=g_off)
+        assert np.array_equal(out_d.cpu().numpy(), out_h)
+        ref = o.build_predict(X, p, 1e-6, g_off)
+        tol = max(1e-9, 1e-13 * _cond(p, 1e-6))
+        for i in range(9):
+            assert relerr(out_h[i], ref[i].reshape(-1)) < min(tol, 1e-6), i
+    buf = torch.full((9, 3001), -7.0, dtype=torch.float64, device='cuda:0')
+    assert engine.predict_device(p, Xd, out=buf) is buf and np.array_equal(buf.cpu().numpy(), engine.predict(p, X))
+    assert tuple(engine.predict_device(p, Xd[:0]).shape) == (9, 0)
+    with pytest.raises(ValueError):
+        engine.predict_device(p, Xd.cpu())
+    with pytest.raises(ValueError):
+        engine.predict_device(p, Xd.float())
+    pk = _Packed(p)
+    host = np.zeros((9, 8))
+    rc = engine.lib.zigp_predict_device(engine.ctx, C.byref(pk.struct), C.c_void_p(X.ctypes.data), 8, 1e-6, 0.0, C.c_void_p(host.ctypes.data))
+    assert rc == _lib.ZIGP_EARG and b'device memory' in engine.lib.zigp_last_error(engine.ctx)
+    engine.set_chunk(16384)
+
+
 @pytest.mark.parametrize('N,M,Mg,D,ell,chunk,us', CASES)
 def test_elbo_and_gradient_match_oracle(engine, N, M, Mg, D, ell, chunk, us):
     import zigp_oracle_torch as ot
@@ -362,8 +396,13 @@ def test_chunk_rule_is_reported_by_the_library():
     e = zigp.DenseEngine(0)
     try:
         assert [e.get_chunk(M) for M in (1024, 1000, 512, 256, 128, 50, 2048)] == [32768, 32768, 65536, 131072, 131072, 131072, 32768]
+        # rows per pass of a given row range: equal passes; a short range in ONE pass while its panels fit 9 GB (M = 2048 and up
+        # fall back to the M-scaled chunk)
+        assert e.get_chunk_rows(1024, 1000000) == 32768 and e.get_chunk_rows(512, 100000) == 100352 and e.get_chunk_rows(1024, 125000) == 125952
+        assert e.get_chunk_rows(1024, 131072) == 131072 and e.get_chunk_rows(2048, 131072) == 32768 and e.get_chunk_rows(2048, 40000) == 40960
+        assert e.get_chunk_rows(1024, 0) == 1024
         e.set_chunk(4096)
-        assert e.get_chunk(1024) == 4096 and e.get_chunk(64) == 4096
+        assert e.get_chunk(1024) == 4096 and e.get_chunk(64) == 4096 and e.get_chunk_rows(512, 100000) == 4096
         with pytest.raises(ValueError):
             e.get_chunk(0)
         assert e.comm_info() == dict(rank=0, nranks=0, allreduce_calls=0)

@@ -154,3 +154,4 @@ def test_device_fit_loop_at_the_pptr_init_and_failure_report(engine):
     with pytest.raises(zigp.NotPositiveDefiniteError) as ei:
         bad.steps(rows_seq[:5], batch, 0.0, scale)
     assert 'step 0' in str(ei.value) and np.array_equal(bad.x, x0) and bad.t == 0
+    assert ei.value.steps_applied == 0 and ei.value.elbo_data.size == 0 and ei.value.kl.size == 0

@@ -9,8 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'zero-inflated-gp_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch, torch.distributed as dist
 import bench, zigp
-from zigp.parallel import ShardedELBO, ShardedKronELBO
+from zigp.parallel import ShardedELBO, ShardedKronELBO, ShardedKronFit
+from onofftf.model import KronDeviceFit
 from test_gpu_kron import make_kron_problem
+from test_cpu_host import _kron_pset
 
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', str(bench.free_port()))
 torch.cuda.set_device(0)
@@ -35,6 +37,17 @@ ref = dict(dense=eng.elbo(p), dense_value=eng.elbo(p, need_grad=False), dense_no
            kron=eng.kron_elbo(pk, Xk, Yk, scale=3.0, f_mu=0.25), kron_value=eng.kron_elbo(pk, Xk, Yk, need_grad=False),
            kron_nokl=eng.kron_elbo(pk, Xk, Yk, include_kl=False), kron_large=eng.kron_elbo(pl, Xl, Yl),
            kron_panel=eng.kron_elbo(pp, Xp, Yp), head=eng.kron_head_elbo(ph, Xk, (Yk > 0).astype(float), 'bernoulli', f_mu=0.1))
+# the device fit loop (zigp_kron_fit_steps: the all-reduce of each step's result block sits in front of k_fit_update): first WITHOUT a communicator
+FIT_ROWS = [0, 700, 1400, 300, 2000]
+fit_ref = {}
+for tag, (Xq, Yq, pq) in (('fit_32x32', (Xk, Yk, pk)), ('fit_10x100', (Xl, Yl, pl))):
+    eng.set_data(Xq, Yq)
+    ps = _kron_pset(pq)
+    f = KronDeviceFit(eng, ps)
+    rows = [r % (Xq.shape[0] - 500) for r in FIT_ROWS]
+    ed_, kl_ = f.steps(rows, 500, 1e-5, Xq.shape[0] / 500.0)
+    fit_ref[tag] = (ed_, kl_, f.x.copy(), f.m.copy(), f.v.copy())
+eng.set_data(X, Y)
 assert eng.comm_info()['nranks'] == 0
 sh = ShardedELBO(eng, dist, device='cuda:0', library_comm=True)      # the opt-in library communicator
 shk = ShardedKronELBO(eng, dist, device='cuda:0', library_comm=True)        # same engine: shares the communicator
@@ -47,6 +60,21 @@ for k in ref:
     assert same(ref[k], got[k]), k
 n = eng.comm_info()['allreduce_calls']
 assert n == len(ref) + 1, n                                # one all-reduce per step (+ the self-check), no more
+# ... and WITH the communicator, through the data-parallel wrapper (one rank: the sum is the identity, every bit must be the same)
+for tag, (Xq, Yq, pq) in (('fit_32x32', (Xk, Yk, pk)), ('fit_10x100', (Xl, Yl, pl))):
+    eng.set_data(Xq, Yq)
+    ps = _kron_pset(pq)
+    f = ShardedKronFit(eng, ps, dist, device='cuda:0', library_comm=True)
+    assert f.on_device and f.library_comm
+    rows = [r % (Xq.shape[0] - 500) for r in FIT_ROWS]
+    before = eng.comm_info()['allreduce_calls']
+    ed_, kl_ = f.steps(rows, 500, 1e-5, Xq.shape[0] / 500.0)
+    assert eng.comm_info()['allreduce_calls'] - before == len(rows), (tag, eng.comm_info()['allreduce_calls'] - before)   # one all-reduce per iteration
+    r_ = fit_ref[tag]
+    assert np.array_equal(ed_, r_[0]) and np.array_equal(kl_, r_[1]) and np.array_equal(f.fit.x, r_[2]) and np.array_equal(f.fit.m, r_[3]) and np.array_equal(f.fit.v, r_[4]), tag
+    assert f.t == len(rows)
+eng.set_data(X, Y)
+n = eng.comm_info()['allreduce_calls']
 # a non-PD Kuu is reported after the exchange, and the communicator keeps working
 bad = dict(p, Zf=p['Zf'].copy()); bad['Zf'][1] = bad['Zf'][0]
 try:

@@ -28,9 +28,11 @@ int zigp_comm_init(zigp_ctx* c, int32_t rank, int32_t nranks, const void* id128)
   // ncclCommInitRank is collective and has no timeout of its own: a peer that never arrives (crashed, RCCL not loadable there, another
   // id) would block this rank forever.  It runs on a helper thread; if it has not returned after comm_timeout_s (zigp_comm_set_timeout,
   // default 120 s, env ZIGP_COMM_TIMEOUT_S) the call gives up with ZIGP_ECOMM and leaves the helper behind (detached; the state it
-  // writes to is shared-owned, so a late return is harmless).  The caller should then fall back or exit -- never retry on this id.
+  // writes to is shared-owned).  If the helper's ncclCommInitRank does return later, nobody will ever use that communicator: the helper
+  // destroys it itself (`abandoned`).  While it is still blocked it holds RCCL's bootstrap sockets and a thread: after a timeout the
+  // process should fall back to the torch.distributed exchange or exit (os._exit or a fresh child process) -- never retry on this id.
   struct InitJob {
-    std::mutex m; std::condition_variable cv; bool done = false;
+    std::mutex m; std::condition_variable cv; bool done = false, abandoned = false;
     ncclResult_t r = ncclSuccess; hipError_t he = hipSuccess; ncclComm_t comm = nullptr; ncclUniqueId id;
   };
   auto job = std::make_shared<InitJob>();
@@ -41,13 +43,19 @@ int zigp_comm_init(zigp_ctx* c, int32_t rank, int32_t nranks, const void* id128)
     ncclResult_t r = ncclSuccess;
     const hipError_t he = hipSetDevice(device);          // the current device is per thread
     if (he == hipSuccess) r = api->CommInitRank(&comm, nranks, job->id, rank);
-    std::lock_guard<std::mutex> g(job->m);
-    job->he = he; job->r = r; job->comm = comm; job->done = true;
-    job->cv.notify_all();
+    bool late;
+    {
+      std::lock_guard<std::mutex> g(job->m);
+      job->he = he; job->r = r; job->comm = comm; job->done = true;
+      late = job->abandoned;
+      job->cv.notify_all();
+    }
+    if (late && he == hipSuccess && r == ncclSuccess && comm) (void)api->CommDestroy(comm);   // the caller gave up on it: do not leak it
   }).detach();
   {
     std::unique_lock<std::mutex> g(job->m);
     if (!job->cv.wait_for(g, std::chrono::duration<double>(c->comm_timeout_s), [&] { return job->done; })) {
+      job->abandoned = true;        // (under the lock: the helper sees it when it finishes)
       char b[256];
       snprintf(b, sizeof(b), "zigp_comm_init: ncclCommInitRank(rank %d of %d) did not return within %.0f s -- a peer never joined; "
                "giving up on this communicator", (int)rank, (int)nranks, c->comm_timeout_s);

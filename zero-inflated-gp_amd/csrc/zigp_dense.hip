@@ -349,23 +349,25 @@ int dense_mxm_forward(zigp_ctx* c, DenseCall& k) {
 // that the last chunk is not a sliver whose GEMMs leave most of the 512 workgroup slots empty (N = 1e5, chunk 32768: 4 x 25600).
 // Unless the caller fixed it (zigp_set_chunk), the chunk scales with 1 / M so that a launch keeps its ~2000 tiles (4 waves of the 512
 // workgroup slots) and the panels their size: 32768 rows at M = 1024, 65536 at M = 512 (cfg2: 2 chunks instead of 4, 8.05 -> 7.6 ms)
-int64_t auto_chunk(const zigp_ctx* c) {
-  if (!c->chunk_auto) return c->chunk;
-  const int64_t Mmax = std::max(c->lat[0].Mp, c->lat[1].Mp);
-  return std::min<int64_t>(131072, std::max<int64_t>(32768, round_up(32768 * 1024 / std::max<int64_t>(Mmax, 128), 1024)));
+int64_t auto_chunk_for(bool chunk_auto, int64_t chunk_set, int64_t Mp) {
+  if (!chunk_auto) return chunk_set;
+  return std::min<int64_t>(131072, std::max<int64_t>(32768, round_up(32768 * 1024 / std::max<int64_t>(Mp, 128), 1024)));
+}
+// Rows per pass for a row range of `span` rows.  A range of up to 131072 rows goes through in ONE pass unless the caller fixed the chunk: no
+// chunk boundary (where the side stream's kgrads outlast the rank-N updates), one prologue / tail per product instead of two to four -- cfg2
+// (1e5 rows, M = 512) 5.98 -> 5.81 ms, the 125 000-row shard of cfg3 23.4 -> 23.0 ms (tools/chunk_sweep.py, profiles/r04ao_chunk_sweep.log).
+// The rule is bounded by the panels' bytes (4 panels of 8 Mp span bytes per latent: <= 9 GB, i.e. M <= 1024 at 131072 rows -- what was
+// measured); beyond that, and on long ranges, the M-scaled chunk applies (cfg3: 32768 rows 167.8 ms, 65536: 170.2, 131072: 169.2).
+int64_t chunk_rows_for(bool chunk_auto, int64_t chunk_set, int64_t Mp, int64_t span) {
+  int64_t chunk = auto_chunk_for(chunk_auto, chunk_set, Mp);
+  if (chunk_auto && span > 0 && span <= 131072 && 4 * 2 * 8 * Mp * round_up(span, 1024) <= ((int64_t)9 << 30)) chunk = 131072;
+  if (span <= 0) return 1024;
+  const int64_t nchunks = (span + chunk - 1) / chunk;
+  return std::max<int64_t>(1024, round_up((span + nchunks - 1) / nchunks, 1024));
 }
 int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
   const int64_t span = k.has_rows ? (k.row_end - k.row_begin) : 0;
-  // A row range of up to 131072 rows goes through in ONE pass unless the caller fixed the chunk: no chunk boundary (where the side stream's
-  // kgrads outlast the rank-N updates), one prologue / tail per product instead of two to four -- cfg2 (1e5 rows, M = 512) 5.98 -> 5.81 ms, the
-  // 125 000-row shard of cfg3 23.4 -> 23.0 ms; long ranges stay at the M-scaled chunk (cfg3: 32768 rows 167.8 ms, 65536: 170.2, 131072: 169.2;
-  // tools/chunk_sweep.py, profiles/r04ao_chunk_sweep.log)
-  const int64_t chunk = (c->chunk_auto && span > 0 && span <= 131072) ? 131072 : auto_chunk(c);
-  k.Nc = 1024;
-  if (span > 0) {
-    const int64_t nchunks = (span + chunk - 1) / chunk;
-    k.Nc = std::max<int64_t>(1024, round_up((span + nchunks - 1) / nchunks, 1024));
-  }
+  k.Nc = chunk_rows_for(c->chunk_auto, c->chunk, std::max(c->lat[0].Mp, c->lat[1].Mp), span);
   const int64_t Nc = k.Nc;
   const int D = k.D;
   k.pw_blocks = (int)(Nc / PW_PTS);
@@ -659,9 +661,12 @@ int zigp_set_pivot_rtol(zigp_ctx* c, double rtol) {
 
 int64_t zigp_get_chunk(zigp_ctx* c, int32_t M) {
   if (!c || M <= 0) return ZIGP_EARG;
-  if (!c->chunk_auto) return c->chunk;
-  const int64_t Mp = round_up(M, BM);
-  return std::min<int64_t>(131072, std::max<int64_t>(32768, round_up(32768 * 1024 / std::max<int64_t>(Mp, 128), 1024)));
+  return auto_chunk_for(c->chunk_auto, c->chunk, round_up(M, BM));
+}
+
+int64_t zigp_get_chunk_rows(zigp_ctx* c, int32_t M, int64_t span) {
+  if (!c || M <= 0 || span < 0) return ZIGP_EARG;
+  return chunk_rows_for(c->chunk_auto, c->chunk, round_up(M, BM), span);
 }
 
 static_assert(MAXD == 8, "zigp_ctx::mean_a / mean_da hold MAXD entries");
@@ -762,6 +767,22 @@ int zigp_predict(zigp_ctx* c, const zigp_params* p, const double* Xnew, int64_t 
   ZIGP_HIP(c, hipMemcpyAsync(out9, c->out9.p, sizeof(double) * 9 * N, hipMemcpyDeviceToHost, c->stream));
   ZIGP_HIP(c, hipStreamSynchronize(c->stream));
   return ZIGP_OK;
+}
+
+int zigp_predict_device(zigp_ctx* c, const zigp_params* p, const double* dXnew, int64_t N, double jitter, double g_offset, double* d_out9) {
+  if (!c) return ZIGP_EARG;
+  ZIGP_TRY(validate_params(c, p));
+  if (N < 0 || (N > 0 && (!dXnew || !d_out9))) return fail_arg(c, "zigp_predict_device: bad arguments");
+  if (N == 0) return ZIGP_OK;
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  hipPointerAttribute_t ax, ao;     // both must be device memory of this context's GPU (a host pointer here would fault inside a kernel)
+  if (hipPointerGetAttributes(&ax, dXnew) != hipSuccess || hipPointerGetAttributes(&ao, d_out9) != hipSuccess ||
+      ax.type != hipMemoryTypeDevice || ao.type != hipMemoryTypeDevice || ax.device != c->device || ao.device != c->device) {
+    (void)hipGetLastError();
+    return fail_arg(c, "zigp_predict_device: Xnew and out9 must be device memory of the context's GPU");
+  }
+  // rows in place: no copy in, no copy out; the call is complete on return (run_dense ends with the stream's synchronisation)
+  return run_dense(c, p, dXnew, nullptr, N, p->D, jitter, 1.0, g_offset, 0, N, 0, true, d_out9, nullptr, nullptr, nullptr);
 }
 
 int zigp_prior_kl(zigp_ctx* c, const zigp_params* p, double jitter, double* kl2) {

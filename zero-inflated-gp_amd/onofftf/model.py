@@ -90,26 +90,47 @@ class KronDeviceFit:
         self.x = np.concatenate([q.free() for q in ps])
         self.m, self.v = np.zeros_like(self.x), np.zeros_like(self.x)
         self.t = 0
+        self._written = [q.value.copy() for q in ps]      # what the ParamSet held when x was last derived from / written to it
         v = pset.params
         self.shape = dict(M0f=v['f_ind/z_0'].value.shape[0], M1f=v['f_ind/z_1'].value.shape[0], M0g=v['g_ind/z_0'].value.shape[0],
                           M1g=v['g_ind/z_1'].value.shape[0], D0=v['f_ind/z_0'].value.shape[1], D1=v['f_ind/z_1'].value.shape[1])
 
-    def steps(self, row_begin, batch, jitter, scale, Xw=None, Yw=None):
+    def steps(self, row_begin, batch, jitter, scale, Xw=None, Yw=None, include_kl=True):
         """len(row_begin) iterations on the resident data set (engine.set_data): returns (elbo_data, kl) per step; the ParamSet holds the
-        constrained values after the last one.  If the engine raises (a Cholesky failure), x / m / v are the state before the failing step."""
+        constrained values after the last one.  If the engine raises in step k (a Cholesky failure), x / m / v are the state after the k
+        updates that WERE applied, self.t has advanced by k, and the exception carries `steps_applied`, `elbo_data`, `kl` of those steps:
+        a caller that catches it and goes on (with more jitter, say) continues with the right iteration count and bias correction.
+        The ParamSet is read again when something other than this object changed it since the last call (load_checkpoint, an assignment
+        to .value): see resync().  include_kl: False on the ranks > 0 of a data-parallel fit (zigp.parallel.ShardedKronFit)."""
+        if self._stale():
+            self.resync()
         try:
             out = self.engine.kron_fit_steps(self.shape, self.x, self.m, self.v, self.lr, self.positive, self.t, row_begin, batch, jitter=jitter,
-                                             scale=scale, Xw=Xw, Yw=Yw, beta1=self.beta1, beta2=self.beta2, eps=self.eps)
+                                             scale=scale, Xw=Xw, Yw=Yw, beta1=self.beta1, beta2=self.beta2, eps=self.eps, include_kl=include_kl)
             self.t += len(row_begin)
+        except Exception as e:
+            self.t += int(getattr(e, 'steps_applied', 0))
+            raise
         finally:
             self.sync_params()
         return out
+
+    def _stale(self):
+        """did anyone else write the ParamSet since sync_params? (cheap: ~20 small arrays against the copies kept there)"""
+        return any(not np.array_equal(self.pset.params[k].value, w) for k, w in zip(FIT_BLOCK_NAMES, self._written))
+
+    def resync(self):
+        """Take the free state from the ParamSet again (after load_checkpoint or a manual assignment); Adam's moments and the iteration
+        count are kept -- reset them by making a new KronDeviceFit if the parameters are unrelated to the ones trained so far."""
+        self.x = np.concatenate([self.pset.params[k].free() for k in FIT_BLOCK_NAMES])
+        self._written = [self.pset.params[k].value.copy() for k in FIT_BLOCK_NAMES]
 
     def sync_params(self):
         o = 0
         for k, n in zip(FIT_BLOCK_NAMES, self.sizes):
             self.pset.params[k].set_free(self.x[o:o + n])
             o += n
+        self._written = [self.pset.params[k].value.copy() for k in FIT_BLOCK_NAMES]
 
 
 def save_checkpoint(pset, path):

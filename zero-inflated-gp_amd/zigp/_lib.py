@@ -79,6 +79,7 @@ SIGNATURES = {
     'zigp_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64,
                             C.c_int32, dp, dp, C.POINTER(zigp_grads)]),
     'zigp_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), dp, C.c_int64, C.c_double, C.c_double, dp]),
+    'zigp_predict_device': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p]),
     'zigp_prior_kl': (C.c_int, [C.c_void_p, C.POINTER(zigp_params), C.c_double, dp]),
     'zigp_rbf_K': (C.c_int, [C.c_void_p, dp, C.c_int64, dp, C.c_int64, C.c_int32, dp, C.c_double, dp]),
     'zigp_kron_elbo': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -89,6 +90,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_int64, dp, dp, C.c_double, C.c_double, C.c_int32, dp, dp]),
     'zigp_kron_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, C.c_int64, C.c_double, C.c_double, C.c_double, dp]),
     'zigp_get_chunk': (C.c_int64, [C.c_void_p, C.c_int32]),
+    'zigp_get_chunk_rows': (C.c_int64, [C.c_void_p, C.c_int32, C.c_int64]),
     'zigp_set_pivot_rtol': (C.c_int, [C.c_void_p, C.c_double]),
     'zigp_comm_unique_id': (C.c_int, [C.c_void_p]),
     'zigp_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

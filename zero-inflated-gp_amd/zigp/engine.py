@@ -171,6 +171,14 @@ class DenseEngine:
             raise ValueError('zigp_get_chunk: bad M')
         return r
 
+    def get_chunk_rows(self, M, span):
+        """rows per pass the dense path uses for a row range of `span` rows at M inducing points per latent (equal passes; short ranges
+        go through in one pass while the panels stay within 9 GB)"""
+        r = int(self.lib.zigp_get_chunk_rows(self.ctx, int(M), int(span)))
+        if r < 0:
+            raise ValueError('zigp_get_chunk_rows: bad M or span')
+        return r
+
     def set_pivot_rtol(self, rtol):
         """smallest accepted Cholesky pivot = rtol * eps * (variance + jitter); default 8, 0 = tf.cholesky's bare pivot > 0 test"""
         _check(self.lib, self.ctx, self.lib.zigp_set_pivot_rtol(self.ctx, float(rtol)))
@@ -301,6 +309,25 @@ class DenseEngine:
         out = np.zeros((9, Xnew.shape[0]))
         _check(self.lib, self.ctx, self.lib.zigp_predict(self.ctx, C.byref(pk.struct), ptr(Xnew), Xnew.shape[0], float(jitter),
                                                           float(g_offset), ptr(out)))
+        return out
+
+    def predict_device(self, p, X_t, jitter=1e-6, g_offset=0.0, out=None):
+        """predict on a torch CUDA float64 tensor (N,D) of the engine's device; returns (or fills `out` with) a (9,N) CUDA tensor in the
+        order of OnOffSVGP.build_predict -- nothing but the parameters crosses PCIe."""
+        import torch
+        pk = _Packed(p)
+        self._set_mean_function(p, pk.D)
+        if not (X_t.is_cuda and X_t.device.index == self.device and X_t.dtype == torch.float64 and X_t.is_contiguous() and X_t.dim() == 2 and X_t.shape[1] == pk.D):
+            raise ValueError('predict_device: need a contiguous float64 (N,%d) tensor on cuda:%d' % (pk.D, self.device))
+        N = int(X_t.shape[0])
+        if out is None:
+            out = torch.empty((9, N), dtype=torch.float64, device=X_t.device)
+        elif not (out.is_cuda and out.device.index == self.device and out.dtype == torch.float64 and out.is_contiguous() and tuple(out.shape) == (9, N)):
+            raise ValueError('predict_device: out must be a contiguous float64 (9,N) tensor on the same device')
+        torch.cuda.current_stream(self.device).synchronize()      # the engine's streams are not ordered after torch's
+        if N:
+            _check(self.lib, self.ctx, self.lib.zigp_predict_device(self.ctx, C.byref(pk.struct), C.c_void_p(X_t.data_ptr()), N, float(jitter),
+                                                                     float(g_offset), C.c_void_p(out.data_ptr())))
         return out
 
     def prior_kl(self, p, jitter=1e-6):
@@ -449,7 +476,17 @@ class DenseEngine:
         rc = self.lib.zigp_kron_fit_steps(self.ctx, C.byref(s), C.byref(o), ptr(x), ptr(m), ptr(v), x.size, int(t0), n, rb.ctypes.data, int(batch),
                                           ptr(xw) if xw is not None else None, ptr(yw) if yw is not None else None, float(jitter), float(scale),
                                           1 if include_kl else 0, ptr(ed), ptr(kl))
-        _check(self.lib, self.ctx, rc)
+        try:
+            _check(self.lib, self.ctx, rc)
+        except ZigpError as e:
+            # include/zigp.h: after a failure x / m / v hold the state before the failing step and the history from that step on is NaN --
+            # the caller learns how many updates WERE applied (its iteration count and Adam's bias correction depend on it) and gets the
+            # history of those steps
+            fin = np.isfinite(ed)
+            done = 0 if (n == 0 or fin.all()) else int(np.argmin(fin))     # (all finite: the call failed before any step ran)
+            e.steps_applied = done
+            e.elbo_data, e.kl = ed[:done].copy(), kl[:done].copy()
+            raise
         return ed, kl
 
     def kron_stepper(self, p):

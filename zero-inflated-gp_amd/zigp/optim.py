@@ -89,15 +89,27 @@ class AdamGroups:
         self.pset = pset
         self.b1, self.b2, self.eps = beta1, beta2, eps
         self.t = 0
-        self.x = {k: pset.params[k].free().copy() for k in pset.names()}
         self.m = {k: np.zeros(pset.params[k].value.size) for k in pset.names()}
         self.v = {k: np.zeros(pset.params[k].value.size) for k in pset.names()}
+        self.resync()
+
+    def resync(self):
+        """Take the free vectors from the ParamSet again.  step() does this by itself for any parameter whose constrained value is no
+        longer the one it wrote (load_checkpoint, an assignment to .value): the cached free vector would silently overwrite such a change.
+        The moments and the iteration count are kept."""
+        self.x = {k: self.pset.params[k].free().copy() for k in self.pset.names()}
+        self._written = {k: self.pset.params[k].value.copy() for k in self.pset.names()}
 
     def step(self, grads):
         """One minimisation step of cost = -ELBO given d ELBO / d (constrained)."""
         self.t += 1
         for k in self.pset.names():
             p = self.pset.params[k]
+            if k not in self.m:                                    # un-fixed since construction: it joins with fresh moments
+                self.m[k], self.v[k] = np.zeros(p.value.size), np.zeros(p.value.size)
+                self._written[k] = None
+            if self._written[k] is None or not np.array_equal(p.value, self._written[k]):   # changed behind our back: start from what the ParamSet holds now
+                self.x[k] = p.free().copy()
             x = self.x[k]
             g = -np.asarray(p.transform.grad_free(x, np.asarray(grads[k], dtype=np.float64).reshape(-1))).reshape(-1)
             self.m[k] = self.b1 * self.m[k] + (1 - self.b1) * g
@@ -105,3 +117,4 @@ class AdamGroups:
             lr_t = p.learning_rate * np.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
             self.x[k] = x - lr_t * self.m[k] / (np.sqrt(self.v[k]) + self.eps)
             p.set_free(self.x[k])
+            self._written[k] = p.value.copy()

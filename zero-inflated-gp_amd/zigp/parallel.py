@@ -186,3 +186,45 @@ class ShardedKronELBO(_Sharded):
         gv, spec = _flatten_kron(g)
         out = self._allreduce_host(np.concatenate([np.array([ed, kl]), gv]))
         return float(out[0]), float(out[1]), _unflatten_kron(out[2:], spec)
+
+
+class ShardedKronFit(_Sharded):
+    """Data-parallel form of the reference's training loop (scripts/onoff.py:375-381: minibatch gradient of -ELBO, Log1pe chain, one Adam
+    per learning rate): every rank holds the same parameters and Adam state, steps on a minibatch of ITS OWN resident shard, and the
+    step's result block is summed over the ranks before the update -- so the parameters stay identical without ever being exchanged.
+
+    With the library communicator (library_comm=True and it formed: zigp_comm_init) the whole loop runs on the device
+    (onofftf.model.KronDeviceFit -> zigp_kron_fit_steps; the all-reduce of each step's result block is an ncclAllReduce on the engine's
+    stream in front of k_fit_update, one host synchronisation per call).  Otherwise (gloo rehearsals, two ranks on one GPU, RCCL not
+    loadable) the same iterations run on the host: ShardedKronELBO's all-reduced gradient + zigp.optim.AdamGroups, one engine call per
+    iteration.  Both give every rank the single-process result of the same batches (sum order aside).
+    scale is the minibatch scale of the WHOLE job, num_data / (rows of all ranks' batches) (scripts/onoff.py:311)."""
+
+    def __init__(self, engine, pset, dist=None, device=None, library_comm=None, beta1=0.9, beta2=0.999, eps=1e-8):
+        super().__init__(engine, dist, device, library_comm)
+        from onofftf.model import KronDeviceFit
+        self.pset = pset
+        self.on_device = dist is None or self.library_comm
+        if self.on_device:
+            self.fit = KronDeviceFit(engine, pset, beta1=beta1, beta2=beta2, eps=eps)
+        else:
+            from .optim import AdamGroups
+            self.adam = AdamGroups(pset, beta1=beta1, beta2=beta2, eps=eps)
+            self._elbo = ShardedKronELBO(engine, dist, device=device, library_comm=False)
+
+    @property
+    def t(self):
+        return self.fit.t if self.on_device else self.adam.t
+
+    def steps(self, row_begin, batch, jitter, scale):
+        """len(row_begin) iterations; row_begin[i] = first row (of THIS rank's resident shard) of its batch i.  Returns the history
+        (elbo_data[n], kl[n]) summed over ranks, each at the parameters before that step's update; the ParamSet holds the new values."""
+        if self.on_device:
+            return self.fit.steps(row_begin, batch, jitter, scale, include_kl=(self.rank == 0))
+        from onofftf.model import engine_params, named_grads
+        ed_h, kl_h = np.zeros(len(row_begin)), np.zeros(len(row_begin))
+        for i, rb in enumerate(row_begin):
+            ed, kl, g = self._elbo.kron_elbo(engine_params(self.pset), jitter=jitter, scale=scale, rows=(int(rb), int(rb) + int(batch)))
+            ed_h[i], kl_h[i] = ed, kl
+            self.adam.step(named_grads(g))
+        return ed_h, kl_h
