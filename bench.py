@@ -247,7 +247,7 @@ def timeit(f, n, warm):
 
 def kron_fused_products(nb0, nb1, large):
     """16x16x4 MFMA products the fused Kronecker kernels EXECUTE per 16-point tile and latent (forward kernel + backward kernel, which
-    recomputes the forward tile), for a grid of nb0 x nb1 16-row blocks (csrc/zigp_kronf.hip, zigp_kronl.h):
+    recomputes the forward tile), for a grid of nb0 x nb1 16-row blocks (csrc/zigp_kronf.hip, zigp_kronl.h; HISTORY.md section 5b):
     forward A0, A1, B0, C0; backward + B1, C1, P0 dA0, P1 dA1, the sums over points dAlpha, dS2, dP0, dP1 and the moment products."""
     fwd = 4 * (nb0 * nb0 + nb1 * nb1 + 2 * nb0 * nb1)
     bwd = fwd + 2 * 4 * nb0 * nb1 + 4 * (nb0 * nb0 + nb1 * nb1) + 4 * (2 * nb0 * nb1 + nb0 * nb0 + nb1 * nb1) + 4 * (nb0 + nb1)
@@ -255,7 +255,7 @@ def kron_fused_products(nb0, nb1, large):
 
 
 def kron_roofline(n_rows, t, nb0, nb1, large=False):
-    """cfg5-style entries: the path is MFMA / VALU-issue bound, not HBM bound -- executed matrix flops over the step"""
+    """cfg5-style entries: the path is MFMA / VALU-issue bound, not HBM bound (HISTORY.md section 5b) -- executed matrix flops over the step"""
     tiles = (n_rows + 15) // 16
     fl = 2.0 * tiles * kron_fused_products(nb0, nb1, large) * 2048.0        # two latents; a 16x16x4 product = 2048 flop
     return dict(executed_mfma_flops=fl, tflops=fl / t / 1e12, frac_mfma=fl / t / PEAK_FP64_MFMA,

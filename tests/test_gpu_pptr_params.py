@@ -7,7 +7,7 @@ The spatial factor is the badly conditioned one.  Where th
 part by more than 1e-6, the test applies the rule of tests/test_gpu_kron.py: the GPU must stay within 3x of the OP-ORDER FLOOR -- the
 distance from the oracle of the same factored identities evaluated on the CPU with the oracle's own LU inverse (values) or its autograd
 (gradients) -- and within 10x of the oracle's own error against a 40-digit evaluation.  Every number is printed (and recorded in
-DESIGN.md section 1)."""
+HISTORY.md section 1)."""
 import os
 
 import mpmath as mp
@@ -59,7 +59,7 @@ def _inv_compensated():
 
 
 def _factored_elbo_and_grad_torch(X, Y, p_np, jitter, scale, compensated=False):
-    """The FACTORED identities the engine evaluates (DESIGN.md section 5b / SURVEY.md a10, a11), on the CPU in torch with the oracle's own
+    """The FACTORED identities the engine evaluates (HISTORY.md section 5b / SURVEY.md a10, a11), on the CPU in torch with the oracle's own
     inverse (torch.linalg.inv, LU) and autograd: its distance from the literal dense order is what the op order alone costs.
     compensated: the reverse pass of the inverse in 40 digits (_inv_compensated) -- the accurate evaluation of the same algebra, against
     which the literal oracle's OWN float64 error on the ill-conditioned gradient blocks is measured."""

@@ -466,7 +466,7 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
       ZIGP_HIP(c, hipEventRecord(c->ev_fork, c->stream_main));
       ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
       c->stream = c->stream2;
-      // (the next chunk's panels BEFORE this chunk's kgrads was measured and dropped: cfg2 +0.1 ms)
+      // (the next chunk's panels BEFORE this chunk's kgrads was measured and dropped: cfg2 +0.1 ms, HISTORY.md section 5 r4)
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], k.dX, k.Nrows, n0, Nc, D, k.ell_h[h]));
       if (kuf_side)
         for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]));

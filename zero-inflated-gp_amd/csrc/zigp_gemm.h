@@ -427,7 +427,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
     return lds + (it % NSTAGE) * STAGE_DOUBLES;
   };
   // One BK step of this wave's RW x 64 sub-tile, fully unrolled.  The loop has ONE body per statement (runtime predicates inside the
-  // unrolled nest, and a choice of bodies, spill and pessimise its schedule).
+  // unrolled nest, and a choice of bodies, spill and pessimise its schedule; HISTORY.md section 5).
   auto body = [&](const double* As, auto mask_c) {     // mask_c: which of the wave's sub-tile rows take part (bit tm)
     constexpr int MASK = decltype(mask_c)::value;
     const double* Bs = As + TILE_DOUBLES;

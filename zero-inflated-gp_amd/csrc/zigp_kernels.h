@@ -287,7 +287,7 @@ constexpr int KG_SPLIT = 4;   // column splits (blockIdx.y); each split accumula
 // cfg3 -0.3 ... -1.1 ms per step, cfg2 -1.3 %): beside MFMA-bound products that leave 7 of the 8 TB/s of HBM idle, fp64 VALU work costs
 // more than bytes.  K stays valid until this kernel is done: the next chunk's panels are built behind it on the same stream
 // (dense_chunk_loop).  (The recomputing form, the eight-way column split and a slim 1-row x 2-column version are in
-// tools/r4_experiment_arms.patch and DESIGN.md section 5.)
+// tools/r4_experiment_arms.patch and HISTORY.md section 5.)
 template <int D>
 __global__ void __launch_bounds__(256)
 k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const double* __restrict__ alpha,

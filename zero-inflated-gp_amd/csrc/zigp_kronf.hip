@@ -1006,7 +1006,7 @@ k_kf_finish(KfFinishArgs a) {
   __syncthreads();
   if (p == 0) {
     // (rounds 3: these ran one thread per element with k in ascending order, to keep the last digits of d var / d ell where a test's
-    // "op-order floor" margin had seen them; with the compensated sandwich below that margin is gone -- section 1 of DESIGN.md -- and
+    // "op-order floor" margin had seen them; with the compensated sandwich below that margin is gone -- section 1 of HISTORY.md -- and
     // the products are back on the MFMA pipe, the independent ones of the phase on different waves)
     kf_lds_mm<false, false, false>(sX, sdAl, sPo, Mq0, Mq1, Mq1);           // X = dAl P1
     kf_lds_mm<false, true, true>(sdP, sdAl, sT, Mq0, Mq0, Mq1, 4);          // dP0 += dAl T0^T
