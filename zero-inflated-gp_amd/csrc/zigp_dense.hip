@@ -147,34 +147,66 @@ int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, i
   return 0;
 }
 
-// Forward panels of one latent for the chunk starting at row n0: A1, A2 (+ H, J' when a gradient is wanted), column partials.
-int latent_chunk_forward(zigp_ctx* c, Latent& lt, int64_t Nc, bool need_grad) {
-  const int Mp = lt.Mp, nbm = Mp / BM, nbn = (int)(Nc / BN);
-  const int np = Mp / 32;   // allocated partial rows per fused column sum (a kernel writes one per wave tile: 64 or 32 rows)
-  TileList tl, tu;
-  const bool paired = trmm_paired_pays(nbm, nbn);
-  ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, tl, paired));
-  ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, tu, paired));
-  const double fl = (double)lt.M * lt.M * (double)Nc;
-  {
-    ProfScope ps(c, PC_GEMM_A1, fl);   // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
-    EpiStoreColsum ep{lt.vec.p, nullptr, lt.part.p, lt.part.p + (size_t)np * Nc};
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, tl, mk_args(lt.Wt.p, Mp, lt.K.p, Nc, lt.A1.p, Nc), ep)));
-  }
-  {
-    ProfScope ps(c, PC_GEMM_A2, fl);   // A2 = W^T A1 ; partial column sums  sum s^2 A2^2
-    EpiStoreColsum ep{nullptr, lt.s2.p, nullptr, lt.part.p + (size_t)2 * np * Nc};
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, tu, mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc), ep)));
-  }
-  if (need_grad) {
+// Forward panels of both latents for one chunk: A1, A2 (+ J' when a gradient is wanted), column partials.
+// Where the triangular products run the paired order (equal-length units filling whole waves of the 512 resident workgroups: cfg3), each
+// product class is ONE launch for both latents (run_gemm2: latent g's workgroups fill the tail of latent f's; cfg3 -0.8 % same-box,
+// profiles/r05l_ab_merge_fg.log).  Not in the LPT regime (cfg2: +1.2 % merged -- there a product reads the panel the previous launch of
+// the SAME latent has just written, part of it still in the 256 MB Infinity Cache, and the merged order A1f A1g A2f A2g puts a whole
+// panel of the other latent in between), and not for the rank-N update (its 512-workgroup split-K plan fills the chip exactly: +0.2 %).
+int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad) {
+  const int nbn = (int)(Nc / BN);
+  struct Set { TileList tl, tu, tf; double fl; GemmArgs a1, a2, j; EpiStoreColsum e1, e2; } q[2];
+  bool merge = true;
+  for (int h = 0; h < 2; ++h) {
+    Latent& lt = c->lat[h];
+    const int Mp = lt.Mp, nbm = Mp / BM;
+    const int np = Mp / 32;   // allocated partial rows per fused column sum (a kernel writes one per wave tile: 64 or 32 rows)
+    const bool paired = trmm_paired_pays(nbm, nbn);
+    merge = merge && paired;
+    ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, q[h].tl, paired));
+    ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, q[h].tu, paired));
+    if (need_grad) ZIGP_TRY(tiles_full_xcd(c, nbm, nbn, nbm * (BM / BK), q[h].tf));
+    q[h].fl = (double)lt.M * lt.M * (double)Nc;
+    // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
+    q[h].a1 = mk_args(lt.Wt.p, Mp, lt.K.p, Nc, lt.A1.p, Nc);
+    q[h].e1 = EpiStoreColsum{lt.vec.p, nullptr, lt.part.p, lt.part.p + (size_t)np * Nc};
+    // A2 = W^T A1 ; partial column sums  sum s^2 A2^2
+    q[h].a2 = mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc);
+    q[h].e2 = EpiStoreColsum{nullptr, lt.s2.p, nullptr, lt.part.p + (size_t)2 * np * Nc};
     // J' = Q A2, Q = Kuu^-1 diag(s^2) - I (M x M, dense): the two triangular products H = W diag(s^2) A2, J' = W^T H - A2 of the reverse
     // pass as ONE full product of the same flop count -- every tile the full k range (no triangular padding, half as many prologues and
     // epilogues per flop), no H panel written and read back, no operand tile in the epilogue (r4: J' 61.9 -> 70.2 TFLOP/s, step -3.8 %,
     // profiles/r04ak_ab_qform.log; the two-product form is in tools/r4_experiment_arms.patch).
-    TileList tf;
-    ZIGP_TRY(tiles_full_xcd(c, nbm, nbn, nbm * (BM / BK), tf));
-    ProfScope ps(c, PC_GEMM_J, 2.0 * fl);
-    ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, tf, mk_args(lt.Qt.p, Mp, lt.A2.p, Nc, lt.Jp.p, Nc), EpiStorePanel())));
+    q[h].j = mk_args(lt.Qt.p, Mp, lt.A2.p, Nc, lt.Jp.p, Nc);
+  }
+  if (merge) {
+    {
+      ProfScope ps(c, PC_GEMM_A1, q[0].fl + q[1].fl);
+      ZIGP_TRY((run_gemm2<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, q[0].tl, q[0].a1, q[0].e1, q[1].tl, q[1].a1, q[1].e1)));
+    }
+    {
+      ProfScope ps(c, PC_GEMM_A2, q[0].fl + q[1].fl);
+      ZIGP_TRY((run_gemm2<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, q[0].tu, q[0].a2, q[0].e2, q[1].tu, q[1].a2, q[1].e2)));
+    }
+    if (need_grad) {
+      ProfScope ps(c, PC_GEMM_J, 2.0 * (q[0].fl + q[1].fl));
+      ZIGP_TRY((run_gemm2<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, q[0].tf, q[0].j, EpiStorePanel(), q[1].tf, q[1].j, EpiStorePanel())));
+    }
+    return 0;
+  }
+  for (int h = 0; h < 2; ++h) {
+    {
+      ProfScope ps(c, PC_GEMM_A1, q[h].fl);
+      ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, q[h].tl, q[h].a1, q[h].e1)));
+    }
+    {
+      ProfScope ps(c, PC_GEMM_A2, q[h].fl);
+      ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, q[h].tu, q[h].a2, q[h].e2)));
+    }
+    if (need_grad) {
+      ProfScope ps(c, PC_GEMM_J, 2.0 * q[h].fl);
+      ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, q[h].tf, q[h].j, EpiStorePanel())));
+    }
   }
   return 0;
 }
@@ -456,7 +488,7 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
       ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0));
       side_busy = false;
     }
-    for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_forward(c, c->lat[h], Nc, k.need_grad));
+    ZIGP_TRY(chunk_forward(c, Nc, k.need_grad));
     ZIGP_TRY(dense_pointwise(c, k, n0, Nc));
     // side work of this chunk: its kgrads and the next chunk's Kuf panels (gradient mode only: without the SYRKs there is
     // nothing on the main stream to hide them under)

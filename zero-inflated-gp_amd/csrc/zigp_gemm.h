@@ -524,7 +524,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 
 template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, int WAVES, class Epi>
 __global__ void __launch_bounds__(64 * WAVES, ((NSTAGE <= 2) ? 2 : 1) * WAVES / 4)
-gemm_f64_kernel(GemmArgs g, Epi epi) {
+gemm_f64_kernel(GemmArgs g, Epi epi, GemmArgs g1, Epi epi1, int split) {
+  // Two argument sets in one launch (the chunk loop's products of latent f and latent g): workgroups [0, split) run set 0 with
+  // list position blockIdx.x, workgroups [round_up(split, 8), gridDim.x) run set 1 with list position blockIdx.x - round_up(split, 8)
+  // (the lists are built for "launch position p runs on XCD p % 8"); the workgroups in between are padding.  A plain launch passes
+  // split = gridDim.x.  The choice is made once per workgroup, in scalar registers.
+  int wg = blockIdx.x;
+  if (wg >= split) {
+    const int s8 = (split + 7) & ~7;
+    if (wg < s8) return;
+    wg -= s8; g = g1; epi = epi1;
+  }
   constexpr int WNW = Shape<WAVES>::WNW;
   static_assert(TILE_DOUBLES >= 128 * 16 + 16, "padded k-contiguous image must fit the stage");
   extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
@@ -533,7 +543,7 @@ gemm_f64_kernel(GemmArgs g, Epi epi) {
   const int wm = wave / WNW, wn = wave % WNW;
   bool ring_used = false;
   for (int u = 0; u < g.per; ++u) {
-  const GemmTile tl = g.tiles[(int64_t)blockIdx.x * g.per + u];
+  const GemmTile tl = g.tiles[(int64_t)wg * g.per + u];
   if (tl.kend <= tl.kbeg) continue;                 // padding entry (uniform over the workgroup)
   if (ring_used) __builtin_amdgcn_s_barrier();      // slower waves may still read the previous tile's last stage
   ring_used = true;

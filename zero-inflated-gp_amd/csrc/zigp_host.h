@@ -62,7 +62,30 @@ static int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, KS, TRI, WV, EP>), dim3(tl.n / tl.per), dim3(64 * WV), shm, c->stream, g, ep);
+  const int nwg = tl.n / tl.per;
+  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, KS, TRI, WV, EP>), dim3(nwg), dim3(64 * WV), shm, c->stream, g, ep, g, ep, nwg);
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+// The same product for two argument sets (latent f and latent g of one chunk) in ONE launch: set 1's workgroups follow set 0's in the
+// dispatch order, so the tail of one product is filled by the head of the other and a chunk costs four launch boundaries instead of
+// eight.
+template <int AL, int BL, bool KS, int TRI = TRI_NONE, class EP>
+static int run_gemm2(zigp_ctx* c, const TileList& tl0, GemmArgs g0, EP ep0, const TileList& tl1, GemmArgs g1, EP ep1) {
+  if (tl0.n == 0) return run_gemm<AL, BL, KS, TRI>(c, tl1, g1, ep1);
+  if (tl1.n == 0) return run_gemm<AL, BL, KS, TRI>(c, tl0, g0, ep0);
+  constexpr int WV = WavesFor<AL, BL, KS>::value;
+  g0.tiles = tl0.d; g0.per = tl0.per; g1.tiles = tl1.d; g1.per = tl1.per;
+  constexpr size_t shm = sizeof(double) * NST * STAGE_DOUBLES;
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<AL, BL, NST, KS, TRI, WV, EP>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_set = true;
+  }
+  const int n0 = tl0.n / tl0.per, n1 = tl1.n / tl1.per;
+  hipLaunchKernelGGL((gemm_f64_kernel<AL, BL, NST, KS, TRI, WV, EP>), dim3((unsigned)(round_up(n0, 8) + n1)), dim3(64 * WV), shm, c->stream,
+                     g0, ep0, g1, ep1, n0);
   ZIGP_HIP(c, hipGetLastError());
   return 0;
 }
