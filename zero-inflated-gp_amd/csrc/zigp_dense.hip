@@ -148,21 +148,18 @@ int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, i
 }
 
 // Forward panels of both latents for one chunk: A1, A2 (+ J' when a gradient is wanted), column partials.
-// Where the triangular products run the paired order (equal-length units filling whole waves of the 512 resident workgroups: cfg3), each
-// product class is ONE launch for both latents (run_gemm2: latent g's workgroups fill the tail of latent f's; cfg3 -0.8 % same-box,
-// profiles/r05l_ab_merge_fg.log).  Not in the LPT regime (cfg2: +1.2 % merged -- there a product reads the panel the previous launch of
-// the SAME latent has just written, part of it still in the 256 MB Infinity Cache, and the merged order A1f A1g A2f A2g puts a whole
-// panel of the other latent in between), and not for the rank-N update (its 512-workgroup split-K plan fills the chip exactly: +0.2 %).
+// Where the triangular products run the paired order (trmm_paired_pays: cfg3, cfg2), each product class is ONE launch for both latents
+// (run_gemm2: latent g's workgroups fill the tail of latent f's, three launch boundaries fewer per chunk; cfg3 -0.8 % same-box,
+// profiles/r05l_ab_merge_fg.log).  In the LPT regime the products stay per latent, in the order A1 A2 J' (f), A1 A2 J' (g) (merged there:
+// cfg2 +1.2 %), and so does the rank-N update everywhere (its 512-workgroup split-K plan fills the chip exactly; merged +0.2 %).
 int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad) {
   const int nbn = (int)(Nc / BN);
   struct Set { TileList tl, tu, tf; double fl; GemmArgs a1, a2, j; EpiStoreColsum e1, e2; } q[2];
-  bool merge = true;
+  const bool paired = trmm_paired_pays(nbn * ((c->lat[0].Mp / BM + 1) / 2 + (c->lat[1].Mp / BM + 1) / 2)), merge = paired;
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
     const int Mp = lt.Mp, nbm = Mp / BM;
     const int np = Mp / 32;   // allocated partial rows per fused column sum (a kernel writes one per wave tile: 64 or 32 rows)
-    const bool paired = trmm_paired_pays(nbm, nbn);
-    merge = merge && paired;
     ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, q[h].tl, paired));
     ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, q[h].tu, paired));
     if (need_grad) ZIGP_TRY(tiles_full_xcd(c, nbm, nbn, nbm * (BM / BK), q[h].tf));

@@ -143,13 +143,14 @@ static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, bool paired, Ti
         for (int e = 0; e < 2; ++e) v.push_back(e0 + e < q[x].size() ? q[x][e0 + e] : mk_tile(0, 0, 0, 0));
   }, tl, 2);
 }
-// The paired order has nbn * ceil(nbm / 2) units of EQUAL length: it only pays where they fill whole waves of the 512 resident
-// workgroups (cfg3: 256 panels x 4 units = 2 waves exactly; cfg2: 392 x 2 = 784 units would leave the second wave 47 % empty, and so
-// would the short last chunk of cfg3) -- otherwise LPT, whose tiles of mixed length pack the tail.
-static inline bool trmm_paired_pays(int nbm, int nbn) {
-  const int units = nbn * ((nbm + 1) / 2), slots = 512;
-  const int waves = (units + slots - 1) / slots;
-  return units >= slots && (double)units / ((double)waves * slots) >= 0.95;
+// The paired order has nbn * ceil(nbm / 2) units of EQUAL length per latent: it pays (2.2x fewer bytes, +6 % on the triangular
+// products) where the units of BOTH latents, launched together (run_gemm2), fill whole waves of the 512 resident workgroups --
+// cfg3: 2 x 256 panels x 4 units = 4 waves exactly; cfg2: 2 x 784 x 2 = 3136 units = 6.1 waves, 0.875 full, still -1.3 % against LPT
+// (profiles/r05l_ab_merge_fg.log); launched per latent the same units are 3.06 waves and lose (+1.6 %).  Otherwise LPT, one launch
+// per latent, whose tiles of mixed length pack the tail.
+static inline bool trmm_paired_pays(int units_both_latents) {
+  const int slots = 512, waves = (units_both_latents + slots - 1) / slots;
+  return units_both_latents >= slots && (double)units_both_latents / ((double)waves * slots) >= 0.85;
 }
 static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired) { return tiles_trmm(c, true, nbm, nbn, paired, tl); }
 static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired) { return tiles_trmm(c, false, nbm, nbn, paired, tl); }
