@@ -49,6 +49,10 @@ int zigp_test_gemm(zigp_ctx* ctx, int32_t transA, int32_t transB, int64_t m, int
  * an ordered reduction, as in the M x M forward of zigp_elbo (0: one workgroup per tile, as in the Kronecker panel path). */
 int zigp_test_potrf_trtri(zigp_ctx* ctx, int64_t n, const double* A, double* L, double* W, int32_t split_k);
 
+/* The chunk loop's cross-covariance kernel on its own: K (M,N) row-major = var * exp(-0.5 |(z_m - x_n) / ell|^2) as k_kuf_build writes a
+ * Kuf panel (kern.K(X, Xnew), onofftf/main.py:266; its exponential is hand-written, see csrc/zigp_kernels.h).  X (N,D), Z (M,D), ell (D). */
+int zigp_test_kuf(zigp_ctx* ctx, int64_t N, int32_t M, int32_t D, const double* X, const double* Z, const double* ell, double var, double* K);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,35 @@ def test_rbf_K_matches_oracle(engine, D, ard):
     assert relerr(Ks, o.rbf_K(X1, None, ell, var)) < 1e-12
 
 
+def test_kuf_panel_kernel_golden_kernse_np_and_ulp(engine):
+    """The chunk loop's Kuf kernel (k_kuf_build: exponential written out by hand -- 32-entry table, degree-6 polynomial, ldexp) against
+    the reference's own kernse_np outputs (G1), and against an 80-bit evaluation over 800 units of -log K: within a few ulp plus the
+    conditioning of exp (the argument itself carries a few roundings: relative error ~ eps * y), gradual underflow, exact zero beyond."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g1_kernse_np.npz'))
+    for tag in ('d1', 'd3s', 'd3ard'):
+        Z, X, ell, var = g[tag + '_Z'], g[tag + '_X'], g[tag + '_ell'], float(g[tag + '_var'])
+        assert relerr(engine.test_kuf(X, Z, ell, var), g[tag + '_Kzx']) < 1e-12
+    rng = np.random.RandomState(11)
+    eps = np.finfo(np.float64).eps
+    for D in (1, 2, 3, 5, 8):
+        N, M = 3000 + 37 * D, 70 + D
+        X = rng.randn(N, D) * rng.choice([0.3, 3.0, 30.0], size=(N, 1))
+        Z = rng.randn(M, D)
+        ell = 0.5 + rng.rand(D)
+        var = 1.7
+        K = engine.test_kuf(X, Z, ell, var)
+        L = np.longdouble
+        d = (Z.astype(L)[:, None, :] - X.astype(L)[None, :, :]) / ell.astype(L)
+        y = L(0.5) * (d * d).sum(-1)
+        ref = L(var) * np.exp(-y)
+        tol = (4.0 + 8.0 * y) * eps * ref + L(5e-324)
+        bad = np.abs(K.astype(L) - ref) > tol
+        assert not bad.any(), (D, int(bad.sum()), float(np.max(np.abs(K.astype(L) - ref) / (ref + L(1e-300)))))
+        assert (K[np.asarray(y > 760)] == 0.0).all() and (K >= 0).all() and np.isfinite(K).all()
+        assert float(y.max()) > 800 or D < 3        # the sweep reaches past the underflow threshold
+
+
 def test_rbf_K_golden_kernse_np(engine):
     """Golden vectors produced by the reference's own kernse_np (onofftf/utils.py:26-58)."""
     import os

@@ -43,6 +43,7 @@ struct TileList {
 struct Latent {
   int M = 0, Mp = 0;
   DevBuf Z, ell, u, s, s2;              // Z (Mp,D) zero padded; u,s,s2 (Mp) zero padded
+  DevBuf Zs;                            // Z scaled by KUF_C / ell_d (k_kuf_build's units), same padding
   double var = 1.0;
   DevBuf Kuu, L, W;                      // (Mp,Mp)
   DevBuf K, A1, A2, Jp;                  // chunk panels [Mp][Nc]: Kuf, A1 = W K, A2 = W^T A1, J' = Q A2 (= W^T W diag(s^2) A2 - A2)

@@ -29,11 +29,11 @@ struct HostLatent {
   int M; const double *Z, *u, *s, *ell; double var;
 };
 
-// Parameters of both latents to the device (zero-padded to Mp): ONE staged image [Z | ell | u | s] x 2 and one copy -- the eight
+// Parameters of both latents to the device (zero-padded to Mp): ONE staged image [Z | ell | u | s | Zs] x 2 and one copy -- the eight
 // separate copies of the first version were eight launches (~7 us apart) in front of a launch-bound M x M stage.  lt.Z / ell / u / s
 // are views into the context's parameter arena.
 int latents_upload(zigp_ctx* c, const HostLatent (&hl)[2], int D) {
-  size_t off[2][5], total = 0;
+  size_t off[2][6], total = 0;
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
     lt.M = hl[h].M;
@@ -44,7 +44,8 @@ int latents_upload(zigp_ctx* c, const HostLatent (&hl)[2], int D) {
     off[h][1] = total; total += MAXD;        // ell
     off[h][2] = total; total += Mp;          // u
     off[h][3] = total; total += Mp;          // s
-    off[h][4] = total;
+    off[h][4] = total; total += Mp * D;      // Zs = Z scaled to k_kuf_build's units (the same doubles the kernel multiplies into x)
+    off[h][5] = total;
   }
   ZIGP_ENSURE(c, c->parm, total);
   ZIGP_PINNED(c, img, total);
@@ -55,13 +56,16 @@ int latents_upload(zigp_ctx* c, const HostLatent (&hl)[2], int D) {
     memcpy(img + off[h][1], q.ell, sizeof(double) * D);
     memcpy(img + off[h][2], q.u, sizeof(double) * q.M);
     memcpy(img + off[h][3], q.s, sizeof(double) * q.M);
+    const KufHyp kh = make_kuf_hyp(q.ell, q.var, D);
+    for (int m = 0; m < q.M; ++m)
+      for (int d = 0; d < D; ++d) img[off[h][4] + (size_t)m * D + d] = q.Z[(size_t)m * D + d] * kh.scale[d];
   }
   ZIGP_HIP(c, hipMemcpyAsync(c->parm.p, img, sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
     const size_t Mp = lt.Mp;
     lt.Z.alias(c->parm.p + off[h][0], Mp * D); lt.ell.alias(c->parm.p + off[h][1], MAXD);
-    lt.u.alias(c->parm.p + off[h][2], Mp); lt.s.alias(c->parm.p + off[h][3], Mp);
+    lt.u.alias(c->parm.p + off[h][2], Mp); lt.s.alias(c->parm.p + off[h][3], Mp); lt.Zs.alias(c->parm.p + off[h][4], Mp * D);
     ZIGP_ENSURE(c, lt.s2, Mp);
     ZIGP_ENSURE(c, lt.Kuu, Mp * Mp);
     ZIGP_ENSURE(c, lt.L, Mp * Mp);
@@ -139,10 +143,16 @@ int latents_forward(zigp_ctx* c, const HostLatent (&hl)[2], int D, double jitter
 // Kuf panel of one latent for the chunk starting at row n0 (HBM-write bound; runs on the side stream under the previous chunk's SYRKs)
 int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D, const double* ell_host) {
   const int Mp = lt.Mp;
-  KernHyp hyp = make_hyp(ell_host, lt.var, D);
+  const KufHyp kh = make_kuf_hyp(ell_host, lt.var, D);
   ProfScope ps(c, PC_KUF);
-  hipLaunchKernelGGL(k_kuf_build, dim3((unsigned)(Nc / 512), Mp / 16), dim3(256), 0, c->stream, dX, Nrows, n0, lt.Z.p, lt.M, hyp,
-                     lt.K.p, Nc);
+  const dim3 grid((unsigned)(Nc / 512), Mp / 16), block(256);
+#define ZIGP_KUF(DD) \
+  case DD: hipLaunchKernelGGL(k_kuf_build<DD>, grid, block, 0, c->stream, dX, Nrows, n0, lt.Zs.p, lt.M, kh, lt.K.p, Nc); break;
+  switch (D) {
+    ZIGP_KUF(1) ZIGP_KUF(2) ZIGP_KUF(3) ZIGP_KUF(4) ZIGP_KUF(5) ZIGP_KUF(6) ZIGP_KUF(7) ZIGP_KUF(8)
+    default: return fail_arg(c, "D out of range");
+  }
+#undef ZIGP_KUF
   ZIGP_HIP(c, hipGetLastError());
   return 0;
 }
@@ -908,6 +918,38 @@ int zigp_clock_stamp(zigp_ctx* c, int64_t* out) {
 }
 
 // ---- diagnostics -------------------------------------------------------------------------------
+int zigp_test_kuf(zigp_ctx* c, int64_t N, int32_t M, int32_t D, const double* X, const double* Z, const double* ell, double var, double* K) {
+  if (!c) return ZIGP_EARG;
+  if (N <= 0 || M <= 0 || D < 1 || D > MAXD || !X || !Z || !ell || !K) return fail_arg(c, "zigp_test_kuf: bad arguments");
+  ZIGP_HIP(c, hipSetDevice(c->device));
+  const int64_t Nc = round_up(N, 1024);
+  const int Mp = (int)round_up(M, 16);
+  const KufHyp kh = make_kuf_hyp(ell, var, D);
+  std::vector<double> zs((size_t)Mp * D, 0.0), hk((size_t)Mp * Nc);
+  for (int m = 0; m < M; ++m)
+    for (int d = 0; d < D; ++d) zs[(size_t)m * D + d] = Z[(size_t)m * D + d] * kh.scale[d];
+  DevBuf dx, dz, dk;
+  auto body = [&]() -> int {
+    ZIGP_ENSURE(c, dx, (size_t)N * D); ZIGP_ENSURE(c, dz, zs.size()); ZIGP_ENSURE(c, dk, hk.size());
+    ZIGP_HIP(c, hipMemcpyAsync(dx.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice, c->stream));
+    ZIGP_HIP(c, hipMemcpyAsync(dz.p, zs.data(), sizeof(double) * zs.size(), hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((unsigned)(Nc / 512), Mp / 16), block(256);
+#define ZIGP_KUF(DD) \
+  case DD: hipLaunchKernelGGL(k_kuf_build<DD>, grid, block, 0, c->stream, dx.p, N, (int64_t)0, dz.p, M, kh, dk.p, Nc); break;
+    switch (D) { ZIGP_KUF(1) ZIGP_KUF(2) ZIGP_KUF(3) ZIGP_KUF(4) ZIGP_KUF(5) ZIGP_KUF(6) ZIGP_KUF(7) ZIGP_KUF(8) }
+#undef ZIGP_KUF
+    ZIGP_HIP(c, hipGetLastError());
+    ZIGP_HIP(c, hipMemcpyAsync(hk.data(), dk.p, sizeof(double) * hk.size(), hipMemcpyDeviceToHost, c->stream));
+    ZIGP_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+  };
+  const int rc = body();
+  dx.release(); dz.release(); dk.release();
+  if (rc) return rc;
+  for (int m = 0; m < M; ++m) memcpy(K + (size_t)m * N, &hk[(size_t)m * Nc], sizeof(double) * N);
+  return ZIGP_OK;
+}
+
 int zigp_test_gemm(zigp_ctx* c, int32_t transA, int32_t transB, int64_t m, int64_t n, int64_t k, const double* A, const double* B, double* C) {
   if (!c) return ZIGP_EARG;
   if (m <= 0 || n <= 0 || k <= 0 || !A || !B || !C) return fail_arg(c, "zigp_test_gemm: bad arguments");

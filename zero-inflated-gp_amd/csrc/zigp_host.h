@@ -488,6 +488,13 @@ static inline KernHyp make_hyp(const double* ell, double var, int D) {
   return h;
 }
 
+static inline KufHyp make_kuf_hyp(const double* ell, double var, int D) {
+  KufHyp h;
+  for (int d = 0; d < MAXD; ++d) h.scale[d] = (d < D) ? KUF_C * (1.0 / ell[d]) : 0.0;
+  h.var = var;
+  return h;
+}
+
 // ---- small transfers through the pinned arena (zigp_ctx.h) ----
 // Start of an API call that stages transfers: make sure nothing of an earlier call (one that returned an error before its
 // final synchronisation, say) is still reading or writing the arena, then rewind it.

@@ -95,35 +95,68 @@ __global__ void k_kuu_setup(const double* __restrict__ Z, int64_t M, KernHyp h, 
 // ---------------------------------------------------------------------------------------------
 // Kuf panel for one chunk: K[m][n] = var*exp(-0.5*|(z_m - x_n)/ell|^2), m < M ; 0 for padded rows.
 // (kern.K(X, Xnew), onofftf/main.py:266.)  grid (Nc/512, Mp/16); thread = two adjacent columns, 16 rows.
+// This kernel runs beside the MFMA-bound products and every fp64 VALU instruction of it is paid in MFMA time (the matrix pipe and the
+// vector ALU share issue slots: a knock-out with a 2-instruction stand-in for exp() takes 1.35 ms off the cfg3 step,
+// profiles/r05o_kuf_exp.log) -- so the exponential is written out with as few instructions as full precision allows instead of calling
+// the library's exp() (~25 instructions with its special cases):
+//   inputs pre-scaled by c / ell_d, c = sqrt(16 / ln 2) (Zs on the host, x here), so that  w = -sum_d (zs_d - xs_d)^2 = -y 32 / ln 2,
+//   y = 0.5 r^2;  exp(-y) = 2^(w / 32) = 2^E * T[j] * 2^(g / 32)  with  n = rint(w) = 32 E + j (j = n & 31, E = n >> 5: floor semantics,
+//   w <= 0), g = w - n in [-1/2, 1/2] (exact), T[j] = var 2^(j / 32) from a 32-entry LDS table (a wave's reads hit at most two entries per
+//   bank), 2^(g / 32) = exp(g ln2 / 32) by its degree-6 Taylor polynomial (next term < 3.5e-18), v_ldexp_f64 for 2^E (gradual underflow,
+//   0 below 2^-1075; a saturated conversion of a huge |w| gives E = -2^26: 0 as well).  16 + 2 D fp64 / integer VALU instructions per
+//   element (22 at D = 3, was 35); the result is within 2 ulp of the correctly rounded value of exp at the computed argument (table
+//   entry, product, final fma): tests/test_gpu_blocks.py::test_kuf_panel_kernel_golden_kernse_np_and_ulp.
 // ---------------------------------------------------------------------------------------------
+constexpr double KUF_C = 0x1.337cc2183b050p+2;   // sqrt(16 / ln 2)
+struct KufHyp { double scale[MAXD]; double var; };   // scale[d] = KUF_C * (1 / ell_d): the same doubles the host multiplied into Zs
+__device__ const double KUF_T[32] = {
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0, 0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0,
+    0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0, 0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0, 0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0,
+    0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0, 0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0, 0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0,
+    0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0};
+__device__ __forceinline__ double kuf_exp2_32(double w, const double* T) {   // T[j] * 2^(w / 32), w <= 0
+  const double kn = __builtin_rint(w);
+  const double g = w - kn;
+  double p = fma(g, 0x1.430912f86c787p-43, 0x1.5d87fe78a6731p-35);
+  p = fma(g, p, 0x1.3b2ab6fba4e77p-27);
+  p = fma(g, p, 0x1.c6b08d704a0c0p-20);
+  p = fma(g, p, 0x1.ebfbdff82c58fp-13);
+  p = fma(g, p, 0x1.62e42fefa39efp-6);
+  p = fma(g, p, 1.0);
+  const int n = (int)kn;
+  return __builtin_amdgcn_ldexp(T[n & 31] * p, n >> 5);
+}
+template <int D>
 __global__ void __launch_bounds__(256)
-k_kuf_build(const double* __restrict__ X, int64_t N, int64_t n0, const double* __restrict__ Z, int M, KernHyp h,
+k_kuf_build(const double* __restrict__ X, int64_t N, int64_t n0, const double* __restrict__ Zs, int M, KufHyp h,
             double* __restrict__ K, int64_t Nc) {
+  __shared__ double T[32];
+  if (threadIdx.x < 32) T[threadIdx.x] = h.var * KUF_T[threadIdx.x];
   const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;   // two adjacent columns: 16-byte stores
   const int m0 = blockIdx.y * 16;
-  double xs[2][MAXD];
+  double xs[2][D];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const bool valid = (n0 + n + e) < N;
 #pragma unroll
-    for (int d = 0; d < MAXD; ++d) xs[e][d] = (d < h.D && valid) ? X[(n0 + n + e) * h.D + d] * h.inv_ell[d] : 0.0;
+    for (int d = 0; d < D; ++d) xs[e][d] = valid ? X[(n0 + n + e) * D + d] * h.scale[d] : 0.0;
   }
+  __syncthreads();
 #pragma unroll 4
   for (int mm = 0; mm < 16; ++mm) {
     const int m = m0 + mm;
-    double2 v = make_double2(0.0, 0.0);
-    if (m < M) {
-      double r0 = 0.0, r1 = 0.0;
+    double2* out = reinterpret_cast<double2*>(K + (int64_t)m * Nc + n);
+    if (m >= M) { *out = make_double2(0.0, 0.0); continue; }     // uniform over the block
+    double w0, w1;
 #pragma unroll
-      for (int d = 0; d < MAXD; ++d)
-        if (d < h.D) {
-          const double zs = Z[m * h.D + d] * h.inv_ell[d];
-          const double t0 = zs - xs[0][d], t1 = zs - xs[1][d];
-          r0 = fma(t0, t0, r0); r1 = fma(t1, t1, r1);
-        }
-      v.x = h.var * exp(-0.5 * r0); v.y = h.var * exp(-0.5 * r1);
+    for (int d = 0; d < D; ++d) {
+      const double zs = Zs[m * D + d];      // uniform: a scalar load
+      const double t0 = zs - xs[0][d], t1 = zs - xs[1][d];
+      w0 = d == 0 ? -t0 * t0 : fma(-t0, t0, w0); w1 = d == 0 ? -t1 * t1 : fma(-t1, t1, w1);
     }
-    *reinterpret_cast<double2*>(K + (int64_t)m * Nc + n) = v;
+    *out = make_double2(kuf_exp2_32(w0, T), kuf_exp2_32(w1, T));
   }
 }
 

@@ -114,6 +114,7 @@ SIGNATURES = {
     'zigp_profile_sampling': (C.c_int, [C.c_void_p, C.c_int32]),
     'zigp_clock_stamp': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'zigp_test_gemm': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, dp, dp, dp]),
+    'zigp_test_kuf': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, dp, dp, dp, C.c_double, dp]),
     'zigp_test_potrf_trtri': (C.c_int, [C.c_void_p, C.c_int64, dp, dp, dp, C.c_int32]),
 }
 

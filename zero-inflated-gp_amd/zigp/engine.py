@@ -615,6 +615,18 @@ class DenseEngine:
         _check(self.lib, self.ctx, self.lib.zigp_test_gemm(self.ctx, int(transA), int(transB), m, n, k, ptr(A), ptr(B), ptr(out)))
         return out
 
+    def test_kuf(self, X, Z, ell, var):
+        """K (M,N) = kern.K(Z, X) as the chunk loop's k_kuf_build writes a Kuf panel (hand-written exponential)."""
+        X, Z = as_f64(X), as_f64(Z)
+        if X.ndim == 1: X = X[:, None]
+        if Z.ndim == 1: Z = Z[:, None]
+        N, D = X.shape
+        M = Z.shape[0]
+        ell = as_f64(np.broadcast_to(np.asarray(ell, dtype=np.float64), (D,)))
+        out = np.zeros((M, N))
+        _check(self.lib, self.ctx, self.lib.zigp_test_kuf(self.ctx, N, M, D, ptr(X), ptr(Z), ptr(ell), float(var), ptr(out)))
+        return out
+
     def test_potrf_trtri(self, A, split_k=False):
         A = as_f64(A)
         n = A.shape[0]
