@@ -106,6 +106,31 @@ def test_elbo_and_gradient_match_oracle(engine, N, M, Mg, D, ell, chunk, us):
         assert e < max(1e-6, 1e-13 * c), (k, e)
 
 
+def test_inputs_far_from_the_origin_translation_invariance(engine):
+    """The RBF kernel only sees differences (KernSE.K, onofftf/main.py:41-57): moving X and Z by the same vector must not change the step
+    beyond the rounding of the scaled coordinates (x / ell is formed before the difference, as the reference does: (shift / ell) eps ~ 4e-12
+    per difference here, ~1e-8 after the conditioning of the step -- the same for every gradient block).  Code that works with absolute
+    coordinates would lose (shift / ell)^2 eps ~ 3e-8 per term instead: k_kgrad's moment sums are taken about the mean inducing input and
+    moved to z_m afterwards, and the Z / lengthscale gradients must come out no worse than the blocks that never see a coordinate."""
+    X, Y, p = make_problem(3000, 200, 3, seed=21, Mg=136, ell=0.25)
+    q = lambda a: np.round(a * 2.0 ** 20) / 2.0 ** 20
+    X = q(X); p['Zf'] = q(p['Zf']); p['Zg'] = q(p['Zg'])
+    engine.set_chunk(1024)
+    engine.set_data(X, Y)
+    ed0, kl0, g0 = engine.elbo(p, jitter=1e-6)
+    shift = np.array([4096.0, -4096.0, 1024.0])
+    p2 = dict(p, Zf=p['Zf'] + shift, Zg=p['Zg'] + shift)
+    assert np.array_equal((p2['Zf'] - shift), p['Zf'])          # exactly representable
+    engine.set_data(X + shift, Y)
+    ed1, kl1, g1 = engine.elbo(p2, jitter=1e-6)
+    print('  elbo_data relerr %.2e, kl relerr %.2e' % (abs(ed1 - ed0) / abs(ed0), abs(kl1 - kl0) / abs(kl0)))
+    assert abs(ed1 - ed0) < 1e-7 * abs(ed0) and abs(kl1 - kl0) < 1e-7 * abs(kl0)
+    for k in g0:
+        e = relerr(g1[k], g0[k])
+        print('  grad %-10s relerr %.2e' % (k, e))
+        assert e < 1e-6, (k, e)
+
+
 def test_value_only_and_no_kl(engine):
     import zigp_oracle as o
     X, Y, p = make_problem(1000, 64, 3, seed=5)

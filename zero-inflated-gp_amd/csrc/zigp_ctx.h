@@ -43,6 +43,7 @@ struct TileList {
 struct Latent {
   int M = 0, Mp = 0;
   DevBuf Z, ell, u, s, s2;              // Z (Mp,D) zero padded; u,s,s2 (Mp) zero padded
+  double zc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // mean inducing input (host copy): centre of k_kgrad's moment sums
   DevBuf Zs;                            // Z scaled by KUF_C / ell_d (k_kuf_build's units), same padding
   double var = 1.0;
   DevBuf Kuu, L, W;                      // (Mp,Mp)

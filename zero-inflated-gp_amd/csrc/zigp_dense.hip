@@ -57,6 +57,11 @@ int latents_upload(zigp_ctx* c, const HostLatent (&hl)[2], int D) {
     memcpy(img + off[h][2], q.u, sizeof(double) * q.M);
     memcpy(img + off[h][3], q.s, sizeof(double) * q.M);
     const KufHyp kh = make_kuf_hyp(q.ell, q.var, D);
+    for (int d = 0; d < MAXD; ++d) {      // centre of k_kgrad's moment sums: the mean inducing input
+      double sum = 0.0;
+      if (d < D) for (int m = 0; m < q.M; ++m) sum += q.Z[(size_t)m * D + d];
+      c->lat[h].zc[d] = q.M > 0 ? sum / q.M : 0.0;
+    }
     for (int m = 0; m < q.M; ++m)
       for (int d = 0; d < D; ++d) img[off[h][4] + (size_t)m * D + d] = q.Z[(size_t)m * D + d] * kh.scale[d];
   }
@@ -221,7 +226,8 @@ int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad) {
 // Kuf-cotangent reductions of one latent and chunk (HBM-read bound; runs on the side stream under the chunk's SYRKs)
 int latent_chunk_kgrad(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, int64_t n0, int64_t Nc, int D, const double* ell_host) {
   const int Mp = lt.Mp;
-  const KernHyp hyp = make_hyp(ell_host, lt.var, D);
+  KgCentre hyp;
+  for (int d = 0; d < MAXD; ++d) hyp.c[d] = lt.zc[d];
   double* alpha = lt.vec.p + Mp;
   {
     ProfScope ps(c, PC_RED);

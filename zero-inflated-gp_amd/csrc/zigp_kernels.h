@@ -321,23 +321,28 @@ constexpr int KG_SPLIT = 4;   // column splits (blockIdx.y); each split accumula
 // more than bytes.  K stays valid until this kernel is done: the next chunk's panels are built behind it on the same stream
 // (dense_chunk_loop).  (The recomputing form, the eight-way column split and a slim 1-row x 2-column version are in
 // tools/r4_experiment_arms.patch and HISTORY.md section 5.)
+// The moment sums are taken about ONE centre c (the mean of the latent's inducing inputs, from the host) and moved to z_m after the block
+// reduction:  sum F K (x - z) = S1 - dz S0,  sum F K (x - z)^2 = S2 - 2 dz S1 + dz^2 S0,  dz = z_m - c  -- two fused multiply-adds per
+// element and dimension instead of four (x - c and its square are formed once per column, for all KG_ROWS rows): 12.5 instead of 17 fp64
+// VALU instructions per element at D = 3, and this kernel runs beside the MFMA-bound rank-N updates, where every VALU instruction is
+// paid in matrix-pipe time (k_kuf_build above).  The shift costs (|dz| / ell)^2 ulp of cancellation -- the spread of the inducing
+// inputs in lengthscales, not of the data's offset from the origin.
+struct KgCentre { double c[MAXD]; };
 template <int D>
 __global__ void __launch_bounds__(256)
 k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const double* __restrict__ alpha,
         const double* __restrict__ gm, const double* __restrict__ gv, const double* __restrict__ X, int64_t N, int64_t n0,
-        const double* __restrict__ Z, int M, int64_t Nc, int64_t slab, KernHyp hyp, double* __restrict__ krow) {
+        const double* __restrict__ Z, int M, int64_t Nc, int64_t slab, KgCentre ctr, double* __restrict__ krow) {
   constexpr int W = 2 + 2 * D;
   __shared__ double sh[4][KG_ROWS * W];
+  __shared__ double tot[KG_ROWS * W];
   krow += (int64_t)blockIdx.y * slab;
   const int m0 = blockIdx.x * KG_ROWS;
   if (m0 >= M) return;
-  double zz[KG_ROWS][D], am[KG_ROWS], acc[KG_ROWS][W];
+  double am[KG_ROWS], acc[KG_ROWS][W];
 #pragma unroll
   for (int r = 0; r < KG_ROWS; ++r) {
-    const int m = min(m0 + r, M - 1);
-    am[r] = alpha[m];
-#pragma unroll
-    for (int d = 0; d < D; ++d) zz[r][d] = Z[m * D + d];
+    am[r] = alpha[min(m0 + r, M - 1)];
 #pragma unroll
     for (int q = 0; q < W; ++q) acc[r][q] = 0.0;
   }
@@ -345,9 +350,9 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
   const int64_t nmax = min(nbeg + nspan, N - n0);
   for (int64_t n = nbeg + threadIdx.x; n < nmax; n += 256) {
     const double gmn = gm[n], gv2 = 2.0 * gv[n];
-    double x[D];
+    double xc[D], xx[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = X[(n0 + n) * D + d];
+    for (int d = 0; d < D; ++d) { xc[d] = X[(n0 + n) * D + d] - ctr.c[d]; xx[d] = xc[d] * xc[d]; }
 #pragma unroll
     for (int r = 0; r < KG_ROWS; ++r) {
       const int64_t o = (int64_t)(m0 + r) * Nc + n;     // rows beyond M are zero-padded panels (inside the allocation)
@@ -357,10 +362,8 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
       acc[r][1 + 2 * D] = fma(kk, gmn, acc[r][1 + 2 * D]);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        const double df = x[d] - zz[r][d];
-        const double td = t * df;
-        acc[r][1 + d] += td;
-        acc[r][1 + D + d] = fma(td, df, acc[r][1 + D + d]);
+        acc[r][1 + d] = fma(t, xc[d], acc[r][1 + d]);
+        acc[r][1 + D + d] = fma(t, xx[d], acc[r][1 + D + d]);
       }
     }
   }
@@ -373,9 +376,20 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
       if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][r * W + q] = v;
     }
   __syncthreads();
+  if (threadIdx.x < KG_ROWS * W) tot[threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  __syncthreads();
   if (threadIdx.x < KG_ROWS * W) {
     const int r = threadIdx.x / W, q = threadIdx.x - r * W;
-    if (m0 + r < M) krow[(int64_t)(m0 + r) * W + q] += (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (m0 + r < M) {
+      const double* S = tot + r * W;
+      double v = S[q];
+      if (q >= 1 && q <= 2 * D) {      // moments about c -> about z_m
+        const int d = (q - 1) % D;
+        const double dz = Z[(m0 + r) * D + d] - ctr.c[d];
+        v = (q <= D) ? fma(-dz, S[0], S[1 + d]) : fma(dz, fma(dz, S[0], -2.0 * S[1 + d]), S[1 + D + d]);
+      }
+      krow[(int64_t)(m0 + r) * W + q] += v;
+    }
   }
 }
 
