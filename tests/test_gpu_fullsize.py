@@ -6,6 +6,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import make_problem, relerr
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -188,3 +190,31 @@ def test_cfg1_toydata_M50_matches_oracle(engine):
     for i in range(9):
         r = ref[i].reshape(-1)
         assert np.max(np.abs(out[i] - r)) <= 1e-6 * max(np.max(np.abs(r)), 1e-300), i
+
+
+def test_two_latents_in_one_launch_with_different_block_counts(engine):
+    """The merged launches of the chunk loop (run_gemm2: A1, A2, J' of latent f and latent g as ONE grid each, paired tile order) with
+    Mf = 300 (3 row blocks: a pair and a single middle tile per column panel) and Mg = 520 (5 row blocks): 304 column panels x (2 + 3)
+    units = 1520 workgroups = 0.99 of three waves -> trmm_paired_pays.  Against the same step in 38 passes of 1024 rows, which takes the
+    LPT order with one launch per latent (8 column panels x 5 units < 512), and against the oracle on a slice."""
+    import zigp_oracle_torch as ot
+    N = 38400
+    X, Y, p = make_problem(N, 300, 3, seed=31, Mg=520, ell=0.3)
+    engine.set_data(X, Y)
+    engine.set_chunk(65536)
+    assert engine.get_chunk_rows(520, N) == 38912               # one pass of 304 column panels: 1520 units
+    ed, kl, g = engine.elbo(p, jitter=1e-6)
+    engine.set_chunk(1024)
+    ed2, kl2, g2 = engine.elbo(p, jitter=1e-6)
+    print('  one pass vs 38: elbo_data %.2e' % (abs(ed - ed2) / abs(ed)), {k: '%.1e' % relerr(g[k], g2[k]) for k in g})
+    assert abs(ed - ed2) <= 1e-9 * abs(ed) and kl == kl2      # (summation order over the points differs; u_m at scale 0.5, jitter 1e-6)
+    for k in g:
+        assert relerr(g[k], g2[k]) <= 1e-7, k
+    engine.set_chunk(65536)
+    rows = (12800, 12800 + 25600)                 # 200 panels x 5 units = 1000 workgroups = 0.98 of two waves: merged as well
+    eds, _, gs = engine.elbo(p, jitter=1e-6, rows=rows, include_kl=False)
+    sl = slice(*rows)
+    e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X[sl], Y[sl], p, 1e-6, include_kl=False)
+    assert abs(eds - d_r) <= 1e-9 * abs(d_r)
+    for k in ot.PARAM_KEYS:
+        assert relerr(gs[k], np.asarray(g_r[k]).reshape(np.asarray(gs[k]).shape)) < 1e-6, k
