@@ -540,7 +540,7 @@ def main():
             hbm = {}
             # kgrad reads the J' and the K panel (16 Mp bytes per column): since late round 4 it reads K again instead of recomputing it from
             # x, z (ZIGP_KGRAD_RECOMPUTE = 0: beside the MFMA-bound products the saved fp64 VALU work is worth more than the bytes)
-            for k, bytes_per_col, bound in (('kgrad', 16.0 * Mp + 8.0 * (D + 2), 'HBM read (J\' and K panels; ~17 fp64 instructions per element)'),
+            for k, bytes_per_col, bound in (('kgrad', 16.0 * Mp + 8.0 * (D + 2), 'HBM read (J\' and K panels; 12.5 fp64 instructions per element)'),
                                             ('kuf_build', 8.0 * Mp + 8.0 * D, 'HBM write')):
                 if prof[k]['launches'] > 0 and prof[k]['ms'] > 0:
                     # bytes over ALL launches of the profiled pass: every column of the shard is swept once per latent and step

@@ -164,8 +164,8 @@ int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, i
 
 // Forward panels of both latents for one chunk: A1, A2 (+ J' when a gradient is wanted), column partials.
 // Where the triangular products run the paired order (trmm_paired_pays: cfg3, cfg2), each product class is ONE launch for both latents
-// (run_gemm2: latent g's workgroups fill the tail of latent f's, three launch boundaries fewer per chunk; cfg3 -0.8 % same-box,
-// profiles/r05l_ab_merge_fg.log).  In the LPT regime the products stay per latent, in the order A1 A2 J' (f), A1 A2 J' (g) (merged there:
+// (run_gemm2: latent g's workgroups fill the tail of latent f's, three launch boundaries fewer per chunk; cfg3 -0.4 ... -0.8 % same-box,
+// profiles/r05l_ab_merge_fg.log, r05s_ab_milestones.log).  In the LPT regime the products stay per latent, in the order A1 A2 J' (f), A1 A2 J' (g) (merged there:
 // cfg2 +1.2 %), and so does the rank-N update everywhere (its 512-workgroup split-K plan fills the chip exactly; merged +0.2 %).
 int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad) {
   const int nbn = (int)(Nc / BN);

@@ -98,7 +98,7 @@ __global__ void k_kuu_setup(const double* __restrict__ Z, int64_t M, KernHyp h, 
 // This kernel runs beside the MFMA-bound products and every fp64 VALU instruction of it is paid in MFMA time (the matrix pipe and the
 // vector ALU share issue slots: a knock-out with a 2-instruction stand-in for exp() takes 1.35 ms off the cfg3 step,
 // profiles/r05o_kuf_exp.log) -- so the exponential is written out with as few instructions as full precision allows instead of calling
-// the library's exp() (~25 instructions with its special cases):
+// the library's exp() (~25 instructions with its special cases; cfg3 -0.15 % same-box, r05s_ab_milestones.log):
 //   inputs pre-scaled by c / ell_d, c = sqrt(16 / ln 2) (Zs on the host, x here), so that  w = -sum_d (zs_d - xs_d)^2 = -y 32 / ln 2,
 //   y = 0.5 r^2;  exp(-y) = 2^(w / 32) = 2^E * T[j] * 2^(g / 32)  with  n = rint(w) = 32 E + j (j = n & 31, E = n >> 5: floor semantics,
 //   w <= 0), g = w - n in [-1/2, 1/2] (exact), T[j] = var 2^(j / 32) from a 32-entry LDS table (a wave's reads hit at most two entries per
@@ -325,7 +325,7 @@ constexpr int KG_SPLIT = 4;   // column splits (blockIdx.y); each split accumula
 // reduction:  sum F K (x - z) = S1 - dz S0,  sum F K (x - z)^2 = S2 - 2 dz S1 + dz^2 S0,  dz = z_m - c  -- two fused multiply-adds per
 // element and dimension instead of four (x - c and its square are formed once per column, for all KG_ROWS rows): 12.5 instead of 17 fp64
 // VALU instructions per element at D = 3, and this kernel runs beside the MFMA-bound rank-N updates, where every VALU instruction is
-// paid in matrix-pipe time (k_kuf_build above).  The shift costs (|dz| / ell)^2 ulp of cancellation -- the spread of the inducing
+// paid in matrix-pipe time (k_kuf_build above; cfg3 -0.3 % same-box, profiles/r05s_ab_milestones.log).  The shift costs (|dz| / ell)^2 ulp of cancellation -- the spread of the inducing
 // inputs in lengthscales, not of the data's offset from the origin.
 struct KgCentre { double c[MAXD]; };
 template <int D>
