@@ -252,9 +252,10 @@ int zigp_comm_info(zigp_ctx* ctx, int32_t* rank, int32_t* nranks, int64_t* allre
 
 /* Stream overlap inside zigp_elbo (default ON since round 3): the HBM-bound kernels of a row chunk (Kuf-cotangent reductions,
  * the next chunk's Kuf panels) run on a second HIP stream underneath the chunk's two MFMA-bound rank-N updates (-3 % per
- * cfg3 step).  Results are bit-identical either way.  Turn it off (0) to profile: every kernel then runs alone on one stream
- * and per-kernel durations from an external tracer (rocprofv3 --stats) mean what they say; the library's own event timing
- * (zigp_profile_*, include/zigp_diag.h) already keeps the chunks it times on one stream. */
+ * cfg3 step), and (round 5) the point-wise stage of a gradient step rides as the leading workgroups of the launch of the J' product,
+ * which does not depend on it (one launch boundary less per chunk).  Results are bit-identical either way.  Turn it off (0) to profile:
+ * every kernel then runs alone, under its own name, on one stream and per-kernel durations from an external tracer (rocprofv3 --stats) mean
+ * what they say; the library's own event timing (zigp_profile_*, include/zigp_diag.h) already keeps the chunks it times that way. */
 int zigp_set_overlap(zigp_ctx* ctx, int32_t on);
 
 #ifdef __cplusplus

@@ -167,7 +167,7 @@ int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, i
 // (run_gemm2: latent g's workgroups fill the tail of latent f's, three launch boundaries fewer per chunk; cfg3 -0.4 ... -0.8 % same-box,
 // profiles/r05l_ab_merge_fg.log, r05s_ab_milestones.log).  In the LPT regime the products stay per latent, in the order A1 A2 J' (f), A1 A2 J' (g) (merged there:
 // cfg2 +1.2 %), and so does the rank-N update everywhere (its 512-workgroup split-K plan fills the chip exactly; merged +0.2 %).
-int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad) {
+int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad, const PwArgs* fuse_pw = nullptr, bool* fused = nullptr) {
   const int nbn = (int)(Nc / BN);
   struct Set { TileList tl, tu, tf; double fl; GemmArgs a1, a2, j; EpiStoreColsum e1, e2; } q[2];
   const bool paired = trmm_paired_pays(nbn * ((c->lat[0].Mp / BM + 1) / 2 + (c->lat[1].Mp / BM + 1) / 2)), merge = paired;
@@ -202,7 +202,11 @@ int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad) {
     }
     if (need_grad) {
       ProfScope ps(c, PC_GEMM_J, 2.0 * (q[0].fl + q[1].fl));
-      ZIGP_TRY((run_gemm2<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, q[0].tf, q[0].j, EpiStorePanel(), q[1].tf, q[1].j, EpiStorePanel())));
+      if (fuse_pw && (Nc / PW_PTS) % 16 == 0) {
+        ZIGP_TRY(run_gemm_j_pw(c, q[0].tf, q[0].j, q[1].tf, q[1].j, *fuse_pw, (int)(Nc / PW_PTS)));
+        if (fused) *fused = true;
+      } else
+        ZIGP_TRY((run_gemm2<LAY_MNCONTIG, LAY_MNCONTIG, false>(c, q[0].tf, q[0].j, EpiStorePanel(), q[1].tf, q[1].j, EpiStorePanel())));
     }
     return 0;
   }
@@ -446,8 +450,7 @@ int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
 }
 
 // point-wise stage of the chunk starting at row n0 (probit moments, expected log-likelihood, reverse pass to gm / gv)
-int dense_pointwise(zigp_ctx* c, const DenseCall& k, int64_t n0, int64_t Nc) {
-  ProfScope ps(c, PC_POINT);
+PwArgs dense_pointwise_args(zigp_ctx* c, const DenseCall& k, int64_t n0, int64_t Nc) {
   PwArgs a;
   a.part_f = c->lat[0].part.p; a.part_g = c->lat[1].part.p; a.np_f = c->lat[0].Mp / 32; a.np_g = c->lat[1].Mp / 32;
   {
@@ -461,6 +464,11 @@ int dense_pointwise(zigp_ctx* c, const DenseCall& k, int64_t n0, int64_t Nc) {
   a.X = k.dX; a.D = k.D; a.mean_on = c->mean_on ? 1 : 0; a.mean_b = c->mean_b;
   for (int d = 0; d < MAXD; ++d) a.mean_a[d] = (d < k.D) ? c->mean_a[d] : 0.0;
   a.acc = c->pw_part.p; a.out9 = k.d_out9 ? k.d_out9 - k.row_begin : nullptr; a.ld9 = k.row_end - k.row_begin;
+  return a;
+}
+int dense_pointwise(zigp_ctx* c, const DenseCall& k, int64_t n0, int64_t Nc) {
+  ProfScope ps(c, PC_POINT);
+  const PwArgs a = dense_pointwise_args(c, k, n0, Nc);
   const int nblk = (int)(Nc / PW_PTS);
   if (k.predict) hipLaunchKernelGGL(k_pointwise<true>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
   else hipLaunchKernelGGL(k_pointwise<false>, dim3(nblk), dim3(PW_THREADS), 0, c->stream, a);
@@ -470,7 +478,7 @@ int dense_pointwise(zigp_ctx* c, const DenseCall& k, int64_t n0, int64_t Nc) {
 
 // ---- chunk loop.  The MFMA-bound GEMMs stay on the main stream; with zigp_set_overlap(1) the HBM-bound kernels of a chunk -- the two
 // Kuf-cotangent reductions and the two Kuf panels of the NEXT chunk -- run on the side stream underneath the chunk's two SYRKs:
-//   main:  [wait side]  A1 A2 H J' (f, g)  point-wise  (record)  SYRK f  SYRK g
+//   main:  [wait side]  A1 (f|g)  A2 (f|g)  [point-wise +] J' (f|g)  (record)  SYRK f  SYRK g
 //   side:                                              (wait)    kgrad f  kgrad g  Kuf f'  Kuf g'  (record)
 // K is only read by A1 (and its rows' x, z by kgrad), J' / gm only by kgrad: the next chunk's GEMMs wait for the side stream, nothing
 // else is shared.  A chunk whose kernels are being timed (profiling samples every prof_every-th chunk) runs everything on the main
@@ -501,8 +509,12 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
       ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0));
       side_busy = false;
     }
-    ZIGP_TRY(chunk_forward(c, Nc, k.need_grad));
-    ZIGP_TRY(dense_pointwise(c, k, n0, Nc));
+    // gradient steps with zigp_set_overlap(1): the point-wise stage rides in the J' launch (run_gemm_j_pw: cfg3 -0.4 % same-box,
+    // profiles/r05t_ab_fuse_pointwise.log); timed chunks and overlap 0 keep every kernel on its own, as for the side stream
+    bool pw_fused = false;
+    const PwArgs pwa = dense_pointwise_args(c, k, n0, Nc);
+    ZIGP_TRY(chunk_forward(c, Nc, k.need_grad, (c->overlap == 1 && k.need_grad && !k.predict && !timed) ? &pwa : nullptr, &pw_fused));
+    if (!pw_fused) ZIGP_TRY(dense_pointwise(c, k, n0, Nc));
     // side work of this chunk: its kgrads and the next chunk's Kuf panels (gradient mode only: without the SYRKs there is
     // nothing on the main stream to hide them under)
     const bool kgrad_side = c->overlap == 1 && k.need_grad && !timed;

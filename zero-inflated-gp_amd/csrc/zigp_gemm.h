@@ -523,13 +523,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
 }
 
 template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, int WAVES, class Epi>
-__global__ void __launch_bounds__(64 * WAVES, ((NSTAGE <= 2) ? 2 : 1) * WAVES / 4)
-gemm_f64_kernel(GemmArgs g, Epi epi, GemmArgs g1, Epi epi1, int split) {
+__device__ __forceinline__ void gemm_workgroup(GemmArgs g, Epi epi, const GemmArgs& g1, const Epi& epi1, int split, int wg, double* lds) {
   // Two argument sets in one launch (the chunk loop's products of latent f and latent g): workgroups [0, split) run set 0 with
-  // list position blockIdx.x, workgroups [round_up(split, 8), gridDim.x) run set 1 with list position blockIdx.x - round_up(split, 8)
+  // list position wg, workgroups [round_up(split, 8), ...) run set 1 with list position wg - round_up(split, 8)
   // (the lists are built for "launch position p runs on XCD p % 8"); the workgroups in between are padding.  A plain launch passes
   // split = gridDim.x.  The choice is made once per workgroup, in scalar registers.
-  int wg = blockIdx.x;
   if (wg >= split) {
     const int s8 = (split + 7) & ~7;
     if (wg < s8) return;
@@ -537,7 +535,6 @@ gemm_f64_kernel(GemmArgs g, Epi epi, GemmArgs g1, Epi epi1, int split) {
   }
   constexpr int WNW = Shape<WAVES>::WNW;
   static_assert(TILE_DOUBLES >= 128 * 16 + 16, "padded k-contiguous image must fit the stage");
-  extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS destinations and wave-level skips stay on the SALU
   const int wm = wave / WNW, wn = wave % WNW;
@@ -560,6 +557,13 @@ gemm_f64_kernel(GemmArgs g, Epi epi, GemmArgs g1, Epi epi1, int split) {
   }
   gemm_tile<ALAY, BLAY, NSTAGE, KSCALE, TRI, WAVES>(g, tl, lds, wave, wm, wn, lane, epi);
   }
+}
+
+template <int ALAY, int BLAY, int NSTAGE, bool KSCALE, int TRI, int WAVES, class Epi>
+__global__ void __launch_bounds__(64 * WAVES, ((NSTAGE <= 2) ? 2 : 1) * WAVES / 4)
+gemm_f64_kernel(GemmArgs g, Epi epi, GemmArgs g1, Epi epi1, int split) {
+  extern __shared__ double lds[];   // NSTAGE * STAGE_DOUBLES
+  gemm_workgroup<ALAY, BLAY, NSTAGE, KSCALE, TRI, WAVES, Epi>(g, epi, g1, epi1, split, (int)blockIdx.x, lds);
 }
 
 }  // namespace zigp

@@ -90,6 +90,37 @@ static int run_gemm2(zigp_ctx* c, const TileList& tl0, GemmArgs g0, EP ep0, cons
   return 0;
 }
 
+// J' = Q A2 of both latents with the point-wise stage as the LEADING workgroups of the same grid (gradient steps): the point-wise stage
+// needs the column sums of A1 / A2 only and J' does not need it, so nothing inside the grid waits for anything; its npw workgroups
+// (two 64-point blocks each; npw a multiple of 8 keeps the tile lists' XCD positions) run while the first tiles start, and the step has
+// one launch and one launch boundary less per chunk.
+template <int NSTAGE_>
+__global__ void __launch_bounds__(512, 4)      // second argument: waves per SIMD (two workgroups per CU: <= 128 VGPRs)
+gemm_j_pw_kernel(GemmArgs g, GemmArgs g1, int split, PwArgs pw, int npw) {
+  extern __shared__ double lds[];
+  if ((int)blockIdx.x < npw) {
+    double (*grp)[PW_GROUPS][PW_PTS] = reinterpret_cast<double (*)[PW_GROUPS][PW_PTS]>(lds + (threadIdx.x >> 8) * (6 * PW_GROUPS * PW_PTS));
+    pw_block<false>(pw, 2 * (int)blockIdx.x + (int)(threadIdx.x >> 8), (int)(threadIdx.x & 255), grp);
+    return;
+  }
+  gemm_workgroup<LAY_MNCONTIG, LAY_MNCONTIG, NSTAGE_, false, TRI_NONE, 8, EpiStorePanel>(g, EpiStorePanel(), g1, EpiStorePanel(), split, (int)blockIdx.x - npw, lds);
+}
+static int run_gemm_j_pw(zigp_ctx* c, const TileList& tl0, GemmArgs g0, const TileList& tl1, GemmArgs g1, const PwArgs& pw, int pw_blocks) {
+  if (tl0.n == 0 || tl1.n == 0 || (pw_blocks % 16) != 0) return fail_arg(c, "run_gemm_j_pw: both latents and a multiple of 1024 points expected");
+  g0.tiles = tl0.d; g0.per = tl0.per; g1.tiles = tl1.d; g1.per = tl1.per;
+  constexpr size_t shm = sizeof(double) * NST * STAGE_DOUBLES;
+  static_assert(shm >= sizeof(double) * 2 * 6 * PW_GROUPS * PW_PTS, "two point-wise blocks' group sums fit the ring");
+  static bool attr_set = false;
+  if (!attr_set) {
+    ZIGP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_j_pw_kernel<NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_set = true;
+  }
+  const int n0 = tl0.n / tl0.per, n1 = tl1.n / tl1.per, npw = pw_blocks / 2;
+  hipLaunchKernelGGL((gemm_j_pw_kernel<NST>), dim3((unsigned)(npw + round_up(n0, 8) + n1)), dim3(512), shm, c->stream, g0, g1, n0, pw, npw);
+  ZIGP_HIP(c, hipGetLastError());
+  return 0;
+}
+
 static inline GemmArgs mk_args(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha = 1.0) {
   GemmArgs g;
   g.seg[0].A = A; g.seg[0].B = B; g.seg[0].lda = lda; g.seg[0].ldb = ldb;

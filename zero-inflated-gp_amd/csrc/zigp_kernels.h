@@ -228,12 +228,11 @@ __device__ __forceinline__ PwOut pointwise_eval(double fm, double fv, double gmn
 // Nc / PW_PTS = 512 blocks x 4 waves keep enough loads in flight to stream the partial-row planes), wave 0 adds the group sums
 // in group order (fixed order: bit-stable) and evaluates the point.
 constexpr int PW_PTS = 64, PW_GROUPS = PW_THREADS / PW_PTS;
+// (a device function: the gradient step runs it as the leading workgroups of the J' launch, two blocks per 512-thread workgroup)
 template <bool PREDICT>
-__global__ void __launch_bounds__(PW_THREADS)
-k_pointwise(PwArgs p) {
-  __shared__ double grp[6][PW_GROUPS][PW_PTS];
-  const int lane = threadIdx.x & (PW_PTS - 1), g = threadIdx.x / PW_PTS;
-  const int64_t n = (int64_t)blockIdx.x * PW_PTS + lane;
+__device__ __forceinline__ void pw_block(const PwArgs& p, int blk, int tid, double (*grp)[PW_GROUPS][PW_PTS]) {
+  const int lane = tid & (PW_PTS - 1), g = tid / PW_PTS;
+  const int64_t n = (int64_t)blk * PW_PTS + lane;
   {
     double fm = 0.0, fsq = 0.0, fs2 = 0.0, gmn = 0.0, gsq = 0.0, gs2 = 0.0;
     for (int q = g; q < p.np1_f; q += PW_GROUPS) {
@@ -290,7 +289,7 @@ k_pointwise(PwArgs p) {
   }
   // block sums = sums over this one wave; acc[block] keeps accumulating chunk after chunk
   const double s0 = wave_sum(valid ? p.scale * o.ve : 0.0), s1 = wave_sum(sc * o.dnoise), s2 = wave_sum(sc * o.dfv), s3 = wave_sum(sc * o.dgv);
-  double* a = p.acc + (int64_t)blockIdx.x * PW_ACC;
+  double* a = p.acc + (int64_t)blk * PW_ACC;
   if (lane == 0) { a[0] += s0; a[1] += s1; a[2] += s2; a[3] += s3; }
   if (p.mean_on) {   // d/d mean_b = sum gm_f, d/d mean_a[d] = sum gm_f x_d
     const double gmf = sc * o.dfm;
@@ -301,6 +300,12 @@ k_pointwise(PwArgs p) {
       if (lane == 0) a[5 + d] += sa;
     }
   }
+}
+template <bool PREDICT>
+__global__ void __launch_bounds__(PW_THREADS)
+k_pointwise(PwArgs p) {
+  __shared__ double grp[6][PW_GROUPS][PW_PTS];
+  pw_block<PREDICT>(p, blockIdx.x, threadIdx.x, grp);
 }
 
 // ---------------------------------------------------------------------------------------------
