@@ -211,6 +211,12 @@ def test_two_latents_in_one_launch_with_different_block_counts(engine):
     for k in g:
         assert relerr(g[k], g2[k]) <= 1e-7, k
     engine.set_chunk(65536)
+    # the single-stream schedule of zigp_set_overlap(0) keeps the point-wise stage in its own launch (with the overlap it rides in the
+    # J' launch of both latents) and runs the side kernels on the main stream: only the order of independent work differs
+    engine.set_overlap(False)
+    ed0, kl0, g0 = engine.elbo(p, jitter=1e-6)
+    engine.set_overlap(True)
+    assert ed0 == ed and kl0 == kl and all(np.array_equal(np.asarray(g0[k]), np.asarray(g[k])) for k in g)
     rows = (12800, 12800 + 25600)                 # 200 panels x 5 units = 1000 workgroups = 0.98 of two waves: merged as well
     eds, _, gs = engine.elbo(p, jitter=1e-6, rows=rows, include_kl=False)
     sl = slice(*rows)
