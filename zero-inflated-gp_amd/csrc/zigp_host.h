@@ -68,8 +68,8 @@ static int run_gemm(zigp_ctx* c, const TileList& tl, GemmArgs g, EP ep) {
   return 0;
 }
 // The same product for two argument sets (latent f and latent g of one chunk) in ONE launch: set 1's workgroups follow set 0's in the
-// dispatch order, so the tail of one product is filled by the head of the other and a chunk costs four launch boundaries instead of
-// eight.
+// dispatch order, so the tail of one product is filled by the head of the other and the forward products of a chunk are three
+// launches instead of six.
 template <int AL, int BL, bool KS, int TRI = TRI_NONE, class EP>
 static int run_gemm2(zigp_ctx* c, const TileList& tl0, GemmArgs g0, EP ep0, const TileList& tl1, GemmArgs g1, EP ep1) {
   if (tl0.n == 0) return run_gemm<AL, BL, KS, TRI>(c, tl1, g1, ep1);
