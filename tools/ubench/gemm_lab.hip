@@ -216,6 +216,116 @@ k_v3(GemmArgs g, Stamp* stamps) {
   }
 }
 
+
+// ---- "dva": the A operand DIRECT to registers (the verdict's suggestion, what the vendor's gfx950 DGEMM kernels do): only the B tile is staged
+// through LDS; each wave fetches its own A fragments -- lane (kq, cj) of sub-tile tm and k-step ks holds A(row 32 wm + 16 tm + cj,
+// k 4 ks + kq) -- with global_load_dwordx2 (16 lanes = 128 contiguous bytes of the m-contiguous image), one staged step ahead, into a
+// second register set.  Per staged step and wave: 8 such loads instead of this wave's share of the A tile's LDS staging (2 x 1 KB), and 4
+// instead of 6 ds_read_b64 per k-step; the two waves of a wave row fetch the same A data (L1 / L2 hits).  The main loop is unrolled over
+// the two register sets / ring slots.  Result (profiles/r05y_gemm_lab_direct_to_vgpr.log): bit-identical to the product kernel, 68.2 vs 71.5 TFLOP/s (72.7 vs 73.5 without
+// the barrier): within 128 VGPRs there is room for ONE step of A prefetch only, every wave then waits for its own ten loads at the top of each
+// step and the barrier collects the slowest of eight -- the LDS ring, where any wave's staged chunk serves all, hides the same latency better.
+template <int OFF> __device__ __forceinline__ double gld64(const char* base, uint32_t off) {
+  double v; asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(v) : "v"(off), "s"(base), "n"(OFF) : "memory"); return v;
+}
+template <int OFF> __device__ __forceinline__ double gld64_first(const char* base, uint32_t off) {    // behind a v_readfirstlane of `base`: 5 wait states
+  double v; asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(v) : "v"(off), "s"(base), "n"(OFF) : "memory"); return v;
+}
+template <int KO>
+__global__ void __launch_bounds__(512, 4)
+k_dva(GemmArgs g, Stamp* stamps) {
+  constexpr bool NOBAR = (KO & 1) != 0, NOEPI = (KO & 4) != 0;
+  constexpr int LDM = 144, TILE_D = 16 * LDM;
+  extern __shared__ double lds[];      // two ring slots of the B tile
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const GemmSeg& sg = g.seg[0];
+  if (stamps && t == 0) { Stamp& s = stamps[blockIdx.x]; s.t0 = (long long)__builtin_amdgcn_s_memtime(); s.r0 = (long long)__builtin_amdgcn_s_memrealtime(); }
+  int lane = t & 63;
+  asm volatile("" : "+v"(lane));
+  const int kq = lane >> 4, cj = lane & 15;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)lds;
+  const uint32_t b_addr0 = lds0 + 8u * (uint32_t)(kq * LDM + wn * 64 + cj);
+  double* __restrict__ C = g.C;
+  const int64_t ld = g.ldc;
+  const uint32_t offB = glds_lane_offset<LAY_MNCONTIG, 8>(sg.ldb, wave, lane);
+  const int64_t csB = glds_chunk_stride<LAY_MNCONTIG, 8>(sg.ldb);
+  uint32_t aoff = (uint32_t)((kq * sg.lda + wm * 32 + cj) * 8);     // k-step ks adds 4 ks lda doubles to the SCALAR base
+  asm volatile("" : "+v"(aoff));
+  const int64_t kstepA = 4 * 8 * sg.lda;
+  const char* nextA = nullptr; const char* nextB = nullptr; int64_t strideA = 0, strideB = 0;
+  double ag[2][4][2];
+  auto issueB = [&](int slot) {
+    stage_mn<8, LDM>(lds + slot * TILE_D, nextB, offB, csB, wave);
+    nextB = glds_pin(nextB + strideB);
+  };
+  auto issueA = [&](auto set_) {
+    constexpr int set = decltype(set_)::value;
+    ag[set][0][0] = gld64_first<0>(nextA, aoff); ag[set][0][1] = gld64<128>(nextA, aoff);
+    sfor<1, 4>([&](auto ks_) { constexpr int ks = decltype(ks_)::value; const char* b = nextA + ks * kstepA; ag[set][ks][0] = gld64<0>(b, aoff); ag[set][ks][1] = gld64<128>(b, aoff); });
+    nextA = glds_pin(nextA + strideA);
+  };
+  mfma_d4 acc[2][4];
+  const GemmTile* my = g.tiles + (int64_t)blockIdx.x * g.per;
+  bool ring_used = false;
+  for (int u = 0; u < g.per; ++u) {
+  const GemmTile tl = my[u];
+  if (tl.kend <= tl.kbeg) continue;
+  const int64_t row0 = (int64_t)tl.bi * BM, col0 = (int64_t)tl.bj * BN;
+  const int total = tl.kend - tl.kbeg;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+  if (ring_used) __builtin_amdgcn_s_barrier();
+  ring_used = true;
+  {
+    const int64_t kfirst = (int64_t)tl.kbeg * BK;
+    nextA = glds_pin((const char*)(sg.A + kfirst * sg.lda + row0));
+    nextB = glds_pin((const char*)(sg.B + kfirst * sg.ldb + col0));
+    strideA = (int64_t)BK * 8 * sg.lda; strideB = (int64_t)BK * 8 * sg.ldb;
+  }
+  issueB(0); issueA(IC<0>{});
+  auto step = [&](int it, auto par_) {
+    constexpr int P = decltype(par_)::value;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!NOBAR) __builtin_amdgcn_s_barrier();
+    if (it + 1 < total) { issueB(P ^ 1); issueA(IC<P ^ 1>{}); }
+    const uint32_t ba = b_addr0 + (uint32_t)(P * TILE_D * 8);
+    double bf[2][4];
+    auto loadB = [&](auto ks_, auto set_) {
+      constexpr int ks = decltype(ks_)::value, set = decltype(set_)::value;
+      sfor<0, 4>([&](auto p_) { constexpr int p = decltype(p_)::value; bf[set][p] = ds_rd64<(ks * 4 * LDM + p * 16) * 8>(ba); });
+    };
+    loadB(IC<0>{}, IC<0>{});
+    sfor<0, 4>([&](auto ks_) { constexpr int ks = decltype(ks_)::value;
+      if constexpr (ks < 3) { loadB(IC<ks + 1>{}, IC<(ks + 1) & 1>{}); wait_lgkm<4>(); } else wait_lgkm<0>();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[P][ks][tm], bf[ks & 1][tn], acc[tm][tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  int it = 0;
+  for (; it + 1 < total; it += 2) { step(it, IC<0>{}); step(it + 1, IC<1>{}); }
+  if (it < total) step(it, IC<0>{});
+  if (NOEPI && acc[0][0][0] != 1.2345e300) continue;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t gi = row0 + wm * 32 + tm * 16 + 4 * r + kq;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) C[gi * ld + col0 + wn * 64 + tn * 16 + cj] = g.alpha * acc[tm][tn][r];
+    }
+  }
+  if (stamps && t == 0) { Stamp& s = stamps[blockIdx.x]; s.t1 = (long long)__builtin_amdgcn_s_memtime(); s.r1 = (long long)__builtin_amdgcn_s_memrealtime(); }
+}
+
 static GemmTile mk(int bi, int bj, int k0, int k1, int flags = 0) {
   GemmTile t; t.bi = bi; t.bj = bj; t.kbeg = k0; t.kend = k1; t.slice = 0; t.kdir = 1; t.pad1 = flags; t.pad2 = 0; return t;
 }
@@ -321,7 +431,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_p));             \
     const GemmArgs g = args(A);                                                                                                       \
     const int grid = (int)tl[A].size() / per[A];                                                                                      \
-    vars.push_back({NAME, [=] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shm_p, 0, g, EpiStore()); }, grid, A, true, false, {}}); \
+    vars.push_back({NAME, [=] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shm_p, 0, g, EpiStore(), g, EpiStore(), grid); }, grid, A, true, false, {}}); \
   }
   ADDP(TRI_NONE, 0, "full  product kernel (8 waves, 2x4 sub-tiles)")
   ADDP(TRI_A_LOWER, 1, "lower product kernel (balanced pairs)")
@@ -339,17 +449,19 @@ int main(int argc, char** argv) {
     vars.push_back({nm, [=] { hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), shm, 0, g, st); }, grid, (A) % 3, false, (KO) == 0, {}}); \
   }
   ADD(8, 4, 0, 0, 0, 0)
-  ADD(8, 4, 0, 0, 3, 0)
-  ADD(8, 4, 0, 0, 3, 1)
-  ADD(8, 1, 0, 0, 0, 0)
-  ADD(8, 1, 0, 0, 3, 1)
-  ADD(8, 1, 1, 0, 1, 0)
-  ADD(8, 1, 1, 0, 1, 1)
-  ADD(8, 1, 1, 0, 4, 1)
-  ADD(8, 1, 2, 0, 2, 0)
-  ADD(8, 1, 2, 0, 2, 1)
-  ADD(8, 1, 2, 0, 5, 1)
-  ADD(8, 1, 1, 4, 1, 0)
+#define ADDD(KO, NAME)                                                                                                                \
+  {                                                                                                                                   \
+    auto kern = k_dva<KO>;                                                                                                            \
+    const size_t shm = sizeof(double) * 2 * 16 * 144;                                                                                 \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));               \
+    const GemmArgs g = args(0);                                                                                                       \
+    const int grid = (int)tl[0].size() / per[0];                                                                                      \
+    Stamp* st = dS;                                                                                                                   \
+    vars.push_back({NAME, [=] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shm, 0, g, st); }, grid, 0, false, (KO) == 0, {}});   \
+  }
+  ADDD(0, "full  dva: A operand direct to registers")
+  ADDD(1, "full  dva ko1 (no barrier; timing only)")
+  ADDD(4, "full  dva ko4 (no stores; timing only)")
 
   Timer tm;
   for (size_t i = 0; i < vars.size(); ++i) {
