@@ -283,6 +283,24 @@ def other_configs(eng, X3, Y3, p3, jitter):
                                   allreduce_us_assumed=50.0,
                                   note='projected_8gpu_speedup (top level) = ms_per_step / (this + the assumed all-reduce): arithmetic on two '
                                        'one-GPU measurements, NOT a measured 8-GPU run; the all-reduce of the 82 KB vector is assumed, never measured here')
+    # cfg4 (N = 8e6 = 8 ranks x 1e6 rows) as ONE resident call on this one GPU: the whole of the 8-GPU job's arithmetic, no exchange
+    # (tests/test_gpu_fullsize.py::test_cfg4_all_eight_shards... checks the eight per-rank results against exactly this call)
+    if N3 == 1000000 and M3 >= 128:
+        try:
+            import torch
+            X8, Y8, _ = synth(CFG4_SHARDS * N3, M3, X3.shape[1])
+            X8d, Y8d = torch.from_numpy(X8).to('cuda:%d' % eng.device), torch.from_numpy(Y8).to('cuda:%d' % eng.device)
+            eng.set_data_device(X8d, Y8d)
+            t4 = timeit(lambda: eng.elbo(p3, jitter=jitter), 2, 1)
+            ed4, kl4, _ = eng.elbo(p3, jitter=jitter, need_grad=False)
+            out['cfg4_on_one_gpu'] = dict(workload='cfg4 stream, N=%d rows (8 x 1e6), M=%d, value+gradient, ONE resident call on one GPU (no exchange)' % (X8.shape[0], M3),
+                                          ms_per_step=t4 * 1e3, steps_per_s_1e6_row_units=X8.shape[0] / 1e6 / t4,
+                                          frac_10M2N=10.0 * M3 * M3 * X8.shape[0] / t4 / PEAK_FP64_MFMA, elbo=ed4 - kl4)
+            eng.set_data(X3[:1024], Y3[:1024])
+            del X8d, Y8d, X8, Y8
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out['cfg4_on_one_gpu_error'] = repr(e)
     # cfg2: N=1e5, M=512
     X2, Y2, p2 = synth(100000, 512, 3)
     eng.set_data(X2, Y2)

@@ -11,11 +11,12 @@ extern "C" {
 /* Accumulated HIP-event time (ms), launch count and algorithmic flops per kernel class since the last reset,
  * measured with HIP events on the stream the kernels run on.  Classes (gemm_f64_kernel template arguments are
  * <A layout, B layout, ring stages, k-scale, triangular mode, waves, epilogue>):
- * 0 gemm_A1  A1 = W K            gemm_f64_kernel<1,1,2,false,1,8,EpiStoreColsum>   (W read through its transpose)
- * 1 gemm_A2  A2 = W^T A1         gemm_f64_kernel<1,1,2,false,2,8,EpiStoreColsum>
- * 2 gemm_H   H = W diag(s^2) A2  gemm_f64_kernel<1,1,2,false,1,8,EpiStore>
- * 3 gemm_J   J' = W^T H - A2     gemm_f64_kernel<1,1,2,false,2,8,EpiSubLoad>
- * 4 syrk     C1 += A1 G A1^T     gemm_f64_kernel<0,0,2,true,3,4,EpiAccum>
+ * 0 gemm_A1  A1 = W K                  gemm_f64_kernel<1,1,2,false,1,8,EpiStoreColsum>   (W read through its transpose; fused sum v A1, sum A1^2)
+ * 1 gemm_A2  A2 = W^T A1               gemm_f64_kernel<1,1,2,false,2,8,EpiColsum>        (fused sum s^2 A2^2; the panel itself is not stored)
+ * 2 gemm_H   (not launched since round 4: H = W diag(s^2) A2 is folded into class 3; the slot keeps the class numbering)
+ * 3 gemm_J   J' = Q A2 = (Q W^T) A1    gemm_f64_kernel<1,1,2,false,0,8,EpiStorePanel>    (one full product on the A1 panel; with zigp_set_overlap(1) it is
+ *                                      gemm_j_pw_kernel, whose leading workgroups are the point-wise stage)
+ * 4 syrk     C1 += A1 G A1^T           gemm_f64_kernel<0,0,2,true,3,4,EpiAccum>
  * 5 kuf_build   6 pointwise   7 kgrad   8 MxM stage (all kernels)   9 everything else. */
 #define ZIGP_NCLASS 10
 int zigp_profile_enable(zigp_ctx* ctx, int32_t on);

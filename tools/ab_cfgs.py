@@ -17,4 +17,9 @@ for name, N, M, rows, reps in (('cfg3', 1000000, 1024, None, 3), ('shard125k', 1
         for _ in range(reps): e.elbo(p, **kw)
         best = min(best, (time.time() - t0) / reps * 1e3)
     out.append('%s %.3f' % (name, best))
+    if name == 'cfg3':          # value-only ELBO of the same rows (the forward pass alone: A1, A2 column sums, point-wise)
+        e.elbo(p, need_grad=False)
+        t0 = time.time()
+        for _ in range(3): e.elbo(p, need_grad=False)
+        out.append('cfg3fwd %.3f' % ((time.time() - t0) / 3 * 1e3))
 print(os.path.basename(os.environ.get('ZIGP_LIB', 'libzigp.so')), ' '.join(out), 'ms')

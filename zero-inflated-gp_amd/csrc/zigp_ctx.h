@@ -47,10 +47,10 @@ struct Latent {
   DevBuf Zs;                            // Z scaled by KUF_C / ell_d (k_kuf_build's units), same padding
   double var = 1.0;
   DevBuf Kuu, L, W;                      // (Mp,Mp)
-  DevBuf K, A1, A2, Jp;                  // chunk panels [Mp][Nc]: Kuf, A1 = W K, A2 = W^T A1, J' = Q A2 (= W^T W diag(s^2) A2 - A2)
+  DevBuf K, A1, Jp;                      // chunk panels [Mp][Nc]: Kuf, A1 = W K, J' = Q W^T A1 (A2 = W^T A1 is reduced to its column sums and never stored: r6)
   DevBuf Wp, a1gm;                       // W diag(s^2) (Mp,Mp); running sum of A1 gm [Mp]
   DevBuf Wt, Wpt;                        // W^T, (W diag(s^2))^T (Mp,Mp): the m-contiguous images the lower-triangular products read
-  DevBuf P, Qt;                          // gradient steps: P = W^T W = Kuu^-1 and Qt = diag(s^2) P - I = Q^T, J' = Q A2 (zigp_dense.hip, chunk_forward)
+  DevBuf P, Qt, Rt;                      // gradient steps: P = W^T W = Kuu^-1, Qt = diag(s^2) P - I = Q^T, Rt = W Qt = (Q W^T)^T: J' = Q A2 = (Q W^T) A1 (zigp_dense.hip, chunk_forward)
   bool P_ready = false;                  // P of THIS call's parameters is in `P` (the reverse M x M stage takes it from there)
   DevBuf part;                           // [3][Mp/32][Nc] partial rows of the fused column sums: v^T A1, sum A1^2, sum s^2 A2^2
   DevBuf gm, gv;                         // cotangents of mean / var per column [Nc]

@@ -2,8 +2,8 @@
 //
 // Per ELBO step (value + gradient), for each latent h in {f, g}:
 //   MxM stage   Kuu = k(Z,Z)+jitter I ; L = chol(Kuu) ; W = L^-1                    (OnOffSVGP.py:96-97, main.py:267-268)
-//   per chunk   K = k(Z, Xc) ; A1 = W K ; A2 = W^T A1 ; column sums -> mean, var      (main.py:266-303)
-//               H = (W diag(s^2)) A2 ; J' = W^T H - A2                                (gradient panels, independent of the cotangents)
+//   per chunk   K = k(Z, Xc) ; A1 = W K ; A2 = W^T A1 ; column sums -> mean, var      (main.py:266-303; A2 lives in accumulators only)
+//               H = (W diag(s^2)) A2 ; J' = W^T H - A2 = Q A2 = (Q W^T) A1            (gradient panels, independent of the cotangents)
 //               point-wise probit / likelihood / reverse pass -> gm, gv               (OnOffSVGP.py:168-204, OnOffLikelihood.py:30-32)
 //               reverse of the two triangular solves, with G = diag(gv), v = W u, alpha = W^T v:
 //                 E = W dA2 = v gm^T + 2 H G ;  F = dK = W^T(E - 2 A1 G) = alpha gm^T + 2 J' G
@@ -80,7 +80,7 @@ int latents_upload(zigp_ctx* c, const HostLatent (&hl)[2], int D) {
     ZIGP_ENSURE(c, lt.Wp, Mp * Mp);
     ZIGP_ENSURE(c, lt.Wt, Mp * Mp);
     ZIGP_ENSURE(c, lt.Wpt, Mp * Mp);
-    ZIGP_ENSURE(c, lt.P, Mp * Mp); ZIGP_ENSURE(c, lt.Qt, Mp * Mp);
+    ZIGP_ENSURE(c, lt.P, Mp * Mp); ZIGP_ENSURE(c, lt.Qt, Mp * Mp); ZIGP_ENSURE(c, lt.Rt, Mp * Mp);
   }
   return 0;
 }
@@ -109,7 +109,7 @@ int latents_forward(zigp_ctx* c, const HostLatent (&hl)[2], int D, double jitter
     }
     ZIGP_TRY(potrf_trtri_jobs(c, 2, jobs, st));
   }
-  for (int step = 0; step < 7; ++step)
+  for (int step = 0; step < 8; ++step)
     for (int h = 0; h < 2; ++h) {
       Latent& lt = c->lat[h];
       const int Mp = lt.Mp;
@@ -137,6 +137,14 @@ int latents_forward(zigp_ctx* c, const HostLatent (&hl)[2], int D, double jitter
           break;
         case 6:   // Q^T = diag(s^2) P - I: J' = W^T (W diag(s^2) A2) - A2 = (P diag(s^2) - I) A2 = Q A2 is ONE full product per chunk
           if (need_grad) hipLaunchKernelGGL(k_rowscale_minus_eye, dim3(ceil_div((int64_t)Mp * Mp, 256)), dim3(256), 0, c->stream, lt.P.p, lt.s2.p, (int64_t)Mp, lt.Qt.p);
+          break;
+        case 7:   // R^T = W Q^T (W lower triangular: k blocks 0 .. bi): J' = Q (W^T A1) = (Q W^T) A1 reads the A1 panel, so that the A2 panel
+                  // has no reader left and is never written (r6; 8 Mp Nc bytes per latent and chunk, the A2 product 66 -> 69 TFLOP/s)
+          if (need_grad) {
+            const int nb = Mp / BM, kb = BM / BK;
+            ZIGP_TRY((run_gemm_sk<LAY_KCONTIG, LAY_MNCONTIG>(c, lt.sk, "rt", nb, [&](int bi, int, int& k0, int& k1) { k0 = 0; k1 = (bi + 1) * kb; },
+                                                             lt.W.p, lt.Qt.p, lt.Rt.p, Mp, SK_STORE, 1.0, false)));
+          }
           break;
         default: break;
       }
@@ -169,7 +177,7 @@ int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, i
 // cfg2 +1.2 %), and so does the rank-N update everywhere (its 512-workgroup split-K plan fills the chip exactly; merged +0.2 %).
 int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad, const PwArgs* fuse_pw = nullptr, bool* fused = nullptr) {
   const int nbn = (int)(Nc / BN);
-  struct Set { TileList tl, tu, tf; double fl; GemmArgs a1, a2, j; EpiStoreColsum e1, e2; } q[2];
+  struct Set { TileList tl, tu, tf; double fl; GemmArgs a1, a2, j; EpiStoreColsum e1; EpiColsum e2; } q[2];
   const bool paired = trmm_paired_pays(nbn * ((c->lat[0].Mp / BM + 1) / 2 + (c->lat[1].Mp / BM + 1) / 2)), merge = paired;
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
@@ -182,14 +190,15 @@ int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad, const PwArgs* fuse_pw
     // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
     q[h].a1 = mk_args(lt.Wt.p, Mp, lt.K.p, Nc, lt.A1.p, Nc);
     q[h].e1 = EpiStoreColsum{lt.vec.p, nullptr, lt.part.p, lt.part.p + (size_t)np * Nc};
-    // A2 = W^T A1 ; partial column sums  sum s^2 A2^2
-    q[h].a2 = mk_args(lt.W.p, Mp, lt.A1.p, Nc, lt.A2.p, Nc);
-    q[h].e2 = EpiStoreColsum{nullptr, lt.s2.p, nullptr, lt.part.p + (size_t)2 * np * Nc};
-    // J' = Q A2, Q = Kuu^-1 diag(s^2) - I (M x M, dense): the two triangular products H = W diag(s^2) A2, J' = W^T H - A2 of the reverse
-    // pass as ONE full product of the same flop count -- every tile the full k range (no triangular padding, half as many prologues and
+    // A2 = W^T A1 ; partial column sums  sum s^2 A2^2 -- the sums only: the panel itself has no reader (EpiColsum; ldc = stride of the partial rows)
+    q[h].a2 = mk_args(lt.W.p, Mp, lt.A1.p, Nc, nullptr, Nc);
+    q[h].e2 = EpiColsum{nullptr, lt.s2.p, nullptr, lt.part.p + (size_t)2 * np * Nc};
+    // J' = Q A2 = (Q W^T) A1, Q = Kuu^-1 diag(s^2) - I (M x M, dense): the two triangular products H = W diag(s^2) A2, J' = W^T H - A2 of the
+    // reverse pass as ONE full product of the same flop count -- every tile the full k range (no triangular padding, half as many prologues and
     // epilogues per flop), no H panel written and read back, no operand tile in the epilogue (r4: J' 61.9 -> 70.2 TFLOP/s, step -3.8 %,
-    // profiles/r04ak_ab_qform.log; the two-product form is in tools/r4_experiment_arms.patch).
-    q[h].j = mk_args(lt.Qt.p, Mp, lt.A2.p, Nc, lt.Jp.p, Nc);
+    // profiles/r04ak_ab_qform.log; the two-product form is in tools/r4_experiment_arms.patch).  r6: with R = Q W^T formed once per step in the
+    // M x M stage (latents_forward) the product reads the A1 panel, not A2.
+    q[h].j = mk_args(lt.Rt.p, Mp, lt.A1.p, Nc, lt.Jp.p, Nc);
   }
   if (merge) {
     {
@@ -431,7 +440,7 @@ int dense_prepare_buffers(zigp_ctx* c, DenseCall& k) {
     const int Mp = lt.Mp;
     ZIGP_ENSURE(c, lt.gm, Nc); ZIGP_ENSURE(c, lt.gv, Nc);
     if (k.has_rows) {
-      ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A2, (size_t)Mp * Nc);
+      ZIGP_ENSURE(c, lt.K, (size_t)Mp * Nc); ZIGP_ENSURE(c, lt.A1, (size_t)Mp * Nc);
       ZIGP_ENSURE(c, lt.part, (size_t)3 * (Mp / 32) * Nc);
       if (k.need_grad) ZIGP_ENSURE(c, lt.Jp, (size_t)Mp * Nc);
     }
@@ -667,7 +676,7 @@ int zigp_destroy(zigp_ctx* c) {
   if (c->comm) { RcclApi* api = rccl_api(nullptr); if (api) (void)api->CommDestroy(static_cast<ncclComm_t>(c->comm)); c->comm = nullptr; }
   for (int h = 0; h < 2; ++h) {
     Latent& l = c->lat[h];
-    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.A2, &l.Jp, &l.Wp, &l.Wt, &l.Wpt, &l.P, &l.Qt, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
+    DevBuf* bs[] = {&l.Z, &l.ell, &l.u, &l.s, &l.s2, &l.Kuu, &l.L, &l.W, &l.K, &l.A1, &l.Jp, &l.Wp, &l.Wt, &l.Wpt, &l.P, &l.Qt, &l.Rt, &l.a1gm, &l.part, &l.gm, &l.gv, &l.du, &l.dsq, &l.krow,
                     &l.dLpart, &l.T1, &l.T2, &l.T3, &l.G, &l.vec, &l.sk};
     for (DevBuf* b : bs) b->release();
   }

@@ -123,44 +123,54 @@ struct EpiAccum {   // C += alpha*acc
 //                                      out2[n] = sum_m w2[m] C[m,n]^2 (w2 == nullptr -> weight 1)
 // written to partial row e.prow (one per wave and row block) of out1/out2 (each [Mp / (16 TM)][ldc]); the point-wise kernel adds the partial
 // rows in index order, so the result does not depend on scheduling.
+template <bool STORE, int TM, int TN>
+__device__ __forceinline__ void epi_colsum(const double (&acc)[TM][TN][4], const EpiCtx& e, const double* __restrict__ w1, const double* __restrict__ w2,
+                                           double* __restrict__ out1, double* __restrict__ out2) {
+  double* __restrict__ C = e.C; const int64_t ld = e.ldc;
+  const int c_i = e.lane >> 4, c_j = e.lane & 15;
+  // one partial row per wave tile (16 * TM rows)
+  double s1[TN], s2[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) { s1[tn] = 0.0; s2[tn] = 0.0; }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t gi = e.row0 + tm * e.tm_stride + 4 * r + c_i;
+      const double a1 = w1 ? w1[gi] : 0.0, a2 = w2 ? w2[gi] : 1.0;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const double v = e.alpha * acc[tm][tn][r];
+        if (STORE) C[gi * ld + e.col0 + tn * 16 + c_j] = v;
+        s1[tn] = fma(a1, v, s1[tn]);
+        s2[tn] = fma(a2 * v, v, s2[tn]);
+      }
+    }
+  const int64_t prow = e.prow;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {   // fixed-order combine of the four 16-lane row groups
+    double a = s1[tn], b = s2[tn];
+    a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+    if (c_i == 0) {
+      const int64_t o = prow * ld + e.col0 + tn * 16 + c_j;
+      if (w1) out1[o] = a;
+      out2[o] = b;
+    }
+  }
+}
 struct EpiStoreColsum {
   const double* __restrict__ w1; const double* __restrict__ w2; double* __restrict__ out1; double* __restrict__ out2;
   template <int TM, int TN>
-  __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const {
-    double* __restrict__ C = e.C; const int64_t ld = e.ldc;
-    const int c_i = e.lane >> 4, c_j = e.lane & 15;
-    {   // one partial row per wave tile (16 * TM rows)
-      double s1[TN], s2[TN];
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) { s1[tn] = 0.0; s2[tn] = 0.0; }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t gi = e.row0 + tm * e.tm_stride + 4 * r + c_i;
-          const double a1 = w1 ? w1[gi] : 0.0, a2 = w2 ? w2[gi] : 1.0;
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            const double v = e.alpha * acc[tm][tn][r];
-            C[gi * ld + e.col0 + tn * 16 + c_j] = v;
-            s1[tn] = fma(a1, v, s1[tn]);
-            s2[tn] = fma(a2 * v, v, s2[tn]);
-          }
-        }
-      const int64_t prow = e.prow;
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {   // fixed-order combine of the four 16-lane row groups
-        double a = s1[tn], b = s2[tn];
-        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-        if (c_i == 0) {
-          const int64_t o = prow * ld + e.col0 + tn * 16 + c_j;
-          if (w1) out1[o] = a;
-          out2[o] = b;
-        }
-      }
-    }
-  }
+  __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const { epi_colsum<true>(acc, e, w1, w2, out1, out2); }
+};
+// The column sums WITHOUT the panel (round 6): A2 = W^T A1 is needed for  sum_m s^2 A2^2  only -- the reverse pass takes J' = (Q W^T) A1 from
+// A1 directly and A2 gm = W^T (A1 gm) is linear -- so the product's 8 Mp Nc bytes are never written: same accumulators, same sums, bit for bit.
+// e.ldc is still the row stride of the partial-row planes; e.C is not used.
+struct EpiColsum {
+  const double* __restrict__ w1; const double* __restrict__ w2; double* __restrict__ out1; double* __restrict__ out2;
+  template <int TM, int TN>
+  __device__ __forceinline__ void operator()(const double (&acc)[TM][TN][4], const EpiCtx& e) const { epi_colsum<false>(acc, e, w1, w2, out1, out2); }
 };
 
 // k-contiguous image swizzle: granule position = (k>>1) ^ kswz(row).  kswz takes 8 distinct values on the even and on the odd rows of

@@ -13,9 +13,9 @@ NCLASS = 10
 LIK_ONOFF, LIK_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2   # include/zigp.h ZIGP_LIK_*
 PROF_CLASSES = ('gemm_A1', 'gemm_A2', 'gemm_H', 'gemm_J', 'syrk', 'kuf_build', 'pointwise', 'kgrad', 'mxm_stage', 'other')
 PROF_KERNELS = {'gemm_A1': 'gemm_f64_kernel<1,1,2,false,1,8,EpiStoreColsum> (A1 = W K, W read through W^T)',
-                'gemm_A2': 'gemm_f64_kernel<1,1,2,false,2,8,EpiStoreColsum> (A2 = W^T A1)',
+                'gemm_A2': 'gemm_f64_kernel<1,1,2,false,2,8,EpiColsum> (A2 = W^T A1, reduced to the column sums sum_m s^2 A2^2 in the epilogue; the panel is not stored)',
                 'gemm_H': 'gemm_f64_kernel<1,1,2,false,1,8,EpiStore> (H = W diag(s^2) A2; not launched since round 4: folded into J\')',
-                'gemm_J': 'gemm_f64_kernel<1,1,2,false,0,8,EpiStorePanel> (J\' = Q A2, Q = Kuu^-1 diag(s^2) - I: the products H = W diag(s^2) A2 and J\' = W^T H - A2 as one full product)',
+                'gemm_J': 'gemm_f64_kernel<1,1,2,false,0,8,EpiStorePanel> (J\' = Q A2 = (Q W^T) A1, Q = Kuu^-1 diag(s^2) - I: the products H = W diag(s^2) A2 and J\' = W^T H - A2 as one full product on the A1 panel)',
                 'syrk': 'gemm_f64_kernel<0,0,2,true,3,4,EpiAccum> (C1 += A1 G A1^T)'}
 
 # double* everywhere in the C-ABI; typed as void* on the Python side so that a plain address (ndarray.ctypes.data, 1 us) can be passed
