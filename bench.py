@@ -262,17 +262,44 @@ def kron_roofline(n_rows, t, nb0, nb1, large=False):
                 bound='mfma/valu issue (fp64 MFMA and VALU serialise on a SIMD); launch latency at minibatch size')
 
 
-def other_configs(eng, X3, Y3, p3, jitter):
+def oracle_timing(f, repeats=3):
+    """median wall time of `repeats` runs of the CPU oracle call f (after one warm-up call)"""
+    f()
+    ts = []
+    for _ in range(repeats):
+        t0 = time.time()
+        f()
+        ts.append(time.time() - t0)
+    return float(np.median(ts)), [round(x, 4) for x in ts]
+
+
+def other_configs(eng, X3, Y3, p3, jitter, cpu_threads=None):
     """The other BASELINE.json configurations and SURVEY section 8d's 'reported separately' numbers, each well under a second
-    (N=1 only; `value` above is cfg3 value+gradient)."""
+    (N=1 only; `value` above is cfg3 value+gradient).  cpu_threads: time the CPU oracle beside cfg2 and beside the reference's own loop body
+    (one 1000-row Kronecker minibatch step, scripts/onoff.py:375-386) with that many torch threads; None: skip."""
     out = {}
     N3, M3 = X3.shape[0], p3['Zf'].shape[0]
+    if cpu_threads:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import torch as _torch
+        import zigp_oracle_torch as ot
+        _torch.set_num_threads(cpu_threads)
     # cfg3 forward-only ELBO and predict (OnOffSVGP.py:160-162; the reference's slowest code is the per-row loop onoffpred.py:176-195)
     t = timeit(lambda: eng.elbo(p3, jitter=jitter, need_grad=False), 2, 1)
     out['cfg3_forward_only'] = dict(ms_per_eval=t * 1e3, evals_per_s=1 / t, frac_4M2N=4.0 * M3 * M3 * N3 / t / PEAK_FP64_MFMA)
     npred = min(262144, N3)
     t = timeit(lambda: eng.predict(p3, X3[:npred], jitter=jitter), 2, 1)
     out['cfg3_predict'] = dict(rows=npred, ms=t * 1e3, rows_per_s=npred / t, note='host X in, (9,N) host out: PCIe-inclusive')
+    try:      # the same prediction with the rows and the (9, N) result resident in HBM (zigp_predict_device): only the parameters cross PCIe
+        import torch
+        X3d = torch.from_numpy(X3).to('cuda:%d' % eng.device)
+        o9 = torch.empty((9, N3), dtype=torch.float64, device=X3d.device)
+        t = timeit(lambda: eng.predict_device(p3, X3d, jitter=jitter, out=o9), 3, 1)
+        out['cfg3_predict_device'] = dict(rows=N3, ms=t * 1e3, rows_per_s=N3 / t, frac_4M2N=4.0 * M3 * M3 * N3 / t / PEAK_FP64_MFMA,
+                                          note='device X in, device (9,N) out (zigp_predict_device): 4 M^2 N flops, the A2 panel is never written')
+        del X3d, o9
+    except Exception as e:
+        out['cfg3_predict_device_error'] = repr(e)
     # the per-rank step of cfg3 under 8-GPU STRONG scaling (1e6 / 8 rows, the replicated M x M stage in full), timed on this one GPU
     if N3 >= 8 and M3 >= 128:
         n8 = N3 // 8
@@ -308,6 +335,12 @@ def other_configs(eng, X3, Y3, p3, jitter):
     ed, kl, _ = eng.elbo(p2, jitter=jitter)
     out['cfg2'] = dict(workload='N=1e5, D=3, M=512, value+gradient', ms_per_step=t * 1e3, steps_per_s=1 / t,
                        frac_10M2N=10.0 * 512 * 512 * 1e5 / t / PEAK_FP64_MFMA, elbo=ed - kl, rows_per_pass=eng.get_chunk_rows(512, 100000))
+    if cpu_threads:
+        srows = 20000
+        med, ts = oracle_timing(lambda: ot.elbo_and_grad(X2[:srows], Y2[:srows], p2, jitter, chunk=srows))
+        out['cfg2']['cpu_baseline'] = dict(value=1.0 / (med * 100000 / srows), unit='ELBO steps/s (extrapolated to 100000 rows)', cores=cpu_threads, kind='port',
+                                           sample='oracle (torch CPU fp64, reference op order + autograd) on the first %d rows of cfg2, median of 3 runs: %.2f s '
+                                                  'at %d threads; EXTRAPOLATED x %d' % (srows, med, cpu_threads, 100000 // srows), runs_s=ts)
     # cfg5: Kronecker pptr, 32 x 32 (tests/golden/pptr.npz is the reference's data file)
     try:
         from onofftf.model import init_params, engine_params
@@ -354,6 +387,13 @@ def other_configs(eng, X3, Y3, p3, jitter):
                                            what='zigp_kron_fit_steps: gradient + Log1pe chain + per-learning-rate Adam update on the device, '
                                                 'ONE host synchronisation per call (ms_per_step above = one host call per iteration, no update)',
                                            cost_first_last=[float(-(ed_[0] - kl_[0])), float(-(ed_[-1] - kl_[-1]))])
+        if cpu_threads:      # the reference's own timing hook: wall time per iteration of the Kronecker loop (scripts/onoff.py:376,385-386)
+            for key, pq in (('cfg5_mb1000', pk), ('ref_grid_10x100_mb1000', pk2)):
+                med, ts = oracle_timing(lambda: ot.kron_elbo_and_grad(xb, yb, pq, 1e-5, scale=n5 / 1000.0))
+                out[key]['cpu_baseline'] = dict(value=1.0 / med, unit='minibatch steps/s (value + gradient, no update)', cores=cpu_threads, kind='port',
+                                                sample='oracle: LITERAL kron_inf + GaussKLkron (dense Kronecker products, scripts/onoff.py:186-241, onofftf/main.py:350-387) '
+                                                       '+ torch autograd on ONE 1000-row minibatch (the whole unit of work, not a sample), median of 3 runs: %.3f s at %d threads'
+                                                       % (med, cpu_threads), runs_s=ts)
         t = timeit(lambda: eng.kron_predict(pk, Xtr, jitter=1e-6, g_offset=-1.0), 3, 1)
         out['cfg5_predict'] = dict(rows=n5, ms=t * 1e3, rows_per_s=n5 / t)
     except Exception as e:   # the Kronecker numbers are extras: never lose the headline line over them
@@ -587,7 +627,11 @@ def main():
                                     'mxm_stage_ms_both_streams': kms.get('mxm_stage', 0.0),
                                     'chunk_loop_ms_sum': sum(v for k, v in kms.items() if k != 'mxm_stage')}
         if not args.no_other_configs and world == 1:
-            res['other_configs'] = other_configs(eng, X, Y, p, jitter)
+            try:
+                ncpu_oc = len(os.sched_getaffinity(0))
+            except Exception:
+                ncpu_oc = os.cpu_count() or 1
+            res['other_configs'] = other_configs(eng, X, Y, p, jitter, cpu_threads=None if args.no_cpu_baseline else min(16, ncpu_oc))
             eng.set_data_device(Xd, Yd)
             s8 = res['other_configs'].get('strong_1of8')
             if s8:

@@ -63,7 +63,7 @@ int zigp_last_info(zigp_ctx* ctx);
 
 /* Tunables: chunk = number of data rows processed per pass through the fused pipeline (multiple of
  * 1024 and <= 1048576).  Default, until this is called: 32768 * 1024 / M rows, clamped to [32768, 131072]; a row range of up to 131072
- * rows goes through in one pass. */
+ * rows goes through in one pass while its panels stay within 9 GB.  chunk_rows = 0 returns to that default rule. */
 int zigp_set_chunk(zigp_ctx* ctx, int64_t chunk_rows);
 /* The chunk (rows per pass) the dense path uses for M inducing points per latent on a long row range: the zigp_set_chunk value, else
  * the default rule. */
@@ -191,6 +191,10 @@ int zigp_kron_fit_steps(zigp_ctx* ctx, const zigp_kron_params* shape, const zigp
                         int64_t t0, int32_t n_steps, const int64_t* row_begin, int64_t batch,
                         const double* Xw, const double* Yw, double jitter, double scale, int32_t include_kl,
                         double* elbo_data, double* kl);
+/* Updates applied by the LAST zigp_kron_fit_steps call of this context: n_steps after a call that returned 0, the k steps before the failing
+ * one after ZIGP_ENOTPD, 0 when the call ended before its first step (bad argument, HIP error).  This -- not a scan of the history for
+ * NaN: an applied step may itself have a non-finite ELBO -- is what the caller's iteration count and Adam's bias correction advance by. */
+int64_t zigp_kron_fit_steps_applied(zigp_ctx* ctx);
 
 /* Mean function of the latent f: m(x) = b + a . x, added to fmean before the likelihood and in zigp_predict
  * (`fmean = fmean + self.mean_function(Xnew)`, onoffgpf/OnOffSVGP.py:29,134).  Covers GPflow's Zero (the reference default:

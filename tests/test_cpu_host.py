@@ -427,6 +427,57 @@ def test_kron_device_fit_counts_the_steps_applied_before_a_failure_and_notices_o
     assert abs(float(pset.params['likelihood/variance'].value[0]) - 0.5) < 1e-12
     adam.resync()
     assert adam.t == 2
+    # (3) a parameter that has gone NaN is still the value these objects wrote: no resync from free(NaN) on every call, and an
+    # explicit reset (load_checkpoint(..., fitter=...)) restarts the moments and the iteration count
+    fit.x[:] = np.nan
+    fit.sync_params()
+    assert not fit._stale()
+    adam.m['likelihood/variance'][:] = 3.0
+    adam.resync(reset=True)
+    assert adam.t == 0 and float(adam.m['likelihood/variance'][0]) == 0.0
+    pset2 = _kron_pset(p)
+    fit2 = KronDeviceFit(eng, pset2)
+    fit2.steps([0, 1], 10, 1e-5, 1.0)
+    fit2.m[:] = 1.0
+    import tempfile
+    from onofftf.model import save_checkpoint, load_checkpoint
+    with tempfile.TemporaryDirectory() as td:
+        save_checkpoint(_kron_pset(p), os.path.join(td, 'model'))
+        load_checkpoint(pset2, os.path.join(td, 'model'), fitter=fit2)
+    assert fit2.t == 0 and not fit2.m.any() and not fit2._stale()
+    assert np.array_equal(fit2.x, KronDeviceFit(eng, _kron_pset(p)).x)
+
+
+def test_wrapper_never_host_reduces_on_an_engine_that_owns_a_communicator():
+    """libzigp all-reduces every result block whenever the context has a communicator (zigp_comm_init), whatever the Python
+    wrapper was asked for.  A wrapper built with library_comm=False on such an engine must hand the (already summed) results through --
+    reducing them again on the host would return world x the sums -- and refuse an engine whose communicator is for another rank."""
+    from zigp.parallel import ShardedELBO, ShardedKronELBO
+
+    class Dist:
+        def __init__(self, rank, world): self.r, self.w = rank, world
+        def get_rank(self): return self.r
+        def get_world_size(self): return self.w
+        def all_reduce(self, *a, **k): raise AssertionError('host all-reduce on an engine that sums in the library')
+        def get_backend(self): return 'gloo'
+
+    class Eng:
+        def __init__(self, rank, n): self.info = dict(rank=rank, nranks=n, allreduce_calls=0)
+        def comm_info(self): return self.info
+        def elbo(self, p, **kw): return 1.5, 0.25, {k: np.ones(2) for k in ('Zf', 'Zg', 'u_fm', 'u_gm', 'u_fs_sqrt', 'u_gs_sqrt', 'ell_f', 'ell_g', 'var_f', 'var_g', 'noise')}
+        def kron_elbo(self, p, X, Y, **kw): return 2.5, 0.5, {'noise': 1.0}
+
+    sh = ShardedELBO(Eng(1, 2), Dist(1, 2), library_comm=False)
+    assert sh.library_comm and not sh._owns_comm
+    ed, kl, g = sh.elbo({})
+    assert (ed, kl) == (1.5, 0.25) and np.array_equal(g['Zf'], np.ones(2))
+    assert ShardedKronELBO(Eng(0, 2), Dist(0, 2), library_comm=False).kron_elbo({})[0] == 2.5
+    with pytest.raises(ValueError):
+        ShardedELBO(Eng(0, 2), Dist(1, 2), library_comm=False)
+    with pytest.raises(ValueError):
+        ShardedELBO(Eng(0, 4), Dist(0, 2), library_comm=False)
+    sh0 = ShardedELBO(Eng(0, 0), Dist(0, 2), library_comm=False)      # no communicator: the torch.distributed exchange, as before
+    assert not sh0.library_comm
 
 
 def test_data_parallel_allreduce_gloo_world2_equals_single_process():

@@ -18,6 +18,12 @@ CASES = [
     (1500, 300, 300, 2, 0.2, 1024, 0.5),
     (1200, 300, 100, 2, 0.25, 1024, 0.5),  # three 128-blocks against one: the two latents' factorisation chains (launched alternately) differ in length
     (1200, 100, 520, 2, 0.25, 1024, 0.5),  # one block against five (the longer chain on the second stream)
+    # every instantiated input dimension (k_kuf_build<D>, k_kgrad<D>, D = 1..8; ARD lengthscales: the broadcast divide of onofftf/main.py:42)
+    (1500, 96, 140, 4, 0.5, 1024, 0.5),
+    (1400, 150, 90, 5, 0.6, 1024, 0.5),
+    (1100, 130, 64, 6, 0.7, 1024, 0.5),
+    (1000, 64, 64, 7, 0.8, None, 0.5),
+    (1300, 150, 100, 8, 0.9, 1024, 0.5),
 ]
 
 
@@ -471,3 +477,77 @@ def test_automatic_rule_takes_a_short_row_range_in_one_pass_with_the_same_result
         assert abs((one + last) - both) <= 1e-12 * abs(both)
     finally:
         e.close()
+
+
+def test_M2048_sixteen_row_blocks_and_the_chunk_rule_beyond_its_one_pass_bound(engine):
+    """M = 2048 (16 row blocks of 128; Mg = 1100: 9 blocks): the tile lists, the split-K plan of the rank-N update and the blocked
+    factorisation at twice cfg3's depth, against the oracle; then a row range beyond the one-pass bound of the chunk rule (4 panels of
+    8 Mp span bytes per latent <= 9 GB, include/zigp.h zigp_get_chunk_rows): 80 000 rows at M = 2048 go through in three passes of the
+    M-scaled chunk -- same step as with a fixed small chunk, and a slice of it against the oracle."""
+    import zigp_oracle as o
+    import zigp_oracle_torch as ot
+    engine.set_chunk(0)                                         # the automatic rule (earlier tests of the session fixed the chunk)
+    assert engine.get_chunk(2048) == 32768
+    assert engine.get_chunk_rows(2048, 60000) == 60416          # 4 * 2 * 8 * 2048 * 60416 B = 7.9 GB: one pass
+    assert engine.get_chunk_rows(2048, 80000) == 27648          # 10.6 GB: the rule falls back to ceil(80000 / 32768) = 3 equal passes
+    X, Y, p = make_problem(80000, 2048, 3, seed=77, Mg=1100, ell=0.1)
+    c = _cond(p, 1e-6)
+    n = 2500
+    engine.set_data(X[:n], Y[:n])
+    ed, kl, g = engine.elbo(p, jitter=1e-6)
+    e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X[:n], Y[:n], p, 1e-6, chunk=1250)
+    print('M=2048: cond(Kuu)=%.2e elbo rel %.2e kl rel %.2e' % (c, abs((ed - kl) - e_r) / abs(e_r), abs(kl - kl_r) / abs(kl_r)))
+    assert abs(ed - d_r) <= 1e-7 * abs(d_r) and abs(kl - kl_r) <= 1e-8 * abs(kl_r)
+    for k in ot.PARAM_KEYS:
+        e = relerr(np.asarray(g[k]).reshape(-1), np.asarray(g_r[k]).reshape(-1))
+        print('  M=2048 grad %-10s relerr %.2e' % (k, e))
+        assert e < max(1e-6, 1e-13 * c), (k, e)
+    out = engine.predict(p, X[:n], jitter=1e-6)
+    ref = o.build_predict(X[:n], p, 1e-6)
+    for i in range(9):
+        assert relerr(out[i], ref[i].reshape(-1)) < max(1e-9, min(1e-6, 1e-13 * c)), i
+    # the long range: automatic rule (3 passes of 27648 rows) against 10 passes of 8192
+    engine.set_chunk(0)
+    engine.set_data(X, Y)
+    ed_a, kl_a, g_a = engine.elbo(p, jitter=1e-6)
+    engine.set_chunk(8192)
+    ed_b, kl_b, g_b = engine.elbo(p, jitter=1e-6)
+    assert abs(ed_a - ed_b) <= 1e-10 * abs(ed_a) and kl_a == kl_b
+    for k in g_a:
+        assert relerr(g_a[k], g_b[k]) <= 1e-7, k
+    rows = (41000, 43000)                                        # inside the second pass of the automatic rule
+    eds, _, gs = engine.elbo(p, jitter=1e-6, rows=rows, include_kl=False)
+    e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X[rows[0]:rows[1]], Y[rows[0]:rows[1]], p, 1e-6, include_kl=False, chunk=1000)
+    assert abs(eds - d_r) <= 1e-7 * abs(d_r)
+    for k in ot.PARAM_KEYS:
+        assert relerr(np.asarray(gs[k]).reshape(-1), np.asarray(g_r[k]).reshape(-1)) < max(1e-6, 1e-13 * c), k
+    engine.set_chunk(16384)
+
+
+@pytest.mark.parametrize('span', [600.0, 5000.0])
+def test_inducing_inputs_spanning_many_lengthscales(engine, span):
+    """A long 1-D input (a time series): M = 400 inducing points on a grid over `span` lengthscales.  k_kgrad takes its moment sums about
+    the MEAN inducing input and shifts them to z_m afterwards, which costs (|z_m - mean| / ell)^2 ulp in the Z / lengthscale gradients
+    (ADVICE r5): at a spread of 300 lengthscales that is ~2e-11 and stays the fast path; beyond 1e3 lengthscales from the mean (span 5000:
+    2500) the engine switches that latent to per-row differences (k_kgrad<D, true>), so the gradients keep the 1e-6 parity with the oracle
+    (autograd of KernSE.K's broadcast difference, onofftf/main.py:41-57) however long the input is."""
+    import zigp_oracle_torch as ot
+    rs = np.random.RandomState(17)
+    N, M = 3000, 400
+    X = np.sort(rs.rand(N, 1) * span, axis=0)
+    f = np.sin(X[:, 0] / 3.0)
+    Y = np.where(np.sin(X[:, 0] / 7.0) + 0.5 * rs.randn(N) > 0, f + 0.1 * rs.randn(N), 0.0)[:, None]
+    Z = (np.arange(M)[:, None] + 0.5) * (span / M)
+    p = dict(Zf=Z, Zg=Z + 0.25 * span / M, u_fm=0.3 * rs.randn(M, 1), u_gm=0.3 * rs.randn(M, 1), u_fs_sqrt=0.3 + rs.rand(M, 1),
+             u_gs_sqrt=0.3 + rs.rand(M, 1), ell_f=np.array([1.0]), ell_g=np.array([1.2]), var_f=1.0, var_g=5.0, noise=0.01)
+    engine.set_chunk(1024)
+    engine.set_data(X, Y)
+    ed, kl, g = engine.elbo(p, jitter=1e-6)
+    e_r, d_r, kl_r, g_r = ot.elbo_and_grad(X, Y, p, 1e-6, chunk=1000)
+    c = _cond(p, 1e-6)
+    assert abs(ed - d_r) <= 1e-7 * abs(d_r) and abs(kl - kl_r) <= 1e-8 * abs(kl_r)
+    for k in ot.PARAM_KEYS:
+        e = relerr(np.asarray(g[k]).reshape(-1), np.asarray(g_r[k]).reshape(-1))
+        print('  span %g ell: cond %.1e grad %-10s relerr %.2e' % (span, c, k, e))
+        assert e < max(1e-6, 1e-13 * c), (k, e)
+    engine.set_chunk(16384)

@@ -160,3 +160,49 @@ def test_mean_function_model_surface(engine):
     assert ml.mean_function.A.value.shape == (1, 1) and np.isfinite(ml.compute_log_likelihood())
     with pytest.raises(TypeError):
         mk(lambda x: 0 * x)
+
+
+def test_look_alikes_run_on_the_reference_cholesky_rule(tmp_path, monkeypatch):
+    """Results identical to the reference on the same inputs includes where it FAILS: tf.cholesky (onofftf/main.py:200,268,355) rejects a
+    non-positive pivot only, so the engines the look-alikes create (zigp.reference_engine: OnOffSVGP, onoff(), predict_onoff(), the
+    likelihood heads, kernels.RBF.compute_K) run with zigp_set_pivot_rtol(ctx, 0); the bare engine keeps its stricter 8 eps (variance +
+    jitter) guard as an option.  Two inducing points 2e-8 lengthscales apart, jitter 0: the second pivot is 1 - exp(-4e-16) ~ 4e-16 -- positive,
+    below 8 eps: accepted by the model's engine, ZIGP_ENOTPD (pivot index 2) on a bare one.  Exact duplicates (pivot 0) fail under both."""
+    import zigp
+    from zigp.engine import reference_engine
+    m, X, Y = _toy_model()
+    Z = np.array([[0.0], [2e-8], [1.0], [2.5], [4.0], [7.0]])
+    p = dict(Zf=Z, Zg=Z + 0.25, u_fm=np.zeros((6, 1)), u_gm=np.zeros((6, 1)), u_fs_sqrt=np.ones((6, 1)), u_gs_sqrt=np.ones((6, 1)),
+             ell_f=np.array([1.0]), ell_g=np.array([1.0]), var_f=1.0, var_g=1.0, noise=0.01)
+    eng = m._engine
+    eng.set_data(X, Y.reshape(-1))
+    ed, kl, _ = eng.elbo(p, jitter=0.0, need_grad=False)             # accepted, as tf.cholesky accepts it
+    assert np.isfinite(ed) and np.isfinite(kl)
+    bare = zigp.DenseEngine(0)
+    try:
+        bare.set_data(X, Y.reshape(-1))
+        with pytest.raises(zigp.NotPositiveDefiniteError):
+            bare.elbo(p, jitter=0.0, need_grad=False)
+        assert bare.lib.zigp_last_info(bare.ctx) == 2
+        bare.set_pivot_rtol(0.0)                                      # ... and the same engine under the reference's rule
+        assert bare.elbo(p, jitter=0.0, need_grad=False)[0] == ed
+    finally:
+        bare.close()
+    dup = dict(p, Zf=np.array([[0.0], [0.0], [1.0], [2.5], [4.0], [7.0]]))
+    with pytest.raises(zigp.NotPositiveDefiniteError):                # pivot exactly 0: "not positive definite" in the reference too
+        eng.elbo(dup, jitter=0.0, need_grad=False)
+    assert eng.lib.zigp_last_info(eng.ctx) == 2
+    m._resident = False                                               # the model's own data goes back in on its next call
+    # every look-alike that builds its own engine takes it from zigp.reference_engine
+    made = []
+    monkeypatch.setattr(zigp, 'reference_engine', lambda device=0: made.append(device) or reference_engine(device))
+    from onofftf import onoff, predict_onoff
+    d = np.load(os.path.join(GOLD, 'pptr.npz'))
+    Xtr, Ytr, Xte, Yte = d['Xtrain'][:3000].copy(), d['Ytrain'][:3000], d['Xtest'][:200].copy(), d['Ytest'][:200]
+    Xtr[:, 2] /= 1000.0
+    Xte[:, 2] /= 1000.0
+    onoff(Xtr, Ytr, Xte, Yte, str(tmp_path) + '/', num_iter=4, num_inducing_f=(6, 8), num_inducing_g=(6, 8), num_minibatch=500,
+          log_every=2, save_every=4, kmeans_seed=1)
+    predict_onoff(Xtr[:500], None, str(tmp_path) + '/', np.array([6, 8]), np.array([6, 8]))
+    m2, _, _ = _toy_model()
+    assert len(made) == 3 and m2._engine is not m._engine

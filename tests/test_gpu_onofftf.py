@@ -136,6 +136,7 @@ def test_device_fit_loop_at_the_pptr_init_and_failure_report(engine):
         engine.set_data(Xtr, Ytr)
         fit = KronDeviceFit(engine, psets[1])
         ed, kl = fit.steps(rows_seq[:n], batch, 1e-5, scale)
+        assert engine.lib.zigp_kron_fit_steps_applied(engine.ctx) == n and fit.t == n      # the library's own count of applied updates
         worst = max(float(np.max(np.abs(psets[1].params[k].value - psets[0].params[k].value)) / np.max(np.abs(psets[0].params[k].value))) for k in FIT_BLOCK_NAMES)
         eh = np.max(np.abs(np.stack([ed, kl], 1) - h_host) / np.abs(h_host))
         c_dev, c_host = -(ed - kl), -(h_host[:, 0] - h_host[:, 1])
@@ -155,3 +156,4 @@ def test_device_fit_loop_at_the_pptr_init_and_failure_report(engine):
         bad.steps(rows_seq[:5], batch, 0.0, scale)
     assert 'step 0' in str(ei.value) and np.array_equal(bad.x, x0) and bad.t == 0
     assert ei.value.steps_applied == 0 and ei.value.elbo_data.size == 0 and ei.value.kl.size == 0
+    assert engine.lib.zigp_kron_fit_steps_applied(engine.ctx) == 0

@@ -44,6 +44,7 @@ struct Latent {
   int M = 0, Mp = 0;
   DevBuf Z, ell, u, s, s2;              // Z (Mp,D) zero padded; u,s,s2 (Mp) zero padded
   double zc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // mean inducing input (host copy): centre of k_kgrad's moment sums
+  bool kg_exact = false;                     // inducing inputs spread over > KG_EXACT_SPREAD lengthscales: k_kgrad forms x - z_m per row (no centre shift)
   DevBuf Zs;                            // Z scaled by KUF_C / ell_d (k_kuf_build's units), same padding
   double var = 1.0;
   DevBuf Kuu, L, W;                      // (Mp,Mp)
@@ -96,6 +97,7 @@ struct zigp_ctx {
   hipEvent_t ev_prep_fork = nullptr, ev_prep = nullptr;
   std::string err;
   int info = 0;
+  int64_t fit_steps_applied = 0;       // zigp_kron_fit_steps: updates applied by the LAST call (all of them, or the ones before a failing step)
   int64_t chunk = 32768;
   bool chunk_auto = true;                // no zigp_set_chunk yet: the chunk follows M (32768 rows at M = 1024, more for smaller M)
   // data
@@ -109,6 +111,8 @@ struct zigp_ctx {
   zigp::Latent lat[2];
   zigp::DevBuf pw_part;                 // pointwise block partials
   // mean function of f, m(x) = mean_b + mean_a . x (zigp_set_mean_function), and its gradient from the last zigp_elbo
+  bool fwd_kuf_side = true;             // value-only / predict passes: the next chunk's Kuf panels on the side stream behind this chunk's A1 (env ZIGP_FWD_KUF_SIDE=0: off)
+  bool trmm_tail = true;                // merged triangular launches: re-deal the last, partly filled wave (tiles_trmm, zigp_host.h); env ZIGP_TRMM_TAIL=0 turns it off
   int overlap = 1;                      // zigp_set_overlap: 1 (default) = HBM-bound side kernels of a chunk on stream2 under its SYRKs
   bool mean_on = false;
   double mean_a[8] = {0}, mean_b = 0.0, mean_da[8] = {0}, mean_db = 0.0;   // 8 = zigp::MAXD (zigp_kernels.h)

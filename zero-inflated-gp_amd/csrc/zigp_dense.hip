@@ -20,6 +20,7 @@
 #include "zigp_comm.h"
 #include <algorithm>
 #include <cmath>
+#include <functional>
 
 using namespace zigp;
 
@@ -57,11 +58,15 @@ int latents_upload(zigp_ctx* c, const HostLatent (&hl)[2], int D) {
     memcpy(img + off[h][2], q.u, sizeof(double) * q.M);
     memcpy(img + off[h][3], q.s, sizeof(double) * q.M);
     const KufHyp kh = make_kuf_hyp(q.ell, q.var, D);
+    double spread = 0.0;
     for (int d = 0; d < MAXD; ++d) {      // centre of k_kgrad's moment sums: the mean inducing input
       double sum = 0.0;
       if (d < D) for (int m = 0; m < q.M; ++m) sum += q.Z[(size_t)m * D + d];
       c->lat[h].zc[d] = q.M > 0 ? sum / q.M : 0.0;
+      if (d < D) for (int m = 0; m < q.M; ++m) spread = std::max(spread, std::fabs(q.Z[(size_t)m * D + d] - c->lat[h].zc[d]) / q.ell[d]);
     }
+    // inducing inputs further than KG_EXACT_SPREAD lengthscales from their mean (or not finite): per-row differences instead of the shift
+    c->lat[h].kg_exact = !(spread <= KG_EXACT_SPREAD);
     for (int m = 0; m < q.M; ++m)
       for (int d = 0; d < D; ++d) img[off[h][4] + (size_t)m * D + d] = q.Z[(size_t)m * D + d] * kh.scale[d];
   }
@@ -175,16 +180,21 @@ int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, i
 // (run_gemm2: latent g's workgroups fill the tail of latent f's, three launch boundaries fewer per chunk; cfg3 -0.4 ... -0.8 % same-box,
 // profiles/r05l_ab_merge_fg.log, r05s_ab_milestones.log).  In the LPT regime the products stay per latent, in the order A1 A2 J' (f), A1 A2 J' (g) (merged there:
 // cfg2 +1.2 %), and so does the rank-N update everywhere (its 512-workgroup split-K plan fills the chip exactly; merged +0.2 %).
-int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad, const PwArgs* fuse_pw = nullptr, bool* fused = nullptr) {
+int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad, const PwArgs* fuse_pw = nullptr, bool* fused = nullptr, const std::function<int()>& after_a1 = nullptr) {
   const int nbn = (int)(Nc / BN);
   struct Set { TileList tl, tu, tf; double fl; GemmArgs a1, a2, j; EpiStoreColsum e1; EpiColsum e2; } q[2];
   const bool paired = trmm_paired_pays(nbn * ((c->lat[0].Mp / BM + 1) / 2 + (c->lat[1].Mp / BM + 1) / 2)), merge = paired;
+  // merged launch = [latent f's units | padding to a multiple of 8 | latent g's units]: a last wave that is not full is re-dealt inside
+  // latent g's list (tiles_trmm: LPT tail)
+  TrmmTail tail = {{0, 0}, {64, 64}};
+  if (merge && c->trmm_tail)
+    tail = trmm_tail_plan(((nbn + 7) / 8) * 8 * ((c->lat[0].Mp / BM + 1) / 2), c->lat[0].Mp / BM, ((nbn + 7) / 8) * 8 * ((c->lat[1].Mp / BM + 1) / 2), c->lat[1].Mp / BM);
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
     const int Mp = lt.Mp, nbm = Mp / BM;
     const int np = Mp / 32;   // allocated partial rows per fused column sum (a kernel writes one per wave tile: 64 or 32 rows)
-    ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, q[h].tl, paired));
-    ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, q[h].tu, paired));
+    ZIGP_TRY(tiles_trmm_lower(c, nbm, nbn, q[h].tl, paired, tail.units[h], tail.bins[h]));
+    ZIGP_TRY(tiles_trmm_upper(c, nbm, nbn, q[h].tu, paired, tail.units[h], tail.bins[h]));
     if (need_grad) ZIGP_TRY(tiles_full_xcd(c, nbm, nbn, nbm * (BM / BK), q[h].tf));
     q[h].fl = (double)lt.M * lt.M * (double)Nc;
     // A1 = W K ; partial column sums  v^T A1 (= mean, since A2^T u = A1^T W u)  and  sum A1^2
@@ -205,6 +215,7 @@ int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad, const PwArgs* fuse_pw
       ProfScope ps(c, PC_GEMM_A1, q[0].fl + q[1].fl);
       ZIGP_TRY((run_gemm2<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, q[0].tl, q[0].a1, q[0].e1, q[1].tl, q[1].a1, q[1].e1)));
     }
+    if (after_a1) ZIGP_TRY(after_a1());     // the Kuf panels have had their only reader of a value-only / predict pass
     {
       ProfScope ps(c, PC_GEMM_A2, q[0].fl + q[1].fl);
       ZIGP_TRY((run_gemm2<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, q[0].tu, q[0].a2, q[0].e2, q[1].tu, q[1].a2, q[1].e2)));
@@ -224,6 +235,7 @@ int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad, const PwArgs* fuse_pw
       ProfScope ps(c, PC_GEMM_A1, q[h].fl);
       ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_LOWER>(c, q[h].tl, q[h].a1, q[h].e1)));
     }
+    if (h == 1 && after_a1) ZIGP_TRY(after_a1());
     {
       ProfScope ps(c, PC_GEMM_A2, q[h].fl);
       ZIGP_TRY((run_gemm<LAY_MNCONTIG, LAY_MNCONTIG, false, TRI_A_UPPER>(c, q[h].tu, q[h].a2, q[h].e2)));
@@ -248,8 +260,12 @@ int latent_chunk_kgrad(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows,
     const int64_t slab = (int64_t)Mp * (2 + 2 * D);
 #define ZIGP_KGRAD(DD)                                                                                                            \
   case DD:                                                                                                                        \
-    hipLaunchKernelGGL(k_kgrad<DD>, gk, bk, 0, c->stream, lt.Jp.p, lt.K.p, alpha, lt.gm.p, lt.gv.p, dX, Nrows, n0, lt.Z.p, lt.M, Nc, \
-                       slab, hyp, lt.krow.p);                                                                                                \
+    if (lt.kg_exact)                                                                                                              \
+      hipLaunchKernelGGL((k_kgrad<DD, true>), gk, bk, 0, c->stream, lt.Jp.p, lt.K.p, alpha, lt.gm.p, lt.gv.p, dX, Nrows, n0, lt.Z.p, lt.M, Nc, \
+                         slab, hyp, lt.krow.p);                                                                                   \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((k_kgrad<DD, false>), gk, bk, 0, c->stream, lt.Jp.p, lt.K.p, alpha, lt.gm.p, lt.gv.p, dX, Nrows, n0, lt.Z.p, lt.M, Nc, \
+                         slab, hyp, lt.krow.p);                                                                                   \
     break;
     switch (D) {
       ZIGP_KGRAD(1) ZIGP_KGRAD(2) ZIGP_KGRAD(3) ZIGP_KGRAD(4) ZIGP_KGRAD(5) ZIGP_KGRAD(6) ZIGP_KGRAD(7) ZIGP_KGRAD(8)
@@ -522,7 +538,25 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
     // profiles/r05t_ab_fuse_pointwise.log); timed chunks and overlap 0 keep every kernel on its own, as for the side stream
     bool pw_fused = false;
     const PwArgs pwa = dense_pointwise_args(c, k, n0, Nc);
-    ZIGP_TRY(chunk_forward(c, Nc, k.need_grad, (c->overlap == 1 && k.need_grad && !k.predict && !timed) ? &pwa : nullptr, &pw_fused));
+    // value-only ELBO and predict (r6): there are no rank-N updates to hide the next chunk's Kuf panels under, but K has ONE reader there
+    // -- A1 -- so the side stream builds the next panels right behind this chunk's A1, beside its A2 product and point-wise stage
+    // (cfg3 value-only: the 4 ms of panel building per pass were serial on the main stream)
+    const bool kuf_fwd_side = c->overlap == 1 && c->fwd_kuf_side && !k.need_grad && has_next && !timed && !timed_next;
+    std::function<int()> after_a1;
+    if (kuf_fwd_side)
+      after_a1 = [&]() -> int {
+        ZIGP_HIP(c, hipEventRecord(c->ev_fork, c->stream_main));
+        ZIGP_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        c->stream = c->stream2;
+        int rc = 0;
+        for (int h = 0; h < 2 && !rc; ++h) rc = latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]);
+        c->stream = c->stream_main;
+        if (rc) return rc;
+        ZIGP_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+        side_busy = true;
+        return 0;
+      };
+    ZIGP_TRY(chunk_forward(c, Nc, k.need_grad, (c->overlap == 1 && k.need_grad && !k.predict && !timed) ? &pwa : nullptr, &pw_fused, after_a1));
     if (!pw_fused) ZIGP_TRY(dense_pointwise(c, k, n0, Nc));
     // side work of this chunk: its kgrads and the next chunk's Kuf panels (gradient mode only: without the SYRKs there is
     // nothing on the main stream to hide them under)
@@ -545,7 +579,7 @@ int dense_chunk_loop(zigp_ctx* c, const DenseCall& k) {
         for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kgrad(c, c->lat[h], k.dX, k.Nrows, n0, Nc, D, k.ell_h[h]));
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_syrk(c, c->lat[h], Nc));
     }
-    if (has_next && !kuf_side) {   // a timed next chunk gets its panels from the main stream, with the side stream drained
+    if (has_next && !kuf_side && !kuf_fwd_side) {   // a timed next chunk gets its panels from the main stream, with the side stream drained
       if (side_busy) { ZIGP_HIP(c, hipStreamWaitEvent(c->stream_main, c->ev_join, 0)); side_busy = false; }
       c->prof_skip = c->prof_on && !timed_next;
       for (int h = 0; h < 2; ++h) ZIGP_TRY(latent_chunk_kuf(c, c->lat[h], k.dX, k.Nrows, n1, chunk_rows(n1), D, k.ell_h[h]));
@@ -662,6 +696,8 @@ int zigp_create(zigp_ctx** out, int device_id) {
   if (hipMalloc((void**)&c->d_info, sizeof(int)) != hipSuccess) { delete c; return ZIGP_EHIP; }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(sizeof(double) * PB * PBLD)) != hipSuccess) { delete c; return ZIGP_EHIP; }
+  if (const char* e = getenv("ZIGP_FWD_KUF_SIDE")) c->fwd_kuf_side = atoi(e) != 0;   // A/B switch (tools/ab_envs.sh); default on
+  if (const char* e = getenv("ZIGP_TRMM_TAIL")) c->trmm_tail = atoi(e) != 0;      // A/B switch of the LPT tail (tools/ab_envs.sh); default on
   if (const char* e = getenv("ZIGP_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0) c->comm_timeout_s = v; }
   *out = c;
   return ZIGP_OK;
@@ -711,7 +747,8 @@ int zigp_set_overlap(zigp_ctx* c, int32_t on) {
 
 int zigp_set_chunk(zigp_ctx* c, int64_t chunk_rows) {
   if (!c) return ZIGP_EARG;
-  if (chunk_rows < 1024 || chunk_rows % 1024 != 0) return fail_arg(c, "chunk must be a positive multiple of 1024");
+  if (chunk_rows == 0) { c->chunk_auto = true; c->chunk = 32768; return ZIGP_OK; }   // back to the automatic rule
+  if (chunk_rows < 1024 || chunk_rows % 1024 != 0) return fail_arg(c, "chunk must be a positive multiple of 1024 (or 0: automatic)");
   if (chunk_rows > (1 << 20)) return fail_arg(c, "chunk must be <= 1048576 rows (32-bit staging offsets; 5 panels of 8*M*chunk bytes per latent)");
   c->chunk = chunk_rows;
   c->chunk_auto = false;

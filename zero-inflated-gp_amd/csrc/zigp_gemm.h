@@ -243,6 +243,16 @@ template <int OFF> __device__ __forceinline__ double ds_rd64(uint32_t a) {    //
   double v; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF)); return v;
 }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// The counted wait of the pipelined reads, TIED to the fragments it releases: the registers written by the ds_read_b64 blocks above are
+// read-write operands of the wait, so every use of them -- the MFMAs are builtins with no other dependence on an asm block -- is ordered
+// behind it by data flow, whatever a later compiler's scheduler or register allocator would like to do with a pure s_waitcnt
+// (the instruction stream is unchanged: same registers in, same registers out).
+template <int N> __device__ __forceinline__ void wait_lgkm_for(double& a, double (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_lgkm_for(double& a0, double& a1, double (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a0), "+v"(a1), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr(const double* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)p; }
 
 // TRI: triangular structure exploited at wave granularity inside diagonal blocks.
@@ -461,7 +471,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const GemmTile& tl,
       load(IC<0>{}, IC<0>{});
       sfor<0, BK / 4>([&](auto ks_) {
         constexpr int ks = decltype(ks_)::value;
-        if constexpr (ks + 1 < BK / 4) { load(IC<ks + 1>{}, IC<(ks + 1) & 1>{}); wait_lgkm<NRD>(); } else wait_lgkm<0>();
+        static_assert(TNW == 4, "wait_lgkm_for ties four B fragments");
+        auto wait_set = [&](auto n_) {      // wait until at most n_ reads are outstanding: the fragment set ks & 1 has landed
+          constexpr int n = decltype(n_)::value;
+          if constexpr (MASK == 3) wait_lgkm_for<n>(af[ks & 1][0], af[ks & 1][1], bf[ks & 1]);
+          else if constexpr (MASK == 1) wait_lgkm_for<n>(af[ks & 1][0], bf[ks & 1]);
+          else wait_lgkm_for<n>(af[ks & 1][1], bf[ks & 1]);
+        };
+        if constexpr (ks + 1 < BK / 4) { load(IC<ks + 1>{}, IC<(ks + 1) & 1>{}); wait_set(IC<NRD>{}); } else wait_set(IC<0>{});
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tm = 0; tm < TMW; ++tm)

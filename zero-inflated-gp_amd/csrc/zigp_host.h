@@ -143,36 +143,92 @@ static inline GemmArgs mk_args(const double* A, int64_t lda, const double* B, in
 //   r3, same-box A/B on the 8-wave kernels (profiles/r03p_ab_paired.log): A1 / A2 / H at the LPT rate (60.4 / 60.4 / 61.1 vs 60.5 / 59.9 /
 //   61.1 TF), J' -3 % (its epilogue loads an A2 tile: with equal-length units all epilogues of a wave of workgroups coincide) -- so
 //   A1, A2 and H take the paired order and J' stays LPT.  (Round 1 had the 4-wave kernels 1-2 % slower in every paired variant.)
-static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, bool paired, TileList& tl) {
+// r6 -- the TAIL of a paired launch.  Units of equal length run in lockstep waves of the 512 resident workgroups, so a launch of
+// W + r units (0 < r < 512) costs ceil as many wave times as if the last wave were full: cfg2 (3136 units of 5 k blocks = 6.125 waves)
+// paid 7 x 5 = 35 block steps for 30.6 of work.  With tail_units = T > 0 the LAST T units of the launch order (T / 8 per XCD queue;
+// the caller passes r + 512) are taken apart into their 2 T tiles and dealt, longest first, onto the 64 workgroup slots of their XCD
+// (longest-processing-time rule; a workgroup then runs up to `per` = 3-4 list entries): the two last waves of cfg2 become one of
+// makespan 6 instead of 2 x 5.  Inside the tail the tiles of a panel no longer walk k in lockstep (its B slabs are fetched more than
+// once: HBM is not what bounds these products); everything in front of it is the paired order unchanged.
+static inline int trmm_tail_makespan(int nbm, int tail_units_per_xcd, int bins) {      // LPT makespan (k blocks) of one XCD's tail
+  std::vector<int> len;
+  const int U = (nbm + 1) / 2;
+  for (int i = 0; i < tail_units_per_xcd; ++i) {       // unit u of a panel = tiles of u + 1 and nbm - u k blocks (the middle one alone when nbm is odd)
+    const int u = i % U, lo = u + 1, hi = nbm - u;
+    len.push_back(hi);
+    if (lo != hi) len.push_back(lo);
+  }
+  std::sort(len.begin(), len.end(), [](int a, int b) { return a > b; });
+  std::vector<int> load(bins, 0);
+  for (int l : len) *std::min_element(load.begin(), load.end()) += l;
+  return *std::max_element(load.begin(), load.end());
+}
+static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, bool paired, TileList& tl, int tail_units = 0, int tail_bins = 64) {
   const int kb = BM / BK;
-  const std::string key = std::string(lower ? "trl:" : "tru:") + std::to_string(nbm) + ":" + std::to_string(nbn) + (paired ? ":p" : ":l");
+  const std::string key = std::string(lower ? "trl:" : "tru:") + std::to_string(nbm) + ":" + std::to_string(nbn) + (paired ? ":p" : ":l") +
+                          (tail_units > 0 ? ":t" + std::to_string(tail_units) + ":" + std::to_string(tail_bins) : std::string());
   if (!paired)
     return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
       if (lower) { for (int bi = nbm - 1; bi >= 0; --bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, (bi + 1) * kb)); }
       else { for (int bi = 0; bi < nbm; ++bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * kb, nbm * kb)); }
     }, tl, 1);
-  return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
-    const int U = (nbm + 1) / 2;
-    auto tile = [&](int bi, int bj, int dir) {
-      GemmTile t = lower ? mk_tile(bi, bj, 0, (bi + 1) * kb) : mk_tile(bi, bj, bi * kb, nbm * kb);
-      t.kdir = dir;
-      return t;
-    };
-    std::vector<GemmTile> q[8];   // per-XCD queues of units (2 entries each)
-    for (int bj = 0; bj < nbn; ++bj)
-      for (int u = 0; u < U; ++u) {
-        const int lo = u, hi = nbm - 1 - u;                 // lo has the short k range for lower, hi for upper
-        std::vector<GemmTile>& dst = q[bj % 8];
-        if (lo == hi) { dst.push_back(tile(lo, bj, lower ? -1 : 1)); dst.push_back(mk_tile(0, 0, 0, 0)); continue; }
-        if (lower) { dst.push_back(tile(lo, bj, 1)); dst.push_back(tile(hi, bj, -1)); }
-        else { dst.push_back(tile(hi, bj, -1)); dst.push_back(tile(lo, bj, 1)); }
+  // per-XCD queues of units (2 entries each); a tail is re-dealt per queue into <= 64 workgroups of up to `per` entries
+  const int U = (nbm + 1) / 2;
+  auto tile = [&](int bi, int bj, int dir) {
+    GemmTile t = lower ? mk_tile(bi, bj, 0, (bi + 1) * kb) : mk_tile(bi, bj, bi * kb, nbm * kb);
+    t.kdir = dir;
+    return t;
+  };
+  std::vector<GemmTile> q[8];
+  for (int bj = 0; bj < nbn; ++bj)
+    for (int u = 0; u < U; ++u) {
+      const int lo = u, hi = nbm - 1 - u;                 // lo has the short k range for lower, hi for upper
+      std::vector<GemmTile>& dst = q[bj % 8];
+      if (lo == hi) { dst.push_back(tile(lo, bj, lower ? -1 : 1)); dst.push_back(mk_tile(0, 0, 0, 0)); continue; }
+      if (lower) { dst.push_back(tile(lo, bj, 1)); dst.push_back(tile(hi, bj, -1)); }
+      else { dst.push_back(tile(hi, bj, -1)); dst.push_back(tile(lo, bj, 1)); }
+    }
+  size_t longest = 0;
+  for (int x = 0; x < 8; ++x) longest = std::max(longest, q[x].size());
+  int per = 2;
+  std::vector<std::vector<GemmTile>> bins[8];      // the re-dealt tail of each queue
+  const int tu = std::min<int>(tail_units / 8, (int)(longest / 2));
+  if (tu > 0) {
+    const int BINS = std::max(1, std::min(64, tail_bins));   // of the 64 resident workgroups per XCD, the share of this list's tail
+    for (int x = 0; x < 8; ++x) {
+      // the queue's units at launch-order positions >= longest / 2 - tu (shorter queues -- nbn not a multiple of 8 -- end in padding there)
+      const size_t first = std::min(q[x].size(), (longest / 2 - (size_t)tu) * 2);
+      std::vector<GemmTile> t(q[x].begin() + first, q[x].end());
+      q[x].resize(first);
+      t.erase(std::remove_if(t.begin(), t.end(), [](const GemmTile& a) { return a.kend <= a.kbeg; }), t.end());
+      std::stable_sort(t.begin(), t.end(), [](const GemmTile& a, const GemmTile& b) { return a.kend - a.kbeg > b.kend - b.kbeg; });
+      bins[x].assign(std::min<size_t>((size_t)BINS, t.size()), std::vector<GemmTile>());
+      std::vector<int> load(bins[x].size(), 0);
+      for (const GemmTile& a : t) {
+        const size_t b = std::min_element(load.begin(), load.end()) - load.begin();
+        bins[x][b].push_back(a);
+        load[b] += a.kend - a.kbeg;
       }
-    size_t longest = 0;
-    for (int x = 0; x < 8; ++x) longest = std::max(longest, q[x].size());
-    for (size_t e0 = 0; e0 < longest; e0 += 2)               // launch position p = 8 * (e0 / 2) + x  ->  XCD x
+      // longest workgroups first in the dispatch order
+      std::vector<size_t> order(bins[x].size());
+      for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return load[a] > load[b]; });
+      std::vector<std::vector<GemmTile>> sorted;
+      for (size_t i : order) sorted.push_back(bins[x][i]);
+      bins[x] = sorted;
+      for (const auto& b : bins[x]) per = std::max(per, (int)b.size());
+    }
+  }
+  return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
+    size_t reg = 0, nb = 0;
+    for (int x = 0; x < 8; ++x) { reg = std::max(reg, q[x].size() / 2); nb = std::max(nb, bins[x].size()); }
+    for (size_t i = 0; i < reg; ++i)                         // launch position p = 8 * i + x  ->  XCD x
       for (int x = 0; x < 8; ++x)
-        for (int e = 0; e < 2; ++e) v.push_back(e0 + e < q[x].size() ? q[x][e0 + e] : mk_tile(0, 0, 0, 0));
-  }, tl, 2);
+        for (int e = 0; e < per; ++e) v.push_back(e < 2 && 2 * i + e < q[x].size() ? q[x][2 * i + e] : mk_tile(0, 0, 0, 0));
+    for (size_t i = 0; i < nb; ++i)
+      for (int x = 0; x < 8; ++x)
+        for (int e = 0; e < per; ++e) v.push_back(i < bins[x].size() && e < (int)bins[x][i].size() ? bins[x][i][e] : mk_tile(0, 0, 0, 0));
+  }, tl, per);
 }
 // The paired order has nbn * ceil(nbm / 2) units of EQUAL length per latent: it pays (2.2x fewer bytes, +6 % on the triangular
 // products) where the units of BOTH latents, launched together (run_gemm2), fill whole waves of the 512 resident workgroups --
@@ -183,8 +239,29 @@ static inline bool trmm_paired_pays(int units_both_latents) {
   const int slots = 512, waves = (units_both_latents + slots - 1) / slots;
   return units_both_latents >= slots && (double)units_both_latents / ((double)waves * slots) >= 0.85;
 }
-static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired) { return tiles_trmm(c, true, nbm, nbn, paired, tl); }
-static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired) { return tiles_trmm(c, false, nbm, nbn, paired, tl); }
+static int tiles_trmm_lower(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired, int tail_units = 0, int tail_bins = 64) { return tiles_trmm(c, true, nbm, nbn, paired, tl, tail_units, tail_bins); }
+static int tiles_trmm_upper(zigp_ctx* c, int nbm, int nbn, TileList& tl, bool paired, int tail_units = 0, int tail_bins = 64) { return tiles_trmm(c, false, nbm, nbn, paired, tl, tail_units, tail_bins); }
+// Tail plan of a merged launch [set 0's units | set 1's units] (unit counts multiples of 8, nbm + 1 k blocks per unit) over 512 slots:
+// with a remainder r the last r + 512 units -- the end of set 1 and, where set 1 is shorter than that, the end of set 0 as well -- become
+// ONE wave of 512 LPT workgroups (64 per XCD, shared between the two sets in proportion to their tails' work) whenever that wave is
+// shorter than the two it replaces.  All zeros: leave the lists as they are.
+struct TrmmTail { int units[2], bins[2]; };
+static inline TrmmTail trmm_tail_plan(int units0, int nbm0, int units1, int nbm1) {
+  TrmmTail none = {{0, 0}, {64, 64}}, t = none;
+  const int slots = 512, total = units0 + units1, r = total % slots;
+  if (r == 0 || total <= slots) return none;
+  const int T = r + slots;
+  t.units[1] = std::min(T, units1);
+  t.units[0] = T - t.units[1];
+  if (t.units[0] > units0 || t.units[0] % 8 || t.units[1] % 8) return none;
+  const double w0 = (double)t.units[0] * (nbm0 + 1), w1 = (double)t.units[1] * (nbm1 + 1);
+  t.bins[1] = t.units[0] == 0 ? 64 : std::max(1, std::min(63, (int)std::lround(64.0 * w1 / (w0 + w1))));
+  t.bins[0] = 64 - t.bins[1];
+  int after = t.units[1] ? trmm_tail_makespan(nbm1, t.units[1] / 8, t.bins[1]) : 0;
+  if (t.units[0]) after = std::max(after, trmm_tail_makespan(nbm0, t.units[0] / 8, t.bins[0]));
+  const int before = (nbm1 + 1) + (t.units[0] ? nbm0 + 1 : nbm1 + 1);       // the two lockstep waves the tail replaces
+  return after < before ? t : none;
+}
 // Split-K plan of the symmetric rank-N update.  Off-diagonal tiles are cut into So slices, diagonal tiles (the balanced lower-triangle
 // path of zigp_gemm.h: 36 of 64 sub-tile products per slice, two slices per barrier -- ~0.6 of a full tile's time) into Sd = So / 2
 // slices of twice the length, So a multiple of 16: the k range then falls into 8 windows, one per XCD, each holding So / 8 slices of

@@ -332,8 +332,12 @@ constexpr int KG_SPLIT = 4;   // column splits (blockIdx.y); each split accumula
 // VALU instructions per element at D = 3, and this kernel runs beside the MFMA-bound rank-N updates, where every VALU instruction is
 // paid in matrix-pipe time (k_kuf_build above; cfg3 -0.3 % same-box, profiles/r05s_ab_milestones.log).  The shift costs (|dz| / ell)^2 ulp of cancellation -- the spread of the inducing
 // inputs in lengthscales, not of the data's offset from the origin.
+// EXACT (round 6): the differences x - z_m are formed per row and nothing is shifted afterwards -- the 17-instruction form of
+// round 4.  The host selects it for a latent whose inducing inputs lie more than KG_EXACT_SPREAD lengthscales from their mean in some
+// dimension (a long 1-D / time-series input: (1e3)^2 ulp = 2e-10 is where the centred form starts to show next to the 1e-6 parity bar).
+constexpr double KG_EXACT_SPREAD = 1.0e3;
 struct KgCentre { double c[MAXD]; };
-template <int D>
+template <int D, bool EXACT>
 __global__ void __launch_bounds__(256)
 k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const double* __restrict__ alpha,
         const double* __restrict__ gm, const double* __restrict__ gv, const double* __restrict__ X, int64_t N, int64_t n0,
@@ -344,10 +348,14 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
   krow += (int64_t)blockIdx.y * slab;
   const int m0 = blockIdx.x * KG_ROWS;
   if (m0 >= M) return;
-  double am[KG_ROWS], acc[KG_ROWS][W];
+  double am[KG_ROWS], acc[KG_ROWS][W], zr[KG_ROWS][EXACT ? D : 1];
 #pragma unroll
   for (int r = 0; r < KG_ROWS; ++r) {
     am[r] = alpha[min(m0 + r, M - 1)];
+    if (EXACT) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) zr[r][d] = Z[min(m0 + r, M - 1) * D + d];
+    }
 #pragma unroll
     for (int q = 0; q < W; ++q) acc[r][q] = 0.0;
   }
@@ -357,7 +365,10 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
     const double gmn = gm[n], gv2 = 2.0 * gv[n];
     double xc[D], xx[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) { xc[d] = X[(n0 + n) * D + d] - ctr.c[d]; xx[d] = xc[d] * xc[d]; }
+    for (int d = 0; d < D; ++d) {
+      if (EXACT) { xc[d] = X[(n0 + n) * D + d]; xx[d] = 0.0; }
+      else { xc[d] = X[(n0 + n) * D + d] - ctr.c[d]; xx[d] = xc[d] * xc[d]; }
+    }
 #pragma unroll
     for (int r = 0; r < KG_ROWS; ++r) {
       const int64_t o = (int64_t)(m0 + r) * Nc + n;     // rows beyond M are zero-padded panels (inside the allocation)
@@ -367,8 +378,14 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
       acc[r][1 + 2 * D] = fma(kk, gmn, acc[r][1 + 2 * D]);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        acc[r][1 + d] = fma(t, xc[d], acc[r][1 + d]);
-        acc[r][1 + D + d] = fma(t, xx[d], acc[r][1 + D + d]);
+        if (EXACT) {
+          const double df = xc[d] - zr[r][d], td = t * df;
+          acc[r][1 + d] += td;
+          acc[r][1 + D + d] = fma(td, df, acc[r][1 + D + d]);
+        } else {
+          acc[r][1 + d] = fma(t, xc[d], acc[r][1 + d]);
+          acc[r][1 + D + d] = fma(t, xx[d], acc[r][1 + D + d]);
+        }
       }
     }
   }
@@ -388,7 +405,7 @@ k_kgrad(const double* __restrict__ Jp, const double* __restrict__ K, const doubl
     if (m0 + r < M) {
       const double* S = tot + r * W;
       double v = S[q];
-      if (q >= 1 && q <= 2 * D) {      // moments about c -> about z_m
+      if (!EXACT && q >= 1 && q <= 2 * D) {      // moments about c -> about z_m
         const int d = (q - 1) % D;
         const double dz = Z[(m0 + r) * D + d] - ctr.c[d];
         v = (q <= D) ? fma(-dz, S[0], S[1 + d]) : fma(dz, fma(dz, S[0], -2.0 * S[1 + d]), S[1 + D + d]);

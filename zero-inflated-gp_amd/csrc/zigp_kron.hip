@@ -814,6 +814,7 @@ int zigp_kron_fit_steps(zigp_ctx* c, const zigp_kron_params* p, const zigp_kron_
                         int64_t n_free, int64_t t0, int32_t n_steps, const int64_t* row_begin, int64_t batch, const double* Xw, const double* Yw,
                         double jitter, double scale, int32_t include_kl, double* elbo_data, double* kl) {
   if (!c) return ZIGP_EARG;
+  c->fit_steps_applied = 0;      // whatever ends this call early, no update of it has been applied
   if (!p || !opts || !free_state || !adam_m || !adam_v || !row_begin) return fail_arg(c, "zigp_kron_fit_steps: NULL argument");
   if (p->M0f <= 0 || p->M1f <= 0 || p->M0g <= 0 || p->M1g <= 0) return fail_arg(c, "inducing counts must be positive");
   if (p->D0 <= 0 || p->D1 <= 0 || p->D0 > MAXD || p->D1 > MAXD) return fail_arg(c, "factor dimensions must be in [1, 8]");
@@ -832,6 +833,8 @@ int zigp_kron_fit_steps(zigp_ctx* c, const zigp_kron_params* p, const zigp_kron_
   KfFitCall fit = {opts, free_state, adam_m, adam_v, n_free, t0, (int)n_steps, row_begin, batch, Xw, Yw, elbo_data, kl};
   return kronf_run(c, p, c->dX, c->dY, batch, jitter, scale, 0.0, 0.0, include_kl, false, nullptr, nullptr, nullptr, nullptr, ZIGP_LIK_ONOFF, nullptr, true, &fit);
 }
+
+int64_t zigp_kron_fit_steps_applied(zigp_ctx* c) { return c ? c->fit_steps_applied : (int64_t)ZIGP_EARG; }
 
 int zigp_kron_predict(zigp_ctx* c, const zigp_kron_params* p, const double* Xnew, int64_t N, double jitter, double g_offset, double f_mu, double* out9) {
   if (!c) return ZIGP_EARG;

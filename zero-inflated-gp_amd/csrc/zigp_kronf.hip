@@ -1718,6 +1718,7 @@ static int kronf_run(zigp_ctx* c, const zigp_kron_params* p, const double* X, co
     const int* hfail = reinterpret_cast<const int*>(hst + 3 * nf + n_hist);
     memcpy(fit->x, hst, sizeof(double) * nf); memcpy(fit->m, hst + nf, sizeof(double) * nf); memcpy(fit->v, hst + 2 * nf, sizeof(double) * nf);
     const int done = hfail[0] ? hfail[0] - 1 : fit->n_steps;       // steps whose update was applied
+    c->fit_steps_applied = done;                                   // (zigp_kron_fit_steps_applied: the caller's iteration count advances by this)
     for (int i = 0; i < fit->n_steps; ++i) {
       if (fit->hist_data) fit->hist_data[i] = i < done ? hst[3 * nf + 2 * i] : NAN;
       if (fit->hist_kl) fit->hist_kl[i] = i < done ? hst[3 * nf + 2 * i + 1] : NAN;

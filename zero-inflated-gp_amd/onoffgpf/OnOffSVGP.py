@@ -46,7 +46,7 @@ class OnOffSVGP(Parameterized):
         self.u_fs_sqrt = Param(np.ones((self.num_inducing_f, self.num_latent)), positive)  # :60-61
         self.u_gs_sqrt = Param(np.ones((self.num_inducing_g, self.num_latent)), positive)  # :62-63
         self._device = int(device)
-        self._engine = zigp.DenseEngine(self._device)      # raises if libzigp.so / GPU is missing: no CPU fallback
+        self._engine = zigp.reference_engine(self._device)  # raises if libzigp.so / GPU is missing: no CPU fallback; tf.cholesky's pivot rule
         self._resident = False
 
     # ---- parameter plumbing -----------------------------------------------------------------
@@ -155,7 +155,7 @@ class OnOffSVGP(Parameterized):
     def __setstate__(self, d):
         self.__dict__.update(d)
         self.__dict__.setdefault('mean_function', Zero())
-        self.__dict__['_engine'] = zigp.DenseEngine(self.__dict__.setdefault('_device', 0))   # the device it was fitted on
+        self.__dict__['_engine'] = zigp.reference_engine(self.__dict__.setdefault('_device', 0))   # the device it was fitted on
 
     @staticmethod
     def ProbitExpectations(gmean, gvar):

@@ -11,7 +11,7 @@ def _get_engine():
     global _engine
     if _engine is None:
         import zigp
-        _engine = zigp.DenseEngine(0)
+        _engine = zigp.reference_engine(0)
     return _engine
 
 

@@ -126,7 +126,7 @@ def restore_and_predict(lik, Xtrain, Xtest, checkpointPath, num_inducing_f, incl
                             include_f_mu=include_f_mu, kern_lr=1e-4, indp_lr=1e-4)
     ck = os.path.join(checkpointPath, 'model') if os.path.isdir(checkpointPath) else checkpointPath
     load_checkpoint(pset, ck)
-    eng = engine or zigp.DenseEngine(device)
+    eng = engine or zigp.reference_engine(device)      # tf.cholesky's acceptance rule (pivot > 0)
     p, f_mu = head_engine_params(pset), head_f_mu(pset)
 
     def run(X):

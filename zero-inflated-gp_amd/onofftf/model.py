@@ -117,12 +117,19 @@ class KronDeviceFit:
 
     def _stale(self):
         """did anyone else write the ParamSet since sync_params? (cheap: ~20 small arrays against the copies kept there)"""
-        return any(not np.array_equal(self.pset.params[k].value, w) for k, w in zip(FIT_BLOCK_NAMES, self._written))
+        # equal_nan: a parameter that HAS gone NaN (a diverged step) is still the value this object wrote -- NaN != NaN must not turn every
+        # later call into a resync from free(NaN)
+        return any(not np.array_equal(self.pset.params[k].value, w, equal_nan=True) for k, w in zip(FIT_BLOCK_NAMES, self._written))
 
-    def resync(self):
-        """Take the free state from the ParamSet again (after load_checkpoint or a manual assignment); Adam's moments and the iteration
-        count are kept -- reset them by making a new KronDeviceFit if the parameters are unrelated to the ones trained so far."""
+    def resync(self, reset=False):
+        """Take the free state from the ParamSet again (after load_checkpoint or a manual assignment).  Adam's moments and the iteration
+        count are kept -- right for a nudged or restored-and-continued fit; reset=True zeroes them (t = 0), for parameters that are
+        unrelated to the ones trained so far (load_checkpoint(..., fitter=...) of another run)."""
         self.x = np.concatenate([self.pset.params[k].free() for k in FIT_BLOCK_NAMES])
+        if reset:
+            self.m[:] = 0.0
+            self.v[:] = 0.0
+            self.t = 0
         self._written = [self.pset.params[k].value.copy() for k in FIT_BLOCK_NAMES]
 
     def sync_params(self):
@@ -138,8 +145,14 @@ def save_checkpoint(pset, path):
     return path if str(path).endswith('.npz') else str(path) + '.npz'
 
 
-def load_checkpoint(pset, path):
+def load_checkpoint(pset, path, fitter=None, reset=True):
+    """Restore the ParamSet from the .npz written by save_checkpoint.  fitter: a KronDeviceFit / zigp.optim.AdamGroups stepping this
+    ParamSet -- it takes the loaded values as its state at once and, with reset=True (the default: a checkpoint holds parameters, not
+    Adam moments -- tf.train.Saver restores them only if they were saved, onofftf/utils.py:61-73 saves all variables of the graph; ours
+    does not keep them), restarts its moments and iteration count instead of carrying those of the parameters it replaced."""
     path = path if str(path).endswith('.npz') else str(path) + '.npz'
     d = np.load(path)
     for k, q in pset.params.items():
         q.value = np.asarray(d[k.replace('/', '__')], dtype=np.float64).reshape(q.value.shape)
+    if fitter is not None:
+        fitter.resync(reset=reset)

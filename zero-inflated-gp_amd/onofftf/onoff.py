@@ -64,7 +64,7 @@ def onoff(Xtrain, Ytrain, Xtest, Ytest, dir, num_iter=50000, num_inducing_f=(10,
     train_data = DataSet(Xtrain, Ytrain)                                             # :43
     num_data = Xtrain.shape[0]                                                       # :54
     pset = init_params(Xtrain, num_inducing_f, num_inducing_g, init_noisevar=0.01, kmeans_seed=kmeans_seed)   # :51-137
-    eng = engine or zigp.DenseEngine(device)
+    eng = engine or zigp.reference_engine(device)      # tf.cholesky's acceptance rule (pivot > 0)
     scale = float(num_data) / float(num_minibatch)                                   # :311
     logger.info('*******  started optimization at ' + time.strftime('%Y%m%d-%H%M') + ' *******')
     # the device loop covers the grids of the fused kernels (<= 32 x <= 32, <= 16 x <= 112: the reference's [10, 100] and BASELINE's

@@ -18,7 +18,7 @@ def predict_onoff(Xtrain, Xtest, checkpointPath, num_inducing_f=np.array([10, 10
     if os.path.isdir(ck):
         ck = os.path.join(ck, 'model')
     load_checkpoint(pset, ck)
-    eng = engine or zigp.DenseEngine(device)
+    eng = engine or zigp.reference_engine(device)      # tf.cholesky's acceptance rule (pivot > 0)
     p = engine_params(pset)
 
     def run(X):

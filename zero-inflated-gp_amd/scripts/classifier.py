@@ -38,7 +38,7 @@ def classifier(Xtrain, Ytrain, Xtest, Ytest, dir, num_iter=500, num_inducing_f=(
     logger.info('traning size   = ' + str(Xtrain.shape[0]))
     logger.info('test size   = ' + str(Xtest.shape[0]))
     pset = init_head_params(Xtrain, num_inducing_f, 'bernoulli', include_f_mu=include_f_mu, kmeans_seed=kmeans_seed)   # :56-112
-    eng = engine or zigp.DenseEngine(device)
+    eng = engine or zigp.reference_engine(device)      # tf.cholesky's acceptance rule (pivot > 0)
     ckpt = os.path.join(dir, 'model_scgp.ckpt')
     fit_head(pset, 'bernoulli', Xtrain, Ytrain_c, num_iter, num_minibatch, logger, ckpt=ckpt, eng=eng, history=history)   # :276-321
     log_kernel_summary(logger, pset)

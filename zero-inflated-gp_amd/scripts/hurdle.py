@@ -31,7 +31,7 @@ def hurdle(Xtrain, Ytrain, Xtest, Ytest, cresults, dir, num_iter=50000, num_indu
     logger.info('test size   = ' + str(Xtest.shape[0]))
     # inducing inputs are initialised from ALL training inputs (:79-80), the data iterator holds the "on" subset (:57)
     pset = init_head_params(Xtrain, num_inducing_f, 'gaussian', kmeans_seed=kmeans_seed)
-    eng = engine or zigp.DenseEngine(device)
+    eng = engine or zigp.reference_engine(device)      # tf.cholesky's acceptance rule (pivot > 0)
     ckpt = os.path.join(dir, 'model_hurdle.ckpt')
     fit_head(pset, 'gaussian', Xtr, Ytr, num_iter, min(num_minibatch, Xtr.shape[0]), logger, ckpt=ckpt, eng=eng, history=history)
     log_kernel_summary(logger, pset)

@@ -21,7 +21,7 @@ def svgp(Xtrain, Ytrain, Xtest, Ytest, dir, num_iter=50000, num_inducing_f=(10, 
     logger.info('test size   = ' + str(Xtest.shape[0]))
     logger.info('number of training examples:' + str(Xtrain.shape))
     pset = init_head_params(Xtrain, num_inducing_f, 'gaussian', kmeans_seed=kmeans_seed)       # :51-112
-    eng = engine or zigp.DenseEngine(device)
+    eng = engine or zigp.reference_engine(device)      # tf.cholesky's acceptance rule (pivot > 0)
     fit_head(pset, 'gaussian', Xtrain, Ytrain, num_iter, num_minibatch, logger, ckpt=os.path.join(dir, 'model') if dir else None,
              eng=eng, history=history)                                                          # :289-334
     log_kernel_summary(logger, pset)                                                            # :337-345

@@ -4,4 +4,4 @@ Python here is plumbing over the C-ABI in include/zigp.h (libzigp.so, hand-writt
 There is no CPU fallback: importing works anywhere, using an engine needs the built library and a GPU.
 """
 from ._lib import ZigpError, NotPositiveDefiniteError  # noqa: F401
-from .engine import DenseEngine, PARAM_KEYS  # noqa: F401
+from .engine import DenseEngine, PARAM_KEYS, reference_engine  # noqa: F401

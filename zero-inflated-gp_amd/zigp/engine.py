@@ -138,7 +138,10 @@ class KronStepper:
 
 
 class DenseEngine:
-    def __init__(self, device=0):
+    def __init__(self, device=0, pivot_rtol=None):
+        """pivot_rtol: smallest accepted Cholesky pivot as a multiple of eps * (variance + jitter).  None keeps the library default
+        (8: an exactly singular Kuu is reported whichever way its rounding-noise pivot falls); 0 is tf.cholesky's bare `pivot > 0` test
+        (onofftf/main.py:200,268,355) -- what the reference look-alikes use: reference_engine() below."""
         self.lib = _lib.load()
         self.ctx = C.c_void_p()
         rc = self.lib.zigp_create(C.byref(self.ctx), int(device))
@@ -149,6 +152,8 @@ class DenseEngine:
         self._full_N = 0
         self.D = 0
         self._keep = None
+        if pivot_rtol is not None:
+            self.set_pivot_rtol(pivot_rtol)
 
     def close(self):
         if self.ctx:
@@ -162,7 +167,8 @@ class DenseEngine:
             pass
 
     def set_chunk(self, rows):
-        _check(self.lib, self.ctx, self.lib.zigp_set_chunk(self.ctx, int(rows)))
+        """rows per pass (a multiple of 1024); None or 0: the library's automatic rule (see get_chunk_rows)"""
+        _check(self.lib, self.ctx, self.lib.zigp_set_chunk(self.ctx, int(rows or 0)))
 
     def get_chunk(self, M):
         """rows per pass of the dense path at M inducing points per latent (the set_chunk value, else the library's rule)"""
@@ -482,8 +488,9 @@ class DenseEngine:
             # include/zigp.h: after a failure x / m / v hold the state before the failing step and the history from that step on is NaN --
             # the caller learns how many updates WERE applied (its iteration count and Adam's bias correction depend on it) and gets the
             # history of those steps
-            fin = np.isfinite(ed)
-            done = 0 if (n == 0 or fin.all()) else int(np.argmin(fin))     # (all finite: the call failed before any step ran)
+            # (the count comes from the library -- zigp_kron_fit_steps_applied; the first non-finite history entry is NOT it: an applied
+            # step can itself have a non-finite ELBO at extreme parameters)
+            done = max(0, min(n, int(self.lib.zigp_kron_fit_steps_applied(self.ctx))))
             e.steps_applied = done
             e.elbo_data, e.kl = ed[:done].copy(), kl[:done].copy()
             raise
@@ -633,3 +640,11 @@ class DenseEngine:
         L, W = np.zeros((n, n)), np.zeros((n, n))
         _check(self.lib, self.ctx, self.lib.zigp_test_potrf_trtri(self.ctx, n, ptr(A), ptr(L), ptr(W), int(bool(split_k))))
         return L, W
+
+
+def reference_engine(device=0):
+    """The engine of the reference look-alikes (onoffgpf.OnOffSVGP, onofftf.onoff / predict_onoff, the likelihood heads): results identical
+    to the reference on the same inputs includes WHERE it fails -- tf.cholesky raises on a non-positive pivot only (onofftf/main.py:200,
+    268,355), so these run with zigp_set_pivot_rtol(ctx, 0).  The stricter default of the bare engine (8 eps (variance + jitter)) stays
+    one call away: engine.set_pivot_rtol(8)."""
+    return DenseEngine(device, pivot_rtol=0.0)

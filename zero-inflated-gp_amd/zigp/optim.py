@@ -93,10 +93,15 @@ class AdamGroups:
         self.v = {k: np.zeros(pset.params[k].value.size) for k in pset.names()}
         self.resync()
 
-    def resync(self):
+    def resync(self, reset=False):
         """Take the free vectors from the ParamSet again.  step() does this by itself for any parameter whose constrained value is no
         longer the one it wrote (load_checkpoint, an assignment to .value): the cached free vector would silently overwrite such a change.
-        The moments and the iteration count are kept."""
+        The moments and the iteration count are kept unless reset=True (parameters unrelated to the ones trained so far)."""
+        if reset:
+            self.t = 0
+            for k in self.m:
+                self.m[k][:] = 0.0
+                self.v[k][:] = 0.0
         self.x = {k: self.pset.params[k].free().copy() for k in self.pset.names()}
         self._written = {k: self.pset.params[k].value.copy() for k in self.pset.names()}
 
@@ -108,7 +113,7 @@ class AdamGroups:
             if k not in self.m:                                    # un-fixed since construction: it joins with fresh moments
                 self.m[k], self.v[k] = np.zeros(p.value.size), np.zeros(p.value.size)
                 self._written[k] = None
-            if self._written[k] is None or not np.array_equal(p.value, self._written[k]):   # changed behind our back: start from what the ParamSet holds now
+            if self._written[k] is None or not np.array_equal(p.value, self._written[k], equal_nan=True):   # changed behind our back: start from what the ParamSet holds now
                 self.x[k] = p.free().copy()
             x = self.x[k]
             g = -np.asarray(p.transform.grad_free(x, np.asarray(grads[k], dtype=np.float64).reshape(-1))).reshape(-1)

@@ -128,6 +128,15 @@ class _Sharded:
                     self.library_comm = False
             elif (info['rank'], info['nranks']) != (self.rank, self.world):       # another wrapper of this engine set it up
                 raise ValueError('engine already has a communicator for rank %d of %d' % (info['rank'], info['nranks']))
+        elif dist is not None and hasattr(engine, 'comm_info'):
+            # An engine that OWNS a communicator (another wrapper formed it) sums every result block over the ranks inside the library,
+            # whatever this wrapper was asked for: reducing its results once more on the host would return world x the sums, silently.
+            info = engine.comm_info()
+            if info['nranks'] > 0:
+                if (info['rank'], info['nranks']) != (self.rank, self.world):
+                    raise ValueError('engine already has a communicator for rank %d of %d (this wrapper: rank %d of %d)'
+                                     % (info['rank'], info['nranks'], self.rank, self.world))
+                self.library_comm = True           # results arrive summed; never host-reduce them again
 
     def _agree(self, ok):
         """True when every rank says ok (MIN over ranks through torch.distributed)"""
