@@ -39,6 +39,12 @@ int zigp_clock_stamp(zigp_ctx* ctx, int64_t* out /*[24]*/);
 /* Kronecker entry points: on != 0 forces the GEMM-panel path (zigp_kron.hip) also for grids the fused register-resident kernels
  * (zigp_kronf.hip) cover -- two independent implementations of the same factored algebra that the tests check against each other. */
 int zigp_set_kron_panels(zigp_ctx* ctx, int32_t on);
+/* Host only -- no context, no GPU: builds the tile lists the chunk loop launches for its triangular products (lower: A1 = W K, else
+ * A2 = W^T A1) of a chunk of Nc rows (a multiple of 128) with Mf / Mg inducing points, exactly as chunk_forward does (paired order, merged
+ * launch, LPT tail of a last wave that is not full when tail_on), and checks them: every (row block, column panel) tile exactly once, with
+ * the whole k range of its row block.  out[8] = {workgroups of latent f's list, of latent g's, entries per workgroup f, g, tail units f, g,
+ * largest tail workgroup in k blocks, paired order (0 / 1)}.  Returns 0, ZIGP_EARG, or -10 ... -13 for a list that is not a partition. */
+int zigp_test_trmm_list(int32_t lower, int32_t Mf, int32_t Mg, int64_t Nc, int32_t tail_on, int64_t* out);
 /* The gradient step of the larger fused grids (<= 16 x <= 112 points) sends its rows through in ranges of `tiles` 16-point tiles
  * (default 1024 = 16 384 rows: the per-point operand records of a range stay within 128 MB).  Results do not depend on it, bit for bit;
  * the tests lower it to run many ranges on small inputs. */

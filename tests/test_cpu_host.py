@@ -712,3 +712,36 @@ def test_classifier_scores_match_sklearn():
     acc, prec, rec, auc = _scores(p.reshape(-1, 1), y.reshape(-1, 1))
     assert abs(acc - accuracy_score(y, p > 0.5)) < 1e-15 and abs(prec - precision_score(y, p > 0.5)) < 1e-15
     assert abs(rec - recall_score(y, p > 0.5)) < 1e-15 and abs(auc - roc_auc_score(y, p)) < 1e-12
+
+
+def test_triangular_tile_lists_are_partitions_with_and_without_the_lpt_tail():
+    """The chunk loop's triangular products run host-built tile lists (paired units, both latents in one launch; since round 6 the last,
+    partly filled wave re-dealt longest-first -- zigp_host.h tiles_trmm / trmm_tail_plan).  zigp_test_trmm_list rebuilds them on the host,
+    as chunk_forward does, and checks that every (row block, column panel) tile occurs exactly once with the whole k range of its row
+    block -- for the bench configurations and a sweep of ragged shapes; no GPU involved."""
+    import ctypes as C
+    from zigp import _lib
+    lib = _lib.load()
+    out = (C.c_int64 * 8)()
+    shapes = [(512, 512, 100352), (1024, 1024, 125952), (1024, 1024, 32768), (1024, 1024, 17408), (300, 520, 38912), (2048, 1100, 27648),
+              (9, 9, 1024), (520, 100, 2048), (1024, 1024, 131072), (640, 128, 65536)]
+    rs = np.random.RandomState(3)
+    shapes += [(int(rs.randint(1, 2300)), int(rs.randint(1, 2300)), 1024 * int(rs.randint(1, 129))) for _ in range(60)]
+    tails = 0
+    for Mf, Mg, Nc in shapes:
+        for lower in (1, 0):
+            res = {}
+            for tail in (0, 1):
+                assert lib.zigp_test_trmm_list(lower, Mf, Mg, Nc, tail, out) == 0, (Mf, Mg, Nc, lower, tail)
+                res[tail] = list(out)
+            plain, lpt = res[0], res[1]
+            assert plain[4] == plain[5] == 0
+            if lpt[4] or lpt[5]:                                   # a tail was planned: one wave of at most 512 workgroups replaces r + 512 units
+                tails += 1
+                assert lpt[7] == 1 and (lpt[0] + lpt[1]) % 512 == 0 and lpt[0] + lpt[1] < plain[0] + plain[1]
+                nbm = max((Mf + 127) // 128, (Mg + 127) // 128)
+                assert 0 < lpt[6] < 2 * (nbm + 1)                  # shorter than the two lockstep waves it replaces
+            else:
+                assert lpt[:4] == plain[:4]
+    assert tails >= 8                                              # the sweep does exercise the tail (cfg2 and the 125 952-row shard among them)
+    assert lib.zigp_test_trmm_list(1, 512, 512, 1000, 1, out) == _lib.ZIGP_EARG      # Nc must be a multiple of 128

@@ -175,6 +175,17 @@ int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, i
   return 0;
 }
 
+// Tile order of the chunk's two triangular products: paired units + merged launch where both latents' units fill waves of the 512 slots
+// (trmm_paired_pays), and then the plan for a last wave that is not full (trmm_tail_plan; merged launch = [latent f's units | latent g's
+// units], unit counts multiples of 8).  Returns `paired`.
+bool chunk_trmm_plan(int Mp0, int Mp1, int nbn, bool tail_on, TrmmTail& tail) {
+  const int u0 = ((nbn + 7) / 8) * 8 * ((Mp0 / BM + 1) / 2), u1 = ((nbn + 7) / 8) * 8 * ((Mp1 / BM + 1) / 2);
+  const bool paired = trmm_paired_pays(nbn * ((Mp0 / BM + 1) / 2 + (Mp1 / BM + 1) / 2));
+  tail = TrmmTail{{0, 0}, {64, 64}};
+  if (paired && tail_on) tail = trmm_tail_plan(u0, Mp0 / BM, u1, Mp1 / BM);
+  return paired;
+}
+
 // Forward panels of both latents for one chunk: A1, A2 (+ J' when a gradient is wanted), column partials.
 // Where the triangular products run the paired order (trmm_paired_pays: cfg3, cfg2), each product class is ONE launch for both latents
 // (run_gemm2: latent g's workgroups fill the tail of latent f's, three launch boundaries fewer per chunk; cfg3 -0.4 ... -0.8 % same-box,
@@ -183,12 +194,8 @@ int latent_chunk_kuf(zigp_ctx* c, Latent& lt, const double* dX, int64_t Nrows, i
 int chunk_forward(zigp_ctx* c, int64_t Nc, bool need_grad, const PwArgs* fuse_pw = nullptr, bool* fused = nullptr, const std::function<int()>& after_a1 = nullptr) {
   const int nbn = (int)(Nc / BN);
   struct Set { TileList tl, tu, tf; double fl; GemmArgs a1, a2, j; EpiStoreColsum e1; EpiColsum e2; } q[2];
-  const bool paired = trmm_paired_pays(nbn * ((c->lat[0].Mp / BM + 1) / 2 + (c->lat[1].Mp / BM + 1) / 2)), merge = paired;
-  // merged launch = [latent f's units | padding to a multiple of 8 | latent g's units]: a last wave that is not full is re-dealt inside
-  // latent g's list (tiles_trmm: LPT tail)
-  TrmmTail tail = {{0, 0}, {64, 64}};
-  if (merge && c->trmm_tail)
-    tail = trmm_tail_plan(((nbn + 7) / 8) * 8 * ((c->lat[0].Mp / BM + 1) / 2), c->lat[0].Mp / BM, ((nbn + 7) / 8) * 8 * ((c->lat[1].Mp / BM + 1) / 2), c->lat[1].Mp / BM);
+  TrmmTail tail;
+  const bool paired = chunk_trmm_plan(c->lat[0].Mp, c->lat[1].Mp, nbn, c->trmm_tail, tail), merge = paired;
   for (int h = 0; h < 2; ++h) {
     Latent& lt = c->lat[h];
     const int Mp = lt.Mp, nbm = Mp / BM;
@@ -1011,6 +1018,41 @@ int zigp_test_kuf(zigp_ctx* c, int64_t N, int32_t M, int32_t D, const double* X,
   dx.release(); dz.release(); dk.release();
   if (rc) return rc;
   for (int m = 0; m < M; ++m) memcpy(K + (size_t)m * N, &hk[(size_t)m * Nc], sizeof(double) * N);
+  return ZIGP_OK;
+}
+
+int zigp_test_trmm_list(int32_t lower, int32_t Mf, int32_t Mg, int64_t Nc, int32_t tail_on, int64_t* out) {
+  // host only (no context, no GPU): the lists chunk_forward would launch for a chunk of Nc rows, checked tile by tile
+  if (Mf <= 0 || Mg <= 0 || Nc <= 0 || Nc % BN != 0 || !out) return ZIGP_EARG;
+  const int Mp[2] = {(int)round_up(Mf, BM), (int)round_up(Mg, BM)}, nbn = (int)(Nc / BN), kb = BM / BK;
+  TrmmTail tail;
+  const bool paired = chunk_trmm_plan(Mp[0], Mp[1], nbn, tail_on != 0, tail);
+  int64_t wgs[2], per[2], worst_tail = 0;
+  for (int h = 0; h < 2; ++h) {
+    const int nbm = Mp[h] / BM;
+    std::vector<GemmTile> v;
+    per[h] = build_trmm_list(lower != 0, nbm, nbn, paired, tail.units[h], tail.bins[h], v);
+    if (v.size() % (size_t)per[h]) return -10;
+    wgs[h] = (int64_t)(v.size() / per[h]);
+    std::vector<int> seen((size_t)nbm * nbn, 0);
+    for (const GemmTile& t : v) {
+      if (t.kend <= t.kbeg) continue;                                   // padding
+      if (t.bi < 0 || t.bi >= nbm || t.bj < 0 || t.bj >= nbn) return -11;
+      const int k0 = lower ? 0 : t.bi * kb, k1 = lower ? (t.bi + 1) * kb : nbm * kb;
+      if (t.kbeg != k0 || t.kend != k1 || (t.kdir != 1 && t.kdir != -1) || t.slice != 0) return -12;   // the whole k range of its row block, nothing else
+      seen[(size_t)t.bi * nbn + t.bj] += 1;
+    }
+    for (int q : seen) if (q != 1) return -13;                          // every tile exactly once
+    if (paired && tail.units[h] > 0) {                                  // workgroups behind the regular units: the LPT tail
+      const int64_t regular = wgs[h] - 8 * (int64_t)std::min(64, tail.bins[h]);
+      for (int64_t w = std::max<int64_t>(regular, 0); w < wgs[h]; ++w) {
+        int64_t load = 0;
+        for (int e = 0; e < per[h]; ++e) { const GemmTile& t = v[(size_t)w * per[h] + e]; load += std::max(0, t.kend - t.kbeg) / kb; }
+        worst_tail = std::max(worst_tail, load);
+      }
+    }
+  }
+  out[0] = wgs[0]; out[1] = wgs[1]; out[2] = per[0]; out[3] = per[1]; out[4] = tail.units[0]; out[5] = tail.units[1]; out[6] = worst_tail; out[7] = paired ? 1 : 0;
   return ZIGP_OK;
 }
 

@@ -163,15 +163,14 @@ static inline int trmm_tail_makespan(int nbm, int tail_units_per_xcd, int bins) 
   for (int l : len) *std::min_element(load.begin(), load.end()) += l;
   return *std::max_element(load.begin(), load.end());
 }
-static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, bool paired, TileList& tl, int tail_units = 0, int tail_bins = 64) {
+// the list itself (host only: zigp_test_trmm_list checks its coverage without a GPU); returns the entries per workgroup
+static int build_trmm_list(bool lower, int nbm, int nbn, bool paired, int tail_units, int tail_bins, std::vector<GemmTile>& v) {
   const int kb = BM / BK;
-  const std::string key = std::string(lower ? "trl:" : "tru:") + std::to_string(nbm) + ":" + std::to_string(nbn) + (paired ? ":p" : ":l") +
-                          (tail_units > 0 ? ":t" + std::to_string(tail_units) + ":" + std::to_string(tail_bins) : std::string());
-  if (!paired)
-    return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
-      if (lower) { for (int bi = nbm - 1; bi >= 0; --bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, (bi + 1) * kb)); }
-      else { for (int bi = 0; bi < nbm; ++bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * kb, nbm * kb)); }
-    }, tl, 1);
+  if (!paired) {
+    if (lower) { for (int bi = nbm - 1; bi >= 0; --bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, 0, (bi + 1) * kb)); }
+    else { for (int bi = 0; bi < nbm; ++bi) for (int bj = 0; bj < nbn; ++bj) v.push_back(mk_tile(bi, bj, bi * kb, nbm * kb)); }
+    return 1;
+  }
   // per-XCD queues of units (2 entries each); a tail is re-dealt per queue into <= 64 workgroups of up to `per` entries
   const int U = (nbm + 1) / 2;
   auto tile = [&](int bi, int bj, int dir) {
@@ -219,7 +218,7 @@ static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, bool paired, Ti
       for (const auto& b : bins[x]) per = std::max(per, (int)b.size());
     }
   }
-  return get_tiles(c, key, [&](std::vector<GemmTile>& v) {
+  {
     size_t reg = 0, nb = 0;
     for (int x = 0; x < 8; ++x) { reg = std::max(reg, q[x].size() / 2); nb = std::max(nb, bins[x].size()); }
     for (size_t i = 0; i < reg; ++i)                         // launch position p = 8 * i + x  ->  XCD x
@@ -228,7 +227,17 @@ static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, bool paired, Ti
     for (size_t i = 0; i < nb; ++i)
       for (int x = 0; x < 8; ++x)
         for (int e = 0; e < per; ++e) v.push_back(i < bins[x].size() && e < (int)bins[x][i].size() ? bins[x][i][e] : mk_tile(0, 0, 0, 0));
-  }, tl, per);
+  }
+  return per;
+}
+static int tiles_trmm(zigp_ctx* c, bool lower, int nbm, int nbn, bool paired, TileList& tl, int tail_units = 0, int tail_bins = 64) {
+  const std::string key = std::string(lower ? "trl:" : "tru:") + std::to_string(nbm) + ":" + std::to_string(nbn) + (paired ? ":p" : ":l") +
+                          (tail_units > 0 ? ":t" + std::to_string(tail_units) + ":" + std::to_string(tail_bins) : std::string());
+  auto it = c->tiles.find(key);
+  if (it != c->tiles.end()) { tl = it->second; return 0; }
+  std::vector<GemmTile> list;
+  const int per = build_trmm_list(lower, nbm, nbn, paired, tail_units, tail_bins, list);
+  return get_tiles(c, key, [&](std::vector<GemmTile>& v) { v = list; }, tl, per);
 }
 // The paired order has nbn * ceil(nbm / 2) units of EQUAL length per latent: it pays (2.2x fewer bytes, +6 % on the triangular
 // products) where the units of BOTH latents, launched together (run_gemm2), fill whole waves of the 512 resident workgroups --

@@ -89,6 +89,7 @@ SIGNATURES = {
     'zigp_kron_fit_steps': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), C.POINTER(zigp_kron_fit_opts), dp, dp, dp, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_void_p, C.c_int64, dp, dp, C.c_double, C.c_double, C.c_int32, dp, dp]),
     'zigp_kron_fit_steps_applied': (C.c_int64, [C.c_void_p]),
+    'zigp_test_trmm_list': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
     'zigp_kron_predict': (C.c_int, [C.c_void_p, C.POINTER(zigp_kron_params), dp, C.c_int64, C.c_double, C.c_double, C.c_double, dp]),
     'zigp_get_chunk': (C.c_int64, [C.c_void_p, C.c_int32]),
     'zigp_get_chunk_rows': (C.c_int64, [C.c_void_p, C.c_int32, C.c_int64]),
