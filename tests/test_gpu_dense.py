@@ -149,6 +149,19 @@ def test_value_only_and_no_kl(engine):
     ed2, kl2, _ = engine.elbo(p, include_kl=False, need_grad=False)
     assert kl2 == 0.0 and ed2 == ed
     assert np.allclose(engine.prior_kl(p), [klf, klg], rtol=1e-9)
+    # value-only and predict passes over several chunks: with the stream overlap the next chunk's Kuf panels are built on the side stream
+    # right behind this chunk's A1 (r6) -- the same kernels in another order of independent work, so the results are the same bits
+    X3, Y3, p3 = make_problem(5000, 150, 3, seed=6, Mg=70)
+    engine.set_chunk(1024)                                  # five passes, the last one partial
+    engine.set_data(X3, Y3)
+    on = (engine.elbo(p3, need_grad=False), engine.predict(p3, X3))
+    engine.set_overlap(False)
+    off = (engine.elbo(p3, need_grad=False), engine.predict(p3, X3))
+    engine.set_overlap(True)
+    assert on[0][0] == off[0][0] and on[0][1] == off[0][1] and np.array_equal(on[1], off[1])
+    e3 = o.elbo(X3, Y3, p3, 1e-6)
+    assert abs(on[0][0] - e3[1]) < 1e-8 * abs(e3[1])
+    engine.set_chunk(16384)
 
 
 def test_row_shards_sum_to_full(engine):
